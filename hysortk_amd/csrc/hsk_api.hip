@@ -1,0 +1,1069 @@
+// hsk_api.hip -- host orchestration + C ABI of libhsk.so (see include/hsk.h).
+//
+// One translation unit, compiled with `hipcc --offload-arch=gfx950`.  The pipeline behind
+// hsk_count() / hsk_count_device():
+//
+//   parse COUNT -> scan -> parse EMIT          (hsk_parse.h)   reads -> per-task supermers
+//   [RCCL all-to-all of supermers]             (hsk_comm.h)    multi-GPU only
+//   per owned task, ascending id:
+//     expand (tile sums, scan, extract)        (hsk_expand.h)  supermers -> canonical k-mers
+//     hist + onesweep passes                   (hsk_sort.h)    LSD radix sort
+//     count COUNT -> scan -> EMIT              (hsk_count.h)   merge-count + [L,U] filter
+//   result assembly (pinned host memory)
+//
+// There is no CPU fallback anywhere in this file: without a gfx950 device hsk_init() fails.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hsk.h"
+#include "hsk_device.h"
+#include "hsk_parse.h"
+#include "hsk_expand.h"
+#include "hsk_sort.h"
+#include "hsk_count.h"
+#include "hsk_synth.h"
+#include "hsk_plan.h"
+#include "hsk_comm.h"
+
+using namespace hsk;
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct DevPool {
+    // freed blocks are kept and reused (hipMalloc/hipFree of multi-GB buffers costs milliseconds
+    // and synchronises the device); exact-fit-or-slightly-larger reuse, trimmed on OOM/destroy.
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    size_t bytes_live = 0, bytes_cached = 0, peak = 0;
+    void *alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            void *p = it->second; size_t sz = it->first;
+            free_blocks.erase(it); bytes_cached -= sz;
+            live[p] = sz; bytes_live += sz; peak = std::max(peak, bytes_live);
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            trim();
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        live[p] = bytes; bytes_live += bytes; peak = std::max(peak, bytes_live);
+        return p;
+    }
+    void release(void *p)
+    {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.insert({it->second, p}); bytes_cached += it->second; bytes_live -= it->second;
+        live.erase(it);
+    }
+    void trim()
+    {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear(); bytes_cached = 0;
+    }
+    void destroy()
+    {
+        trim();
+        for (auto &kv : live) (void)hipFree(kv.first);
+        live.clear(); bytes_live = 0;
+    }
+};
+
+struct EvPair { hipEvent_t a, b; int kind; u64 keys; u64 bytes; };
+
+struct hsk_ctx {
+    hsk_config cfg;
+    int nw = 1;
+    hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;
+    DevPool pool;
+    char err[512] = {0};
+    hsk_stats stats;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<EvPair> ev_pending;
+    void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
+    u32 *d_err = nullptr;
+    Comm comm;
+};
+
+static int fail(hsk_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, HSK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define DALLOC(c, ptr, type, bytes)                                                              \
+    do {                                                                                         \
+        ptr = (type)(c)->pool.alloc(bytes);                                                      \
+        if (!ptr) return fail(c, HSK_ERR_OOM, "device allocation of %zu bytes failed (%s:%d)", (size_t)(bytes), __FILE__, __LINE__); \
+    } while (0)
+
+static hipEvent_t ev_get(hsk_ctx *c)
+{
+    if (!c->ev_free.empty()) { hipEvent_t e = c->ev_free.back(); c->ev_free.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+static void ev_put(hsk_ctx *c, hipEvent_t e) { c->ev_free.push_back(e); }
+
+// phase timer: records an event pair on the stream, elapsed time is summed after the final sync
+struct PhaseTimer {
+    hsk_ctx *c; std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[8];
+    explicit PhaseTimer(hsk_ctx *c_) : c(c_) {}
+    void begin(int ph) { hipEvent_t a = ev_get(c); (void)hipEventRecord(a, c->stream); pairs[ph].push_back({a, nullptr}); }
+    void end(int ph) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream); pairs[ph].back().second = b; }
+    double collect(int ph)
+    {
+        double ms = 0;
+        for (auto &p : pairs[ph]) {
+            float f = 0;
+            if (p.second && hipEventElapsedTime(&f, p.first, p.second) == hipSuccess) ms += f;
+            ev_put(c, p.first); if (p.second) ev_put(c, p.second);
+        }
+        pairs[ph].clear();
+        return ms;
+    }
+};
+enum { PH_TOTAL = 0, PH_PARSE, PH_EXCH, PH_EXTRACT, PH_SORT, PH_COUNT, PH_D2H };
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" int hsk_abi_version(void) { return HSK_ABI_VERSION; }
+
+extern "C" const char *hsk_strerror(int s)
+{
+    switch (s) {
+    case HSK_OK: return "ok";
+    case HSK_ERR_INVALID_ARG: return "invalid argument";
+    case HSK_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+    case HSK_ERR_HIP: return "HIP runtime error";
+    case HSK_ERR_OOM: return "out of memory";
+    case HSK_ERR_DISPATCH: return "Cannot dispatch tasks. May be too unbalanced.";
+    case HSK_ERR_INTERNAL: return "internal device-side check failed";
+    case HSK_ERR_COMM: return "RCCL communication error";
+    case HSK_ERR_UNSUPPORTED: return "not supported";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *hsk_last_error(const hsk_ctx *c) { return c ? c->err : ""; }
+
+extern "C" void hsk_config_default(hsk_config *cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->kmer_size = 31; cfg->minimizer_size = 17; cfg->lower_freq = 15; cfg->upper_freq = 40;   // reference Makefile:1-8
+    cfg->extension = 0; cfg->ntasks = 0; cfg->device = 0; cfg->plain_dispatcher = 0;
+    cfg->dispatch_upper_coe = 1.5; cfg->dispatch_step = 0.05; cfg->radix_bits = 8; cfg->flags = 0;
+}
+
+static int validate_cfg(const hsk_config *cfg)
+{
+    const int K = cfg->kmer_size, M = cfg->minimizer_size;
+    if (!(2 < K && K < 96) || (K % 32) == 0) return 0;            // compiletime.h:10; K%32==0 is UB in the reference
+    if (!(0 < M && M < K) || M > 31) return 0;                      // Makefile:50-52
+    if (!(0 < cfg->lower_freq && cfg->lower_freq <= cfg->upper_freq && cfg->upper_freq <= 65535)) return 0;  // compiletime.h:21
+    if (cfg->extension != 0 && cfg->extension != 1) return 0;
+    if (cfg->ntasks < 0 || cfg->ntasks > HSK_MAX_TASKS) return 0;
+    if (cfg->radix_bits != 0 && (cfg->radix_bits < 4 || cfg->radix_bits > 8)) return 0;
+    return 1;
+}
+
+extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
+{
+    if (!cfg || !out) return HSK_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!validate_cfg(cfg)) return HSK_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return HSK_ERR_NO_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) return HSK_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return HSK_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HSK_ERR_NO_DEVICE;    // kernels are built for gfx950 only
+    hsk_ctx *c = new hsk_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.radix_bits == 0) c->cfg.radix_bits = 8;
+    if (c->cfg.dispatch_upper_coe <= 0) c->cfg.dispatch_upper_coe = 1.5;
+    if (c->cfg.dispatch_step <= 0) c->cfg.dispatch_step = 0.05;
+    c->nw = (cfg->kmer_size + 31) / 32;
+    memset(&c->stats, 0, sizeof c->stats);
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HSK_ERR_HIP; }
+    c->pinned_bytes = 1 << 20;
+    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) { delete c; return HSK_ERR_OOM; }
+    c->d_err = (u32 *)c->pool.alloc(256);
+    if (!c->d_err) { delete c; return HSK_ERR_OOM; }
+    (void)hipMemsetAsync(c->d_err, 0, 256, c->stream);
+    *out = c;
+    return HSK_OK;
+}
+
+extern "C" void hsk_destroy(hsk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    c->comm.destroy();
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    for (auto &p : c->ev_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    c->pool.destroy();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    delete c;
+}
+
+static void drain_profile_events(hsk_ctx *c)
+{
+    for (auto &p : c->ev_pending) {
+        float f = 0;
+        if (hipEventElapsedTime(&f, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) { c->stats.scatter_launches++; c->stats.scatter_keys += p.keys; c->stats.scatter_bytes += p.bytes; c->stats.scatter_ms += f; }
+            else { c->stats.hist_launches++; c->stats.hist_bytes += p.bytes; c->stats.hist_ms += f; }
+        }
+        ev_put(c, p.a); ev_put(c, p.b);
+    }
+    c->ev_pending.clear();
+}
+
+extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
+{
+    if (!c || !out) return HSK_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    drain_profile_events(c);
+    *out = c->stats;
+    if (reset) memset(&c->stats, 0, sizeof c->stats);
+    return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: parse (a4, a5, a6)
+// ------------------------------------------------------------------------------------------------
+struct SupermerStore {
+    u32 ntasks = 0, nblocks = 0;
+    u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
+    u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
+    std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
+    std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
+    std::vector<u32> order;       // storage order of tasks (grouped by owner rank, ascending id)
+};
+
+static void free_store(hsk_ctx *c, SupermerStore &s)
+{
+    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid);
+    s.sm_len = s.sm_bytes = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr;
+}
+
+static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen,
+                                 u64 nreads, int64_t rid_base, u32 ntasks, u32 *nblocks_out)
+{
+    ParseArgs a; memset(&a, 0, sizeof a);
+    a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
+    a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks);
+    a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
+    u32 nblocks = (u32)std::min<u64>(a.ntiles, 1024);
+    a.tiles_per_block = (u32)((a.ntiles + nblocks - 1) / nblocks);
+    nblocks = (u32)((a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block);
+    a.rid_base = rid_base;
+    *nblocks_out = nblocks;
+    return a;
+}
+
+// COUNT + scan + EMIT.  `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
+static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                       int64_t rid_base, u32 ntasks, const std::vector<u32> &order, SupermerStore &st)
+{
+    const bool ext = c->cfg.extension != 0;
+    u32 nblocks = 0;
+    ParseArgs a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &nblocks);
+    st.ntasks = ntasks; st.nblocks = nblocks; st.order = order;
+    u64 *d_blk_cnt, *d_blk_base, *d_task_tot, *d_task_base; u32 *d_order;
+    DALLOC(c, d_blk_cnt, u64 *, (size_t)nblocks * ntasks * 3 * 8);
+    DALLOC(c, d_blk_base, u64 *, (size_t)nblocks * ntasks * 2 * 8);
+    DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8);
+    DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
+    DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
+    HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
+    a.blk_cnt = d_blk_cnt;
+    if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
+    else hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, d_blk_cnt, nblocks, ntasks, d_order, d_task_tot, d_task_base, d_blk_base);
+    st.task_tot.resize((size_t)ntasks * 3); st.task_base.resize((size_t)ntasks * 3);
+    HIPCHK(c, hipMemcpyAsync(st.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.task_base.data(), d_task_base, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st.tot_sup = st.tot_bytes = st.tot_kmers = 0;
+    for (u32 t = 0; t < ntasks; ++t) { st.tot_sup += st.task_tot[3 * t]; st.tot_bytes += st.task_tot[3 * t + 1]; st.tot_kmers += st.task_tot[3 * t + 2]; }
+    DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
+    DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
+    if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
+    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_bytes = st.sm_bytes; a.sm_pos = st.sm_pos; a.sm_rid = st.sm_rid;
+    if (st.tot_sup) {
+        if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 2 * 8, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 2 * 8, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
+    // every later user of these blocks is enqueued on the same stream)
+    c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order);
+    return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: expand one task (a11)
+// ------------------------------------------------------------------------------------------------
+struct TaskSegs { std::vector<ExpSeg> segs; u64 ntiles = 0; u64 nkmers = 0; };
+
+static void finalize_segs(TaskSegs &ts)
+{
+    u64 tile = 0;
+    for (auto &s : ts.segs) { s.tile_start = tile; tile += (s.n_sup + EXP_TILE - 1) / EXP_TILE; }
+    ts.ntiles = tile;
+}
+
+template <int NW>
+static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const u8 *sm_bytes, const u32 *sm_pos, const int32_t *sm_rid,
+                       u64 *d_keys, u64 *d_vals)
+{
+    if (ts.ntiles == 0) return HSK_OK;
+    const bool ext = c->cfg.extension != 0;
+    const int nseg = (int)ts.segs.size();
+    ExpSeg *d_segs; u64 *d_tile_sum, *d_tile_off;
+    DALLOC(c, d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
+    DALLOC(c, d_tile_sum, u64 *, ts.ntiles * 16);
+    DALLOC(c, d_tile_off, u64 *, ts.ntiles * 16);
+    HIPCHK(c, hipMemcpyAsync(d_segs, ts.segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
+    // (ts.segs is host memory owned by the caller and stays alive until the next sync)
+    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len, c->cfg.kmer_size, d_tile_sum);
+    hipLaunchKernelGGL(expand_scan_kernel, dim3(nseg), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, ts.ntiles, d_tile_sum, d_tile_off);
+    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len,
+                                (const u64 *)sm_bytes, sm_pos, sm_rid, d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
+    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len,
+                            (const u64 *)sm_bytes, sm_pos, sm_rid, d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(d_segs); c->pool.release(d_tile_sum); c->pool.release(d_tile_off);
+    return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: sort one task (a12)
+// ------------------------------------------------------------------------------------------------
+// Digit plan: the key is the little-endian integer formed by words 0..NW-1; word w carries
+// min(32, K-32w) bases in its top bits.  Digits are taken from the least significant used bit up.
+static int make_pass_plan(int K, int nw, int rb, PassDesc *out)
+{
+    int np = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int nbases = std::min(32, K - 32 * w);
+        int lo = 64 - 2 * nbases;
+        while (lo < 64) { int bits = std::min(rb, 64 - lo); out[np++] = PassDesc{w, lo, bits}; lo += bits; }
+    }
+    return np;
+}
+
+struct SortScratch {
+    u64 *ghist = nullptr;      // [MAX_PASSES][256]
+    u64 *gbase = nullptr;      // [MAX_PASSES][256]
+    void *lookback = nullptr; size_t lookback_bytes = 0;
+    u32 *tickets = nullptr;    // [MAX_PASSES]
+};
+
+template <int NW, bool HAS_VAL, typename LB>
+static void launch_onesweep(hsk_ctx *c, const SortArgs &a, u32 ntiles)
+{
+    hipLaunchKernelGGL((onesweep_kernel<NW, HAS_VAL, LB>), dim3(ntiles), dim3(SORT_THREADS), 0, c->stream, a);
+}
+
+// Sorts n records in bufA (keys) / valA using bufB / valB as the ping-pong buffer.  On return
+// *out_keys / *out_vals point at whichever buffer holds the sorted data.
+template <int NW>
+static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 *valsB, u64 n, int K, SortScratch &sc,
+                            u64 **out_keys, u64 **out_vals)
+{
+    *out_keys = keysA; *out_vals = valsA;
+    if (n < 2) return HSK_OK;
+    const bool has_val = valsA != nullptr;
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    HistArgs h; memset(&h, 0, sizeof h);
+    h.keys = keysA; h.n = n; h.npass = make_pass_plan(K, NW, c->cfg.radix_bits, h.pass); h.ghist = sc.ghist;
+    HIPCHK(c, hipMemsetAsync(sc.ghist, 0, (size_t)MAX_PASSES * 256 * 8, c->stream));
+    const u32 hblocks = (u32)std::min<u64>((n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16), 2048);
+    EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 1; hp.bytes = n * NW * 8; (void)hipEventRecord(hp.a, c->stream); }
+    hipLaunchKernelGGL((hist_kernel<NW>), dim3(hblocks), dim3(SORT_THREADS), (size_t)h.npass * 256 * 4, c->stream, h);
+    if (profile) { (void)hipEventRecord(hp.b, c->stream); c->ev_pending.push_back(hp); }
+    u64 *hh = (u64 *)c->pinned;                          // [npass][256] histogram, then [npass][256] bases
+    HIPCHK(c, hipMemcpyAsync(hh, sc.ghist, (size_t)h.npass * 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 *hb = hh + (size_t)MAX_PASSES * 256;
+    std::vector<int> todo;
+    for (int p = 0; p < h.npass; ++p) {
+        bool trivial = false; u64 run = 0;
+        for (int d = 0; d < 256; ++d) { if (hh[p * 256 + d] == n) trivial = true; hb[p * 256 + d] = run; run += hh[p * 256 + d]; }
+        if (!trivial) todo.push_back(p);
+    }
+    if (todo.empty()) return HSK_OK;
+    HIPCHK(c, hipMemcpyAsync(sc.gbase, hb, (size_t)h.npass * 256 * 8, hipMemcpyHostToDevice, c->stream));
+    constexpr int TILE = SortTile<NW>::TILE;
+    const u32 ntiles = (u32)((n + TILE - 1) / TILE);
+    const bool wide = n >= (1ULL << 30);
+    const size_t lbw = wide ? 8 : 4;
+    const size_t need = (size_t)todo.size() * ntiles * 256 * lbw;
+    if (need > sc.lookback_bytes) {
+        c->pool.release(sc.lookback);
+        sc.lookback = c->pool.alloc(need); sc.lookback_bytes = need;
+        if (!sc.lookback) { sc.lookback_bytes = 0; return fail(c, HSK_ERR_OOM, "look-back table of %zu bytes", need); }
+    }
+    HIPCHK(c, hipMemsetAsync(sc.lookback, 0, need, c->stream));
+    HIPCHK(c, hipMemsetAsync(sc.tickets, 0, MAX_PASSES * 4, c->stream));
+    u64 *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
+    for (size_t i = 0; i < todo.size(); ++i) {
+        const int p = todo[i];
+        SortArgs a; memset(&a, 0, sizeof a);
+        a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout; a.n = n;
+        a.word = h.pass[p].word; a.shift = h.pass[p].shift; a.bits = h.pass[p].bits;
+        a.gbase = sc.gbase + (size_t)p * 256;
+        a.lookback = (char *)sc.lookback + i * (size_t)ntiles * 256 * lbw;
+        a.ticket = sc.tickets + i; a.err = c->d_err;
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = n; ep.bytes = 2 * n * (NW * 8 + (has_val ? 8 : 0)); (void)hipEventRecord(ep.a, c->stream); }
+        if (has_val) { if (wide) launch_onesweep<NW, true, u64>(c, a, ntiles); else launch_onesweep<NW, true, u32>(c, a, ntiles); }
+        else { if (wide) launch_onesweep<NW, false, u64>(c, a, ntiles); else launch_onesweep<NW, false, u32>(c, a, ntiles); }
+        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+        std::swap(kin, kout); std::swap(vin, vout);
+    }
+    HIPCHK(c, hipGetLastError());
+    *out_keys = kin; *out_vals = vin;
+    return HSK_OK;
+}
+
+static int alloc_sort_scratch(hsk_ctx *c, SortScratch &sc)
+{
+    DALLOC(c, sc.ghist, u64 *, (size_t)MAX_PASSES * 256 * 8);
+    DALLOC(c, sc.gbase, u64 *, (size_t)MAX_PASSES * 256 * 8);
+    DALLOC(c, sc.tickets, u32 *, 256);
+    return HSK_OK;
+}
+static void free_sort_scratch(hsk_ctx *c, SortScratch &sc)
+{
+    c->pool.release(sc.ghist); c->pool.release(sc.gbase); c->pool.release(sc.tickets); c->pool.release(sc.lookback);
+    sc = SortScratch();
+}
+
+static int check_device_error(hsk_ctx *c)
+{
+    u32 *e = (u32 *)((char *)c->pinned + c->pinned_bytes - 64);
+    HIPCHK(c, hipMemcpyAsync(e, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*e) {
+        (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+        return fail(c, HSK_ERR_INTERNAL, "radix look-back timed out (device error word %u)", *e);
+    }
+    return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: merge-count one sorted task (a13)
+// ------------------------------------------------------------------------------------------------
+struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; };
+
+template <int NW>
+static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n, u64 payoff_add, u64 *d_histo, u32 histo_len, TaskOut &out)
+{
+    out = TaskOut();
+    if (n == 0) return HSK_OK;
+    const bool ext = vals != nullptr;
+    const u64 ntiles = (n + CNT_TILE - 1) / CNT_TILE;
+    u64 *d_tile_cnt, *d_total;
+    DALLOC(c, d_tile_cnt, u64 *, ntiles * 16);
+    DALLOC(c, d_total, u64 *, 256);
+    CountArgs a; memset(&a, 0, sizeof a);
+    a.keys = keys; a.vals = vals; a.n = n; a.lower = (u32)c->cfg.lower_freq; a.upper = (u32)c->cfg.upper_freq;
+    a.tile_cnt = d_tile_cnt; a.histo = d_histo; a.histo_len = histo_len;
+    hipLaunchKernelGGL((count_kernel<NW, false, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile_cnt, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out.n = tot[0]; out.npay = ext ? tot[1] : 0;
+    if (out.n) {
+        DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
+        if (ext) {
+            DALLOC(c, out.payoff, u64 *, out.n * 8);
+            DALLOC(c, out.pos, u32 *, out.npay * 4);
+            DALLOC(c, out.rid, int32_t *, out.npay * 4);
+        }
+        a.entries = out.entries; a.payoff = out.payoff; a.pos = out.pos; a.rid = out.rid; a.pay_base = 0;
+        // payoff values are made global by adding the payload count of the preceding tasks
+        a.tile_cnt = d_tile_cnt;
+        if (ext) {
+            // shift the per-tile payload offsets by payoff_add so that payoff[] is global, while pos/rid stay task-local
+            a.pay_base = 0;
+        }
+        if (ext) hipLaunchKernelGGL((count_kernel<NW, true, true>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((count_kernel<NW, true, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    (void)payoff_add;
+    c->pool.release(d_tile_cnt); c->pool.release(d_total);
+    return HSK_OK;
+}
+
+static void free_task_out(hsk_ctx *c, TaskOut &o)
+{
+    c->pool.release(o.entries); c->pool.release(o.payoff); c->pool.release(o.pos); c->pool.release(o.rid);
+    o = TaskOut();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the whole path
+// ------------------------------------------------------------------------------------------------
+struct ResultPriv {
+    std::vector<void *> host_blocks;     // hipHostMalloc'ed
+    std::vector<TaskOut> dev_tasks;      // kept in HBM with HSK_FLAG_KEEP_DEVICE
+};
+
+static void *host_alloc(ResultPriv *rp, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    rp->host_blocks.push_back(p);
+    return p;
+}
+
+static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
+{
+    // one task per ~2^28 k-mers (2 GB of 8-byte keys): large enough to saturate the chip, small
+    // enough that key + ping-pong + look-back buffers of one task stay a small share of HBM
+    u64 est = packed_bytes * 4 * (u64)std::max(nranks, 1);
+    u64 t = (est + (1ULL << 28) - 1) >> 28;
+    t = std::max<u64>(t, (u64)std::max(nranks, 1));
+    return (u32)std::min<u64>(std::max<u64>(t, 1), HSK_MAX_TASKS);
+}
+
+template <int NW>
+static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                        int64_t rid_base, hsk_result *out)
+{
+    const bool ext = c->cfg.extension != 0;
+    const int K = c->cfg.kmer_size;
+    const int nranks = c->comm.active() ? c->comm.nranks : 1;
+    const int rank = c->comm.active() ? c->comm.rank : 0;
+    memset(out, 0, sizeof *out);
+    ResultPriv *rp = new ResultPriv();
+    out->priv = rp; out->nw = NW;
+    PhaseTimer pt(c);
+    pt.begin(PH_TOTAL);
+
+    u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : auto_ntasks(c, packed_bytes, nranks);
+    if (c->comm.active() && !c->cfg.ntasks) {
+        // every rank must use the same task count: take the maximum of the local proposals
+        u64 v = ntasks; int rc = c->comm.allreduce_max_u64(&v, 1, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks) failed: %d", rc);
+        ntasks = (u32)v;
+    }
+    out->ntasks = (int32_t)ntasks;
+    std::vector<int32_t> owner(ntasks, 0);
+    std::vector<u32> order(ntasks);
+    for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+
+    // ---- parse ------------------------------------------------------------------------------------
+    SupermerStore st;
+    pt.begin(PH_PARSE);
+    if (nreads > 0 && packed_bytes > 0) {
+        if (nranks > 1) {
+            // dispatch needs global task sizes first: COUNT once with identity order, exchange sizes,
+            // decide owners, then run the full parse with tasks grouped by owner.
+            SupermerStore probe;
+            int rc = parse_phase(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, order, probe);
+            if (rc) return rc;
+            free_store(c, probe);
+            std::vector<u64> bytes(ntasks);
+            for (u32 t = 0; t < ntasks; ++t) bytes[t] = probe.task_tot[3 * t + 1] + probe.task_tot[3 * t] * (ext ? 9 : 1);
+            rc = c->comm.allreduce_sum_u64(bytes.data(), ntasks, c->stream, c->pool);
+            if (rc) return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc);
+            rc = plan_dispatch(bytes.data(), (int)ntasks, nranks, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data());
+            if (rc) return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
+            std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
+        }
+        int rc = parse_phase(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, order, st);
+        if (rc) return rc;
+    } else {
+        st.ntasks = ntasks; st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0); st.order = order;
+    }
+    pt.end(PH_PARSE);
+    out->total_supermers = st.tot_sup; out->total_supermer_bytes = st.tot_bytes + st.tot_sup * (ext ? 9 : 1);
+
+    // ---- exchange (multi-GPU) ---------------------------------------------------------------------
+    // After this block `segs[t]` lists where the supermers of owned task t live.
+    std::vector<TaskSegs> segs(ntasks);
+    const u8 *x_len = st.sm_len; const u8 *x_bytes = st.sm_bytes; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
+    ExchangeBuffers xb;
+    pt.begin(PH_EXCH);
+    if (nranks > 1) {
+        int rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
+                                    st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
+        if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
+        x_len = xb.len; x_bytes = xb.bytes; x_pos = xb.pos; x_rid = xb.rid;
+        free_store(c, st);
+    } else {
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (st.task_tot[3 * t] == 0) continue;
+            ExpSeg s; s.sup_off = st.task_base[3 * t]; s.n_sup = st.task_tot[3 * t]; s.byte_off = st.task_base[3 * t + 1]; s.kmer_off = 0; s.tile_start = 0;
+            segs[t].segs.push_back(s); segs[t].nkmers = st.task_tot[3 * t + 2];
+        }
+    }
+    pt.end(PH_EXCH);
+    u64 max_task = 0, total_kmers = 0;
+    for (u32 t = 0; t < ntasks; ++t) { finalize_segs(segs[t]); max_task = std::max(max_task, segs[t].nkmers); total_kmers += segs[t].nkmers; }
+    out->total_kmers = total_kmers;
+
+    // ---- per task: expand, sort, count ---------------------------------------------------------------
+    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
+    u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
+    HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
+    u64 *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr;
+    SortScratch sc;
+    if (max_task) {
+        DALLOC(c, keysA, u64 *, max_task * NW * 8 + 64); DALLOC(c, keysB, u64 *, max_task * NW * 8 + 64);
+        if (ext) { DALLOC(c, valsA, u64 *, max_task * 8 + 64); DALLOC(c, valsB, u64 *, max_task * 8 + 64); }
+        int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    }
+    std::vector<TaskOut> touts(ntasks);
+    u64 n_total = 0, pay_total = 0;
+    for (u32 t = 0; t < ntasks; ++t) {
+        if (owner[t] != rank || segs[t].nkmers == 0) continue;
+        const u64 n = segs[t].nkmers;
+        pt.begin(PH_EXTRACT);
+        int rc = expand_task<NW>(c, segs[t], x_len, x_bytes, x_pos, x_rid, keysA, valsA); if (rc) return rc;
+        pt.end(PH_EXTRACT);
+        pt.begin(PH_SORT);
+        u64 *sk, *sv;
+        rc = sort_task_device<NW>(c, keysA, keysB, valsA, valsB, n, K, sc, &sk, &sv); if (rc) return rc;
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        rc = count_task_device<NW>(c, sk, sv, n, pay_total, d_histo, histo_len, touts[t]); if (rc) return rc;
+        pt.end(PH_COUNT);
+        n_total += touts[t].n; pay_total += touts[t].npay;
+    }
+    {
+        int rc = check_device_error(c); if (rc) return rc;
+    }
+    c->pool.release(keysA); c->pool.release(keysB); c->pool.release(valsA); c->pool.release(valsB);
+    free_sort_scratch(c, sc);
+    if (nranks > 1) xb.release(c->pool); else free_store(c, st);
+
+    // ---- result ----------------------------------------------------------------------------------------
+    pt.begin(PH_D2H);
+    out->n = n_total;
+    out->task_off = (uint64_t *)host_alloc(rp, (size_t)(ntasks + 1) * 8);
+    out->histo = (uint64_t *)host_alloc(rp, (size_t)histo_len * 8);
+    out->histo_len = histo_len;
+    if (!out->task_off || !out->histo) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+    HIPCHK(c, hipMemcpyAsync(out->histo, d_histo, (size_t)histo_len * 8, hipMemcpyDeviceToHost, c->stream));
+    const bool keep = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
+    if (!keep) {
+        out->entries = (uint64_t *)host_alloc(rp, n_total * (NW + 1) * 8);
+        if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
+        if (ext) {
+            out->payload_off = (uint64_t *)host_alloc(rp, (n_total + 1) * 8);
+            out->pos = (uint32_t *)host_alloc(rp, pay_total * 4);
+            out->rid = (int32_t *)host_alloc(rp, pay_total * 4);
+            if (!out->payload_off || !out->pos || !out->rid) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+        }
+    }
+    u64 o = 0, po = 0;
+    std::vector<std::pair<u64, u64>> pay_fix;      // (entry offset, payload base) per task, EXT
+    for (u32 t = 0; t < ntasks; ++t) {
+        out->task_off[t] = o;
+        TaskOut &to = touts[t];
+        if (to.n && !keep) {
+            HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext) {
+                HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(out->rid + po, to.rid, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+                pay_fix.push_back({o, po});
+            }
+        }
+        o += to.n; po += to.npay;
+    }
+    out->task_off[ntasks] = o;
+    pt.end(PH_D2H);
+    pt.end(PH_TOTAL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ext && !keep) {
+        // per-task payload offsets -> global offsets (tasks were counted independently)
+        for (size_t i = 0; i < pay_fix.size(); ++i) {
+            const u64 e0 = pay_fix[i].first, base = pay_fix[i].second;
+            const u64 e1 = (i + 1 < pay_fix.size()) ? pay_fix[i + 1].first : n_total;
+            if (base) for (u64 e = e0; e < e1; ++e) out->payload_off[e] += base;
+        }
+        out->payload_off[n_total] = pay_total;
+    }
+    if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
+    else for (auto &to : touts) free_task_out(c, to);
+    c->pool.release(d_histo);
+    out->ms_total = pt.collect(PH_TOTAL); out->ms_parse = pt.collect(PH_PARSE); out->ms_exchange = pt.collect(PH_EXCH);
+    out->ms_extract = pt.collect(PH_EXTRACT); out->ms_sort = pt.collect(PH_SORT); out->ms_count = pt.collect(PH_COUNT);
+    out->ms_d2h = pt.collect(PH_D2H);
+    return HSK_OK;
+}
+
+static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                             int64_t rid_base, hsk_result *out)
+{
+    int rc;
+    switch (c->nw) {
+    case 1: rc = run_pipeline<1>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
+    case 2: rc = run_pipeline<2>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
+    default: rc = run_pipeline<3>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
+    }
+    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); hsk_result_free(c, out); }
+    return rc;
+}
+
+extern "C" void hsk_result_free(hsk_ctx *c, hsk_result *r)
+{
+    if (!r) return;
+    ResultPriv *rp = (ResultPriv *)r->priv;
+    if (rp) {
+        for (void *p : rp->host_blocks) (void)hipHostFree(p);
+        if (c) for (auto &to : rp->dev_tasks) free_task_out(c, to);
+        delete rp;
+    }
+    memset(r, 0, sizeof *r);
+}
+
+// Uploads the DnaBuffer description; returns device arrays with nreads+1 offsets.
+struct DevInput { u8 *packed = nullptr; u64 *roff = nullptr; u32 *rlen = nullptr; };
+
+static int upload_input(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
+                        uint64_t nreads, DevInput &d)
+{
+    DALLOC(c, d.packed, u8 *, packed_bytes + 64);
+    DALLOC(c, d.roff, u64 *, (nreads + 1) * 8);
+    DALLOC(c, d.rlen, u32 *, (nreads + 1) * 4);
+    if (packed_bytes) HIPCHK(c, hipMemcpyAsync(d.packed, packed, packed_bytes, hipMemcpyHostToDevice, c->stream));
+    if (nreads) {
+        HIPCHK(c, hipMemcpyAsync(d.roff, off, nreads * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(d.roff + nreads, &packed_bytes, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffers (and &packed_bytes) may go away after return
+    return HSK_OK;
+}
+static void free_input(hsk_ctx *c, DevInput &d) { c->pool.release(d.packed); c->pool.release(d.roff); c->pool.release(d.rlen); d = DevInput(); }
+
+static int check_host_index(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len, uint64_t nreads)
+{
+    uint64_t prev_end = 0;
+    for (uint64_t r = 0; r < nreads; ++r) {
+        if (off[r] < prev_end) return fail(c, HSK_ERR_INVALID_ARG, "read %llu overlaps its predecessor", (unsigned long long)r);
+        const uint64_t end = off[r] + ((uint64_t)len[r] + 3) / 4;
+        if (end > packed_bytes) return fail(c, HSK_ERR_INVALID_ARG, "read %llu extends past the packed buffer", (unsigned long long)r);
+        prev_end = end;
+    }
+    if (nreads && off[0] != 0) return fail(c, HSK_ERR_INVALID_ARG, "read_byte_off[0] must be 0");
+    return HSK_OK;
+}
+
+extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
+                         uint64_t nreads, int64_t rid_base, hsk_result *out)
+{
+    if (!c || !out || (nreads && (!off || !len)) || (packed_bytes && !packed)) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
+    DevInput d;
+    rc = upload_input(c, packed, packed_bytes, off, len, nreads, d);
+    if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
+    free_input(c, d);
+    return rc;
+}
+
+extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packed_bytes, const void *d_off, const void *d_len,
+                                uint64_t nreads, int64_t rid_base, hsk_result *out)
+{
+    if (!c || !out || (nreads && (!d_off || !d_len)) || (packed_bytes && !d_packed)) return HSK_ERR_INVALID_ARG;
+    if (((uintptr_t)d_packed & 3) != 0) return fail(c, HSK_ERR_INVALID_ARG, "d_packed must be 4-byte aligned");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // the kernels index roff[r+1]: build the (nreads+1)-entry offset array
+    u64 *roff; DALLOC(c, roff, u64 *, (nreads + 1) * 8);
+    if (nreads) HIPCHK(c, hipMemcpyAsync(roff, d_off, nreads * 8, hipMemcpyDeviceToDevice, c->stream));
+    u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
+    *stage = packed_bytes;
+    HIPCHK(c, hipMemcpyAsync(roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
+    int rc = dispatch_pipeline(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, rid_base, out);
+    c->pool.release(roff);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int hsk_stage_destinations(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
+                                      uint64_t nreads, int32_t *dest, uint64_t cap, uint64_t *dest_off)
+{
+    if (!c || !dest_off || (cap && !dest)) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
+    const int K = c->cfg.kmer_size;
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < nreads; ++r) { dest_off[r] = total; total += len[r] >= (uint32_t)K ? len[r] - K + 1 : 0; }
+    dest_off[nreads] = total;
+    if (total > cap) return fail(c, HSK_ERR_INVALID_ARG, "dest capacity %llu < %llu", (unsigned long long)cap, (unsigned long long)total);
+    if (!nreads || !packed_bytes) return HSK_OK;
+    DevInput d; rc = upload_input(c, packed, packed_bytes, off, len, nreads, d); if (rc) return rc;
+    const u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : 1;
+    u32 nblocks; ParseArgs a = make_parse_args(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, 0, ntasks, &nblocks);
+    int32_t *d_dump; DALLOC(c, d_dump, int32_t *, packed_bytes * 4 * 4);
+    a.dump_dest = d_dump;
+    hipLaunchKernelGGL((parse_kernel<PARSE_DUMP, false>), dim3(nblocks), dim3(PARSE_THREADS), 64, c->stream, a);
+    std::vector<int32_t> h(packed_bytes * 4);
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_dump, packed_bytes * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t r = 0; r < nreads; ++r) {
+        const uint64_t nk = dest_off[r + 1] - dest_off[r];
+        for (uint64_t i = 0; i < nk; ++i) dest[dest_off[r] + i] = h[off[r] * 4 + i];
+    }
+    c->pool.release(d_dump); free_input(c, d);
+    return HSK_OK;
+}
+
+template <int NW>
+static int stage_task_kmers_impl(hsk_ctx *c, const DevInput &d, uint64_t packed_bytes, uint64_t nreads, int64_t rid_base, int32_t task,
+                                 uint64_t *keys, uint32_t *pos, int32_t *rid, uint64_t cap, uint64_t *n)
+{
+    const bool ext = c->cfg.extension != 0;
+    const u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : 1;
+    if (task < 0 || (u32)task >= ntasks) return HSK_ERR_INVALID_ARG;
+    std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    SupermerStore st;
+    int rc = parse_phase(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, ntasks, order, st); if (rc) return rc;
+    TaskSegs ts;
+    if (st.task_tot[3 * task]) {
+        ExpSeg s; s.sup_off = st.task_base[3 * task]; s.n_sup = st.task_tot[3 * task]; s.byte_off = st.task_base[3 * task + 1]; s.kmer_off = 0; s.tile_start = 0;
+        ts.segs.push_back(s); ts.nkmers = st.task_tot[3 * task + 2];
+    }
+    finalize_segs(ts);
+    *n = ts.nkmers;
+    if (ts.nkmers > cap) { free_store(c, st); return fail(c, HSK_ERR_INVALID_ARG, "capacity %llu < %llu", (unsigned long long)cap, (unsigned long long)ts.nkmers); }
+    if (ts.nkmers) {
+        u64 *dk, *dv = nullptr;
+        DALLOC(c, dk, u64 *, ts.nkmers * NW * 8 + 64);
+        if (ext) DALLOC(c, dv, u64 *, ts.nkmers * 8 + 64);
+        rc = expand_task<NW>(c, ts, st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, dk, dv);
+        if (rc == HSK_OK) {
+            HIPCHK(c, hipMemcpyAsync(keys, dk, ts.nkmers * NW * 8, hipMemcpyDeviceToHost, c->stream));
+            std::vector<u64> hv;
+            if (ext) { hv.resize(ts.nkmers); HIPCHK(c, hipMemcpyAsync(hv.data(), dv, ts.nkmers * 8, hipMemcpyDeviceToHost, c->stream)); }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (ext) for (u64 i = 0; i < ts.nkmers; ++i) { if (pos) pos[i] = (uint32_t)hv[i]; if (rid) rid[i] = (int32_t)(hv[i] >> 32); }
+        }
+        c->pool.release(dk); c->pool.release(dv);
+    }
+    free_store(c, st);
+    return rc;
+}
+
+extern "C" int hsk_stage_task_kmers(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
+                                    uint64_t nreads, int64_t rid_base, int32_t task, uint64_t *keys, uint32_t *pos, int32_t *rid,
+                                    uint64_t cap, uint64_t *n)
+{
+    if (!c || !n || (cap && !keys)) return HSK_ERR_INVALID_ARG;
+    *n = 0;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
+    if (!nreads || !packed_bytes) return HSK_OK;
+    DevInput d; rc = upload_input(c, packed, packed_bytes, off, len, nreads, d); if (rc) return rc;
+    switch (c->nw) {
+    case 1: rc = stage_task_kmers_impl<1>(c, d, packed_bytes, nreads, rid_base, task, keys, pos, rid, cap, n); break;
+    case 2: rc = stage_task_kmers_impl<2>(c, d, packed_bytes, nreads, rid_base, task, keys, pos, rid, cap, n); break;
+    default: rc = stage_task_kmers_impl<3>(c, d, packed_bytes, nreads, rid_base, task, keys, pos, rid, cap, n); break;
+    }
+    free_input(c, d);
+    return rc;
+}
+
+template <int NW>
+static int stage_sort_impl(hsk_ctx *c, uint64_t *keys, uint64_t *vals, uint64_t n)
+{
+    u64 *ka, *kb, *va = nullptr, *vb = nullptr;
+    DALLOC(c, ka, u64 *, n * NW * 8 + 64); DALLOC(c, kb, u64 *, n * NW * 8 + 64);
+    if (vals) { DALLOC(c, va, u64 *, n * 8 + 64); DALLOC(c, vb, u64 *, n * 8 + 64); }
+    HIPCHK(c, hipMemcpyAsync(ka, keys, n * NW * 8, hipMemcpyHostToDevice, c->stream));
+    if (vals) HIPCHK(c, hipMemcpyAsync(va, vals, n * 8, hipMemcpyHostToDevice, c->stream));
+    SortScratch sc; int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    u64 *sk, *sv;
+    // all 64 bits of every word take part (K = 32*NW would be the natural name; 32*NW-... use full words)
+    rc = sort_task_device<NW>(c, ka, kb, va, vb, n, 32 * NW, sc, &sk, &sv);
+    if (rc == HSK_OK) rc = check_device_error(c);
+    if (rc == HSK_OK) {
+        HIPCHK(c, hipMemcpyAsync(keys, sk, n * NW * 8, hipMemcpyDeviceToHost, c->stream));
+        if (vals) HIPCHK(c, hipMemcpyAsync(vals, sv, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    free_sort_scratch(c, sc);
+    c->pool.release(ka); c->pool.release(kb); c->pool.release(va); c->pool.release(vb);
+    return rc;
+}
+
+extern "C" int hsk_stage_sort(hsk_ctx *c, uint64_t *keys, uint64_t *vals, uint64_t n, int32_t nw)
+{
+    if (!c || (n && !keys) || nw < 1 || nw > 3) return HSK_ERR_INVALID_ARG;
+    if (n == 0) return HSK_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    switch (nw) {
+    case 1: return stage_sort_impl<1>(c, keys, vals, n);
+    case 2: return stage_sort_impl<2>(c, keys, vals, n);
+    default: return stage_sort_impl<3>(c, keys, vals, n);
+    }
+}
+
+template <int NW>
+static int stage_count_impl(hsk_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *out_entries, uint64_t cap, uint64_t *n_out)
+{
+    u64 *dk; DALLOC(c, dk, u64 *, n * NW * 8 + 64);
+    HIPCHK(c, hipMemcpyAsync(dk, keys, n * NW * 8, hipMemcpyHostToDevice, c->stream));
+    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
+    u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
+    HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
+    TaskOut to;
+    int rc = count_task_device<NW>(c, dk, nullptr, n, 0, d_histo, histo_len, to);
+    if (rc == HSK_OK) {
+        *n_out = to.n;
+        if (to.n > cap) rc = fail(c, HSK_ERR_INVALID_ARG, "capacity %llu < %llu", (unsigned long long)cap, (unsigned long long)to.n);
+        else if (to.n) HIPCHK(c, hipMemcpyAsync(out_entries, to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    free_task_out(c, to);
+    c->pool.release(dk); c->pool.release(d_histo);
+    return rc;
+}
+
+extern "C" int hsk_stage_count_sorted(hsk_ctx *c, const uint64_t *keys, uint64_t n, int32_t nw, uint64_t *out_entries, uint64_t cap, uint64_t *n_out)
+{
+    if (!c || !n_out || (n && !keys) || nw < 1 || nw > 3) return HSK_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (n == 0) return HSK_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    switch (nw) {
+    case 1: return stage_count_impl<1>(c, keys, n, out_entries, cap, n_out);
+    case 2: return stage_count_impl<2>(c, keys, n, out_entries, cap, n_out);
+    default: return stage_count_impl<3>(c, keys, n, out_entries, cap, n_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host planning (pure CPU)
+// ------------------------------------------------------------------------------------------------
+extern "C" int hsk_plan_tot_tasks(int omp_max_threads, int thread_per_worker, int avg_task_per_worker, int nprocs)
+{
+    if (thread_per_worker < 1 || nprocs < 1) return -1;
+    return plan_tot_tasks(omp_max_threads, thread_per_worker, avg_task_per_worker, nprocs);
+}
+extern "C" int hsk_plan_classify(const uint64_t *task_kmers, int ntasks, double ratio, int32_t *types)
+{
+    if (!task_kmers || !types || ntasks < 1) return HSK_ERR_INVALID_ARG;
+    plan_classify(task_kmers, ntasks, ratio, types);
+    return HSK_OK;
+}
+extern "C" int hsk_plan_dispatch(const uint64_t *task_bytes, int ntasks, int nprocs, int plain, double upper_coe, double step, int32_t *owner)
+{
+    if (!task_bytes || !owner || ntasks < 1 || nprocs < 1) return HSK_ERR_INVALID_ARG;
+    int rc = plan_dispatch(task_bytes, ntasks, nprocs, plain != 0, upper_coe, step, owner);
+    return rc == 0 ? HSK_OK : (rc == -1 ? HSK_ERR_DISPATCH : HSK_ERR_INVALID_ARG);
+}
+extern "C" int hsk_plan_partition_reads(const uint64_t *read_len, uint64_t nreads, int nprocs, uint64_t *counts)
+{
+    if (!counts || nprocs < 1 || (nreads && !read_len)) return HSK_ERR_INVALID_ARG;
+    return plan_partition_reads(read_len, nreads, nprocs, counts) == 0 ? HSK_OK : HSK_ERR_INVALID_ARG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU
+// ------------------------------------------------------------------------------------------------
+extern "C" int hsk_comm_get_unique_id(void *id128)
+{
+    if (!id128) return HSK_ERR_INVALID_ARG;
+    return Comm::get_unique_id(id128) == 0 ? HSK_OK : HSK_ERR_COMM;
+}
+extern "C" int hsk_comm_init(hsk_ctx *c, int nranks, int rank, const void *id128)
+{
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = c->comm.init(nranks, rank, id128);
+    if (rc) return fail(c, HSK_ERR_COMM, "RCCL init failed: %s", c->comm.last_error.c_str());
+    return HSK_OK;
+}
+extern "C" int hsk_comm_destroy(hsk_ctx *c)
+{
+    if (!c) return HSK_ERR_INVALID_ARG;
+    c->comm.destroy();
+    return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic reads in HBM
+// ------------------------------------------------------------------------------------------------
+extern "C" int hsk_synth_reads(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed,
+                               void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
+{
+    if (!c || !d_packed || !packed_bytes || !d_off || !d_len || read_len == 0 || genome_len < read_len) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 nwords = (genome_len + 31) / 32;
+    const u32 nb = (read_len + 3) / 4;
+    const u64 bytes = nreads * nb;
+    u64 *gw; u8 *pk; u64 *roff; u32 *rlen;
+    DALLOC(c, gw, u64 *, nwords * 8);
+    DALLOC(c, pk, u8 *, bytes + 64);
+    DALLOC(c, roff, u64 *, (nreads + 1) * 8);
+    DALLOC(c, rlen, u32 *, (nreads + 1) * 4);
+    hipLaunchKernelGGL(synth_genome_kernel, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, c->stream, gw, nwords, seed);
+    const u64 seed2 = splitmix64(seed ^ 0xabcdef12345ULL);
+    if (bytes) hipLaunchKernelGGL(synth_reads_kernel, dim3((u32)((bytes + 255) / 256)), dim3(256), 0, c->stream, gw, genome_len, read_len, nreads, seed2, pk);
+    hipLaunchKernelGGL(synth_index_kernel, dim3((u32)((nreads + 256) / 256)), dim3(256), 0, c->stream, roff, rlen, nreads, read_len);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pool.release(gw);
+    *d_packed = pk; *packed_bytes = bytes; *d_off = roff; *d_len = rlen;
+    return HSK_OK;
+}
+
+extern "C" int hsk_synth_free(hsk_ctx *c, void *d_packed, void *d_off, void *d_len)
+{
+    if (!c) return HSK_ERR_INVALID_ARG;
+    c->pool.release(d_packed); c->pool.release(d_off); c->pool.release(d_len);
+    return HSK_OK;
+}
+
+extern "C" int hsk_memcpy_d2h(hsk_ctx *c, void *dst, const void *d_src, uint64_t bytes)
+{
+    if (!c || !dst || !d_src) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HSK_OK;
+}

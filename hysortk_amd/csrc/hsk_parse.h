@@ -1,0 +1,275 @@
+// hsk_parse.h -- minimizer -> task assignment and supermer emission (device).
+//
+// Replaces, for the reads of one rank:
+//   FindKmerDestinationsParallel  reference src/kmerops.cpp:1010-1041  (a4)
+//   SupermerEncoder::encode       reference src/kmerops.cpp:1109-1147  (a5)
+//   ScatteredSupermers            reference include/kmerops.hpp:114     (a6, storage only)
+//
+// Design (not a translation): the packed DnaBuffer is treated as ONE base stream of
+// 4*packed_bytes positions; a workgroup walks tiles of 2048 positions.  Per tile:
+//   1. the tile's bytes (+K-1 bases of halo) are staged in LDS as byte-swapped words,
+//   2. every position gets its canonical M-mer MurmurHash (rolling state is not needed: 64 bits
+//      are pulled from LDS at any bit offset),
+//   3. every k-mer position gets min(hash) over its K-M+1 m-mers (shared-middle trick: 8
+//      consecutive positions of a lane share all but 14 window elements) and dest = min % ntasks,
+//   4. supermer starts are local decisions: a k-mer starts a supermer iff it is the first k-mer of
+//      its read, its dest differs from the previous k-mer, or its position is a multiple of 128.
+// The 128-position cut replaces the reference's "250 bases counted from the run start" cap
+// (kmerops.cpp:1120), which is a serial dependence along the read; cutting at fixed positions
+// keeps every decision tile-local and bounds a supermer to 128 k-mers (len <= 127+K <= 222 < 256,
+// one byte).  Supermer boundaries are an internal wire format (only this library reads them);
+// the multiset of k-mers (and of (k-mer, pos, rid) with EXTENSION) per task is unchanged.
+//
+// Two launches of the same kernel: COUNT (per workgroup x task: supermers, bytes, k-mers) and,
+// after an exclusive scan, EMIT with per-(workgroup, task) cursors in LDS: no global atomics, and
+// the supermers of a task that go to one destination rank are contiguous for the all-to-all.
+#pragma once
+#include "hsk_device.h"
+
+namespace hsk {
+
+constexpr int PARSE_THREADS = 256;
+constexpr int PARSE_PPT = 8;                          // positions per thread
+constexpr int PARSE_TILE = PARSE_THREADS * PARSE_PPT; // 2048 positions = 512 bytes
+constexpr int SUPERMER_CUT = 128;                     // forced supermer boundary period (positions)
+constexpr int MAX_K = 95;
+constexpr int HSK_MAX_TASKS = 1024;
+constexpr int PARSE_WORDS = PARSE_TILE / 16 + 12;     // 128 tile words + halo (K-1 <= 94 bases = 6 words) + overread
+constexpr int PARSE_HMAX = PARSE_TILE + 96;           // hashes for TILE + (K-M) positions
+
+struct ParseArgs {
+    const u8 *packed;          // 4-byte aligned; nothing beyond packed_bytes is read
+    u64 packed_bytes;
+    const u64 *roff;           // nreads + 1 byte offsets (last = packed_bytes)
+    const u32 *rlen;           // nreads
+    u64 nreads;
+    int k, m;
+    u32 ntasks;
+    FastMod fm;
+    u64 ntiles;
+    u32 tiles_per_block;
+    int64_t rid_base;
+    // COUNT: blk_cnt[block][task][3] = {supermers, bytes, kmers}
+    u64 *blk_cnt;
+    // EMIT: blk_base[block][task][2] = {first supermer slot, first byte} (absolute)
+    const u64 *blk_base;
+    u8 *sm_len;                // supermer length in bases (one byte each)
+    u8 *sm_bytes;              // re-aligned 2-bit bases, (len+3)/4 bytes per supermer
+    u32 *sm_pos;               // EXTENSION: PosInRead of the supermer's first base
+    int32_t *sm_rid;           // EXTENSION: ReadId
+    // DUMP (stage test): dest per base position, -1 where no k-mer starts
+    int32_t *dump_dest;
+};
+
+enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
+
+// last r in [lo, hi] with roff[r] <= b   (precondition: roff[lo] <= b)
+__device__ __forceinline__ u64 find_read(const u64 *roff, u64 lo, u64 hi, u64 b)
+{
+    while (lo < hi) {
+        u64 mid = lo + (hi - lo + 1) / 2;
+        if (roff[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int MODE, bool EXT>
+__global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
+{
+    __shared__ u32 s_words[PARSE_WORDS];
+    __shared__ u64 s_hash[PARSE_HMAX];
+    __shared__ u16 s_dest[PARSE_TILE + 8];   // sizes of the statics are multiples of 16 B (dynamic LDS base stays aligned)
+    __shared__ u64 s_rng[2];
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // COUNT: 3*ntasks counters, EMIT: 2*ntasks cursors
+
+    const int tid = threadIdx.x;
+    const int K = a.k, M = a.m, W = K - M + 1;
+    const u64 total_pos = a.packed_bytes * 4;
+
+    if (MODE == PARSE_COUNT) {
+        for (u32 i = tid; i < 3 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
+    } else if (MODE == PARSE_EMIT) {
+        for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS)
+            s_cur[i] = a.blk_base[(u64)blockIdx.x * 2 * a.ntasks + i];
+    }
+    __syncthreads();
+
+    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
+        const u64 tile = tile0 + ti;
+        if (tile >= a.ntiles) break;
+        const u64 gbase = tile * PARSE_TILE;            // first base position of the tile
+        const u64 bbase = gbase >> 2;                   // first byte
+
+        // ---- 1. stage bytes (big-endian words) ------------------------------------------------
+        {
+            const u32 *src = reinterpret_cast<const u32 *>(a.packed + bbase);   // bbase % 512 == 0, base 4-B aligned
+            const u64 left = a.packed_bytes - bbase;                            // bytes readable from bbase
+            for (int i = tid; i < PARSE_WORDS; i += PARSE_THREADS) {
+                u32 wv = 0;
+                if ((u64)i * 4 + 4 <= left) wv = __builtin_bswap32(src[i]);
+                else if ((u64)i * 4 < left) {                                   // last partial word: byte loads only
+                    for (u64 b = (u64)i * 4; b < left; ++b) wv |= (u32)a.packed[bbase + b] << (24 - 8 * (b & 3));
+                }
+                s_words[i] = wv;
+            }
+        }
+        // tile-level read range (reads overlapping [bbase, bbase + 512 + halo))
+        if (tid == 0) {
+            u64 r0 = find_read(a.roff, 0, a.nreads - 1, bbase);
+            u64 blast = bbase + PARSE_TILE / 4 - 1;
+            if (blast >= a.packed_bytes) blast = a.packed_bytes - 1;
+            u64 r1 = find_read(a.roff, r0, a.nreads - 1, blast);
+            s_rng[0] = r0; s_rng[1] = r1;
+        }
+        __syncthreads();
+
+        // ---- 2. canonical m-mer hashes for positions [0, TILE + W - 1) ---------------------------
+        const u64 mmask = ~0ULL << (64 - 2 * M);
+        for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) {
+            u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
+            u64 tw = twin1(fw, M);
+            s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+        }
+        __syncthreads();
+
+        // ---- 3. window minima, dest, validity -------------------------------------------------
+        const int p0 = tid * PARSE_PPT;
+        u64 mn[PARSE_PPT];
+        if (W >= PARSE_PPT) {
+            u64 c = ~0ULL;
+            for (int j = PARSE_PPT - 1; j <= W - 1; ++j) { u64 v = s_hash[p0 + j]; c = v < c ? v : c; }
+            u64 suf = ~0ULL;
+            mn[PARSE_PPT - 1] = c;
+#pragma unroll
+            for (int i = PARSE_PPT - 2; i >= 0; --i) { u64 v = s_hash[p0 + i]; suf = v < suf ? v : suf; mn[i] = suf < c ? suf : c; }
+            u64 run = ~0ULL;
+#pragma unroll
+            for (int i = 1; i < PARSE_PPT; ++i) { u64 v = s_hash[p0 + W + i - 1]; run = v < run ? v : run; mn[i] = run < mn[i] ? run : mn[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                u64 c = ~0ULL;
+                for (int j = 0; j < W; ++j) { u64 v = s_hash[p0 + i + j]; c = v < c ? v : c; }
+                mn[i] = c;
+            }
+        }
+        // read tracking for this lane's 8 positions (2 bytes)
+        u32 posr[PARSE_PPT]; u32 ridx[PARSE_PPT];   // pos in read / read index relative to s_rng[0]
+        {
+            const u64 g0 = gbase + p0;
+            const u64 rlo = s_rng[0], rhi = s_rng[1];
+            u64 r = find_read(a.roff, rlo, rhi, g0 >> 2);
+            u64 rstart = a.roff[r] * 4;
+            u64 rend = rstart + a.rlen[r];
+            u64 nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const u64 g = g0 + i;
+                while (g >= nxt) {
+                    ++r; rstart = nxt; rend = rstart + a.rlen[r];
+                    nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+                }
+                const bool valid = (g < total_pos) && (g + K <= rend);
+                const u32 d = fastmod64(mn[i], a.fm);
+                s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
+                posr[i] = (u32)(g - rstart);
+                ridx[i] = (u32)(r - rlo);
+            }
+        }
+        __syncthreads();
+
+        // ---- 4. supermers ------------------------------------------------------------------------
+        if (MODE == PARSE_DUMP) {
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                u64 g = gbase + p0 + i;
+                if (g < total_pos) { u16 d = s_dest[p0 + i]; a.dump_dest[g] = d == 0xFFFF ? -1 : (int32_t)d; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const int p = p0 + i;
+                const u16 d = s_dest[p];
+                if (d == 0xFFFF) continue;
+                const bool start = ((p & (SUPERMER_CUT - 1)) == 0) || (s_dest[p - 1] != d);   // p==0 -> first clause
+                if (!start) continue;
+                const int lim = (p | (SUPERMER_CUT - 1)) + 1;
+                int q = p + 1;
+                while (q < lim && s_dest[q] == d) ++q;
+                const u32 nk = (u32)(q - p);
+                const u32 len = nk + K - 1;
+                const u32 nb = (len + 3) >> 2;
+                if (MODE == PARSE_COUNT) {
+                    atomicAdd((unsigned long long *)&s_cur[3 * d + 0], 1ULL);
+                    atomicAdd((unsigned long long *)&s_cur[3 * d + 1], (unsigned long long)nb);
+                    atomicAdd((unsigned long long *)&s_cur[3 * d + 2], (unsigned long long)nk);
+                } else {
+                    const u64 slot = atomicAdd((unsigned long long *)&s_cur[2 * d + 0], 1ULL);
+                    const u64 bo = atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)nb);
+                    a.sm_len[slot] = (u8)len;
+                    if (EXT) {
+                        a.sm_pos[slot] = posr[i];
+                        a.sm_rid[slot] = (int32_t)(a.rid_base + (int64_t)(s_rng[0] + ridx[i]));
+                    }
+                    u8 *out = a.sm_bytes + bo;
+                    for (u32 j = 0; j < nb; j += 8) {
+                        u64 x = bits64_be32(s_words, 2u * (u32)p + 8u * j);
+                        const u32 lim8 = (nb - j) < 8 ? (nb - j) : 8;
+                        for (u32 b = 0; b < lim8; ++b) {
+                            u8 byte = (u8)(x >> (56 - 8 * b));
+                            if (j + b == nb - 1 && (len & 3)) byte &= (u8)(0xFF << (2 * (4 - (len & 3))));
+                            out[j + b] = byte;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (MODE == PARSE_COUNT) {
+        for (u32 i = tid; i < 3 * a.ntasks; i += PARSE_THREADS)
+            a.blk_cnt[(u64)blockIdx.x * 3 * a.ntasks + i] = s_cur[i];
+    }
+}
+
+// Exclusive scan of the COUNT matrix: per task totals, task bases (tasks laid out in `order`),
+// and per (block, task) cursors for EMIT.  One thread per task; the matrix is tiny.
+//   task_tot[t][3], task_base[t][3] (supermer slot, byte, kmer), blk_base[b][t][2]
+__global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, const u32 *order,
+                                  u64 *task_tot, u64 *task_base, u64 *blk_base)
+{
+    __shared__ u64 s_tot[HSK_MAX_TASKS * 3];
+    const u32 t = threadIdx.x;
+    if (t < ntasks) {
+        u64 s = 0, b = 0, k = 0;
+        for (u32 blk = 0; blk < nblocks; ++blk) {
+            const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
+            s += c[0]; b += c[1]; k += c[2];
+        }
+        s_tot[3 * t] = s; s_tot[3 * t + 1] = b; s_tot[3 * t + 2] = k;
+        task_tot[3 * t] = s; task_tot[3 * t + 1] = b; task_tot[3 * t + 2] = k;
+    }
+    __syncthreads();
+    if (t == 0) {
+        u64 s = 0, b = 0, k = 0;
+        for (u32 i = 0; i < ntasks; ++i) {
+            const u32 task = order[i];
+            task_base[3 * task] = s; task_base[3 * task + 1] = b; task_base[3 * task + 2] = k;
+            s += s_tot[3 * task]; b += s_tot[3 * task + 1]; k += s_tot[3 * task + 2];
+        }
+    }
+    __syncthreads();
+    if (t < ntasks) {
+        u64 s = task_base[3 * t], b = task_base[3 * t + 1];
+        for (u32 blk = 0; blk < nblocks; ++blk) {
+            const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
+            u64 *o = blk_base + ((u64)blk * ntasks + t) * 2;
+            o[0] = s; o[1] = b;
+            s += c[0]; b += c[1];
+        }
+    }
+}
+
+} // namespace hsk

@@ -1,0 +1,215 @@
+// hsk_sort.h -- LSD radix sort of k-mer records (device), replacing sort_task (reference
+// src/kmerops.cpp:1382-1407) and the vendored sorters it calls (dependency/Raduls raduls.h:1061,
+// dependency/Paradis paradissort.hpp:211).  Same contract as the RADULS call: records of NW
+// 64-bit words are ordered by their key bytes read as ONE little-endian integer (word NW-1 most
+// significant; for K <= 32 plain ascending uint64), optional 8-byte payload carried along.
+//
+// Structure ("one sweep" per digit, written for wave64 / 160 KB LDS):
+//   * hist_kernel:   ONE read of the keys builds the digit histograms of every pass
+//                    (LDS-privatised per workgroup, merged with global atomics).
+//   * onesweep_kernel (the dominant kernel, 2*record bytes of HBM traffic per key and pass):
+//       - tiles are claimed through an atomic ticket, so a tile only ever waits on tiles whose
+//         workgroups are already resident (forward progress without co-residency assumptions);
+//       - keys are loaded wave-striped (coalesced 512 B per wave instruction), ranked inside the
+//         wave with ballot "match" (RADIX_BITS ballots per key, stable), wave totals go through
+//         wave-private LDS counters, digits are prefix-scanned across the 4 waves in LDS;
+//       - the tile's digit counts are published to a look-back table as single-word
+//         {flag,value} granules with agent-scope relaxed atomics (the data is the flag: no
+//         separate fence; per-XCD L2s are not coherent so plain loads would be stale);
+//       - while predecessors are polled the keys are permuted through LDS into digit order, so
+//         the final stores are runs of consecutive addresses per digit (coalesced scatter).
+//     Every spin is bounded; on timeout an error word is set and the host reports HSK_ERR_INTERNAL.
+#pragma once
+#include "hsk_device.h"
+
+namespace hsk {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / WAVE;
+constexpr int MAX_PASSES = 24;
+
+template <int NW> struct SortTile { static constexpr int KPT = 16 / NW; static constexpr int TILE = SORT_THREADS * KPT; };
+template <> struct SortTile<3> { static constexpr int KPT = 5; static constexpr int TILE = SORT_THREADS * 5; };
+
+struct PassDesc { int word; int shift; int bits; };
+
+// k[word] without dynamic register indexing (which would spill the key array to scratch)
+template <int NW> __device__ __forceinline__ u64 pick_word(const u64 *k, int word)
+{
+    if (NW == 1) return k[0];
+    if (NW == 2) return word == 0 ? k[0] : k[1];
+    return word == 0 ? k[0] : (word == 1 ? k[1] : k[NW - 1]);
+}
+
+struct HistArgs {
+    const u64 *keys; u64 n; int npass; PassDesc pass[MAX_PASSES];
+    u64 *ghist;           // [npass][256]
+};
+
+template <int NW>
+__global__ __launch_bounds__(SORT_THREADS) void hist_kernel(HistArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 s_h[];   // [npass][256]
+    for (int i = threadIdx.x; i < a.npass * 256; i += SORT_THREADS) s_h[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * SORT_THREADS;
+    for (u64 g = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; g < a.n; g += stride) {
+        u64 w[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = a.keys[g * NW + i];
+        for (int p = 0; p < a.npass; ++p) {
+            const PassDesc pd = a.pass[p];
+            u32 d = (u32)(pick_word<NW>(w, pd.word) >> pd.shift) & ((1u << pd.bits) - 1);
+            atomicAdd(&s_h[p * 256 + d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.npass * 256; i += SORT_THREADS) {
+        u32 c = s_h[i];
+        if (c) atomicAdd((unsigned long long *)&a.ghist[i], (unsigned long long)c);
+    }
+}
+
+// look-back word: top two bits = status, rest = count
+template <typename LB> struct LBT;
+template <> struct LBT<u32> { static constexpr u32 AGG = 1u << 30, INCL = 2u << 30, VMASK = (1u << 30) - 1, FMASK = 3u << 30; };
+template <> struct LBT<u64> { static constexpr u64 AGG = 1ULL << 62, INCL = 2ULL << 62, VMASK = (1ULL << 62) - 1, FMASK = 3ULL << 62; };
+
+struct SortArgs {
+    const u64 *keys_in; u64 *keys_out;
+    const u64 *vals_in; u64 *vals_out;
+    u64 n;
+    int word, shift, bits;
+    const u64 *gbase;     // [256] exclusive digit offsets of this pass
+    void *lookback;       // [ntiles][256] LB words, zeroed
+    u32 *ticket;          // zeroed
+    u32 *err;             // sticky error word
+};
+
+constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+template <int NW, bool HAS_VAL, typename LB>
+__global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
+{
+    constexpr int KPT = SortTile<NW>::KPT;
+    constexpr int TILE = SortTile<NW>::TILE;
+    typedef LBT<LB> L;
+    __shared__ u64 s_keys[TILE * NW];
+    __shared__ u64 s_vals[HAS_VAL ? TILE : 2];
+    __shared__ u32 s_whist[SORT_WAVES * 256];
+    __shared__ u32 s_dstart[256];
+    __shared__ long long s_delta[256];
+    __shared__ u32 s_scan[8];
+    __shared__ u32 s_tile[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile[0] = atomicAdd(a.ticket, 1u);
+    for (int i = tid; i < SORT_WAVES * 256; i += SORT_THREADS) s_whist[i] = 0;
+    __syncthreads();
+    const u64 tile = s_tile[0];
+    const u64 base = tile * TILE;
+    const u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
+    const u32 dmask = (1u << a.bits) - 1;
+
+    // ---- load (wave-striped) -----------------------------------------------------------------
+    u64 key[KPT][NW];
+    u64 val[HAS_VAL ? KPT : 1];
+    u32 dig[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const u32 idx = wave * (WAVE * KPT) + j * WAVE + lane;
+        const bool ok = idx < nvalid;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) key[j][w] = ok ? a.keys_in[(base + idx) * NW + w] : ~0ULL;
+        if (HAS_VAL) val[j] = ok ? a.vals_in[base + idx] : 0;
+        dig[j] = (u32)(pick_word<NW>(key[j], a.word) >> a.shift) & dmask;
+    }
+
+    // ---- rank inside the wave (stable) ----------------------------------------------------------
+    volatile u32 *wh = s_whist + wave * 256;
+    const u64 lt_mask = (1ULL << lane) - 1;
+    u32 rank[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const u32 d = dig[j];
+        u64 peers = ~0ULL;
+        for (int b = 0; b < a.bits; ++b) {
+            const bool bit = (d >> b) & 1;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const u32 before = (u32)__popcll(peers & lt_mask);
+        const u32 cnt = (u32)__popcll(peers);
+        const u32 old = wh[d];
+        __builtin_amdgcn_wave_barrier();
+        if (before == 0) wh[d] = old + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[j] = old + before;
+    }
+    __syncthreads();
+
+    // ---- digit totals, cross-wave exclusive prefix, digit start inside the tile ----------------
+    u32 total;
+    {
+        u32 run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { u32 c = s_whist[w * 256 + tid]; s_whist[w * 256 + tid] = run; run += c; }
+        total = run;
+    }
+    u32 tile_total;
+    const u32 dstart = block_excl_scan_256<u32>(total, s_scan, &tile_total);
+    s_dstart[tid] = dstart;
+
+    // ---- publish this tile's digit count ---------------------------------------------------------
+    LB *lb = reinterpret_cast<LB *>(a.lookback);
+    LB *mine = lb + tile * 256 + tid;
+    if (tile == 0) __hip_atomic_store(mine, (LB)(L::INCL | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(mine, (LB)(L::AGG | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+
+    // ---- permute through LDS into digit order (overlaps the predecessors' progress) ------------
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const u32 d = dig[j];
+        const u32 lpos = s_dstart[d] + s_whist[wave * 256 + d] + rank[j];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s_keys[lpos * NW + w] = key[j][w];
+        if (HAS_VAL) s_vals[lpos] = val[j];
+    }
+
+    // ---- decoupled look-back: exclusive prefix of digit `tid` over all earlier tiles ----------
+    u64 excl = 0;
+    if (tile > 0) {
+        long long t = (long long)tile - 1;
+        u32 spins = 0;
+        while (t >= 0) {
+            const LB v = __hip_atomic_load(lb + (u64)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const LB f = v & L::FMASK;
+            if (f == 0) {
+                if (++spins > LOOKBACK_SPIN_LIMIT) { atomicOr(a.err, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += (u64)(v & L::VMASK);
+            if (f == L::INCL) break;
+            --t;
+        }
+        __hip_atomic_store(mine, (LB)(L::INCL | (LB)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_delta[tid] = (long long)(a.gbase[tid] + excl) - (long long)dstart;
+    __syncthreads();
+
+    // ---- coalesced scatter -----------------------------------------------------------------------
+    for (u32 i = tid; i < nvalid; i += SORT_THREADS) {
+        u64 k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = s_keys[i * NW + w];
+        const u32 d = (u32)(pick_word<NW>(k, a.word) >> a.shift) & dmask;
+        const u64 o = (u64)(s_delta[d] + (long long)i);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a.keys_out[o * NW + w] = k[w];
+        if (HAS_VAL) a.vals_out[o] = s_vals[i];
+    }
+}
+
+} // namespace hsk

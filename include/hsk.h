@@ -1,0 +1,194 @@
+/*
+ * hsk.h -- C ABI of libhsk.so, the MI355X (gfx950) k-mer counting hot path.
+ *
+ * This is the drop-in boundary for the reference's `kmerops` path: everything that
+ * hysortk::kmer_count() (reference src/hysortk.cpp:36-96) does between receiving the
+ * 2-bit packed DnaBuffer and returning the filtered KmerListS --
+ *     prepare_supermer   (reference src/kmerops.cpp:23-127)
+ *     exchange_supermer  (reference src/kmerops.cpp:130-195)
+ *     filter_kmer        (reference src/kmerops.cpp:198-250)
+ * -- runs behind hsk_count() as hand-written HIP kernels.  The C++ shim in
+ * include/hysortk/ (same names and layouts as the reference's public headers) and the Python
+ * host mirror (hysortk_amd/) both sit on top of exactly these entry points.
+ *
+ * Rules: plain C, POD only, no exceptions cross the boundary, every function returns an
+ * hsk_status (0 = ok).  Buffers returned in hsk_result are owned by the library and released
+ * by hsk_result_free().  One hsk_ctx per process and GPU; a ctx is not thread-safe.
+ */
+#ifndef HSK_H_
+#define HSK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSK_ABI_VERSION 1
+
+typedef enum {
+    HSK_OK = 0,
+    HSK_ERR_INVALID_ARG = 1,   /* bad K/M/L/U/ntasks or NULL pointer (reference: static_assert, compiletime.h:10-22) */
+    HSK_ERR_NO_DEVICE = 2,     /* no HIP device / wrong arch: the product path never falls back to a CPU */
+    HSK_ERR_HIP = 3,           /* a HIP runtime call failed; see hsk_last_error() */
+    HSK_ERR_OOM = 4,           /* device or pinned-host allocation failed */
+    HSK_ERR_DISPATCH = 5,      /* "Cannot dispatch tasks. May be too unbalanced." (reference kmerops.cpp:1319) */
+    HSK_ERR_INTERNAL = 6,      /* device-side consistency check failed (e.g. look-back timeout) */
+    HSK_ERR_COMM = 7,          /* RCCL not available / collective failed */
+    HSK_ERR_UNSUPPORTED = 8    /* valid in the reference, not built yet here */
+} hsk_status;
+
+/* Runtime form of the reference's compile-time macros (reference Makefile:1-46). */
+typedef struct {
+    int32_t kmer_size;        /* KMER_SIZE        2 < K < 96, K % 32 != 0 (reference UB, kmer.hpp:260) */
+    int32_t minimizer_size;   /* MINIMIZER_SIZE   0 < M < K, M <= 31 */
+    int32_t lower_freq;       /* LOWER_KMER_FREQ  1 <= L <= U */
+    int32_t upper_freq;       /* UPPER_KMER_FREQ  U <= 65535 */
+    int32_t extension;        /* EXTENSION        0 | 1: carry (PosInRead, ReadId) through the sort */
+    int32_t ntasks;           /* tot_tasks of prepare_supermer (kmerops.cpp:40-43,76); 0 = pick for the GPU */
+    int32_t device;           /* HIP device ordinal */
+    int32_t plain_dispatcher; /* PLAIN_DISPATCHER: 1 = round robin, 0 = balanced (kmerops.cpp:115-119) */
+    double  dispatch_upper_coe; /* DISPATCH_UPPER_COE (1.5) */
+    double  dispatch_step;      /* DISPATCH_STEP      (0.05) */
+    int32_t radix_bits;       /* digit width of the LSD radix sort: 8 (default) */
+    int32_t flags;            /* HSK_FLAG_* */
+    int64_t reserved[4];
+} hsk_config;
+
+#define HSK_FLAG_PROFILE      1   /* HIP-event timing of every radix scatter launch (hsk_stats) */
+#define HSK_FLAG_KEEP_DEVICE  2   /* hsk_count_device leaves the result in HBM (entries_dev) */
+
+typedef struct hsk_ctx hsk_ctx;
+
+/*
+ * Result of one hsk_count(): the rank-local KmerListS.
+ *   entries: n records of (nw + 1) uint64 = { TKmer longs[nw]; uint64_t cnt } -- byte-identical
+ *            to the reference's KmerListEntryS for EXTENSION == 0 (kmer.hpp:368-383), so the
+ *            C++ shim memcpy's it into std::vector<KmerListEntryS>.
+ *   order:   ascending task id over the tasks this rank owns (copy_results, kmerops.cpp:883-904);
+ *            inside a task ascending as a little-endian multi-word integer (= sort_task,
+ *            kmerops.cpp:1382, RADULS order; for K <= 32 this is plain ascending uint64).
+ *   EXTENSION == 1: CSR payload; entry i owns pos/rid[payload_off[i] .. payload_off[i+1]).
+ */
+typedef struct {
+    uint64_t n;               /* number of (k-mer, count) entries */
+    int32_t  nw;              /* 64-bit words per k-mer: 1 (K<=32), 2 (K<=64), 3 (K<=95) */
+    int32_t  ntasks;          /* tot_tasks actually used */
+    uint64_t *entries;        /* host (pinned) n * (nw+1) words; NULL with HSK_FLAG_KEEP_DEVICE */
+    uint64_t *task_off;       /* host, ntasks+1: entry range of each task id (empty if not owned) */
+    uint64_t *payload_off;    /* host, n+1 (EXTENSION) */
+    uint32_t *pos;            /* host, payload_off[n] (EXTENSION): PosInRead */
+    int32_t  *rid;            /* host, payload_off[n] (EXTENSION): ReadId */
+    uint64_t *histo;          /* host, histo_len bins: histo[c] = #entries with cnt == c */
+    uint64_t histo_len;
+    void     *entries_dev;    /* device copy when HSK_FLAG_KEEP_DEVICE (owned by the ctx) */
+    /* --- measurements of this call --- */
+    uint64_t total_kmers;     /* k-mers extracted on this rank (after the exchange) */
+    uint64_t total_supermers;
+    uint64_t total_supermer_bytes;
+    double   ms_total;        /* device time of the whole path (HIP events) */
+    double   ms_parse;        /* minimizer/supermer kernels */
+    double   ms_exchange;     /* RCCL all-to-all (0 on one GPU) */
+    double   ms_extract;      /* supermer -> canonical k-mer kernels */
+    double   ms_sort;         /* histogram + all radix passes */
+    double   ms_count;        /* merge-count + filter */
+    double   ms_d2h;          /* result copy to the host */
+    void    *priv;            /* library bookkeeping */
+} hsk_result;
+
+/* Per-kernel accounting of the dominant kernel (radix scatter pass), filled when
+ * HSK_FLAG_PROFILE is set.  bytes = algorithmic bytes (records read + written). */
+typedef struct {
+    uint64_t scatter_launches;
+    uint64_t scatter_keys;        /* sum over launches of keys moved */
+    uint64_t scatter_bytes;       /* sum over launches of 2 * record_bytes * keys */
+    double   scatter_ms;          /* sum of launch durations (HIP events on the launch stream) */
+    uint64_t hist_launches;
+    uint64_t hist_bytes;
+    double   hist_ms;
+    int64_t  reserved[8];
+} hsk_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int  hsk_abi_version(void);
+int  hsk_init(const hsk_config *cfg, hsk_ctx **out);
+void hsk_destroy(hsk_ctx *ctx);
+const char *hsk_strerror(int status);
+const char *hsk_last_error(const hsk_ctx *ctx);   /* detail text of the last failure */
+void hsk_config_default(hsk_config *cfg);          /* reference Makefile defaults: K=31 M=17 L=15 U=40 */
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/*
+ * hsk_count: replaces prepare_supermer + exchange_supermer + filter_kmer for the reads of
+ * this rank.  Input is the reference's DnaBuffer memory as is (dnabuffer.hpp:14, dnaseq.hpp:33):
+ *   packed        2-bit bases, 4 per byte, first base in the two MSBs; every read starts on a
+ *                 byte boundary
+ *   read_byte_off nreads offsets into packed (DnaBuffer::getbufoffset)
+ *   read_len      nreads lengths in bases (DnaSeq::size)
+ *   rid_base      global id of read 0 (reference: MPI_Exscan of read counts, kmerops.cpp:65-71)
+ * Collective over the communicator when hsk_comm_init() has been called.
+ */
+int hsk_count(hsk_ctx *ctx, const uint8_t *packed, uint64_t packed_bytes,
+              const uint64_t *read_byte_off, const uint32_t *read_len, uint64_t nreads,
+              int64_t rid_base, hsk_result *out);
+
+/* Same, inputs already resident in HBM (d_read_byte_off has nreads entries). */
+int hsk_count_device(hsk_ctx *ctx, const void *d_packed, uint64_t packed_bytes,
+                     const void *d_read_byte_off, const void *d_read_len, uint64_t nreads,
+                     int64_t rid_base, hsk_result *out);
+
+void hsk_result_free(hsk_ctx *ctx, hsk_result *res);
+int  hsk_get_stats(hsk_ctx *ctx, hsk_stats *out, int reset);
+
+/* ---- stage entry points (each one is a reference function of SURVEY 8a; used by the parity
+ *      tests and by callers that want one stage only) ---------------------------------------- */
+/* a4: FindKmerDestinationsParallel (kmerops.cpp:1010): dest[j] for every k-mer of every read,
+ * concatenated in read order; dest_off[r] .. dest_off[r+1] is read r.  Host in / host out. */
+int hsk_stage_destinations(hsk_ctx *ctx, const uint8_t *packed, uint64_t packed_bytes,
+                           const uint64_t *read_byte_off, const uint32_t *read_len, uint64_t nreads,
+                           int32_t *dest, uint64_t dest_capacity, uint64_t *dest_off);
+/* a5+a11: supermer split followed by GetRepKmers: the canonical k-mers (nw words each, plus
+ * pos,rid when EXTENSION) of task `task`, in unspecified order.  Returns count in *n. */
+int hsk_stage_task_kmers(hsk_ctx *ctx, const uint8_t *packed, uint64_t packed_bytes,
+                         const uint64_t *read_byte_off, const uint32_t *read_len, uint64_t nreads,
+                         int64_t rid_base, int32_t task, uint64_t *keys, uint32_t *pos, int32_t *rid,
+                         uint64_t capacity, uint64_t *n);
+/* a12: sort_task (kmerops.cpp:1382): in-place LSD radix sort of n records of nw words by their
+ * first key_bytes bytes read as a little-endian integer; optional 8-byte payload per record. */
+int hsk_stage_sort(hsk_ctx *ctx, uint64_t *keys, uint64_t *vals, uint64_t n, int32_t nw);
+/* a13: count_sorted_kmers (kmerops.cpp:1410) on a sorted host array; writes entries
+ * {key words, cnt} to out_entries (capacity in entries), *n_out = number kept. */
+int hsk_stage_count_sorted(hsk_ctx *ctx, const uint64_t *sorted_keys, uint64_t n, int32_t nw,
+                           uint64_t *out_entries, uint64_t capacity, uint64_t *n_out);
+
+/* ---- host-side planning (pure CPU; usable without a GPU) ---------------------------------- */
+/* tot_tasks rule of prepare_supermer (kmerops.cpp:40-43,76). */
+int hsk_plan_tot_tasks(int omp_max_threads, int thread_per_worker, int avg_task_per_worker, int nprocs);
+/* HeavyHitterClassifier (kmerops.cpp:1157-1199). */
+int hsk_plan_classify(const uint64_t *task_kmers, int ntasks, double unbalanced_ratio, int32_t *types);
+/* BalancedDispatcher / RoundRobinDispatcher (kmerops.cpp:1201-1327): task -> owner rank. */
+int hsk_plan_dispatch(const uint64_t *task_bytes, int ntasks, int nprocs, int plain,
+                      double upper_coe, double step, int32_t *owner);
+/* FastaIndex::getpartition (fastaindex.cpp:52-100): contiguous split of reads by bases. */
+int hsk_plan_partition_reads(const uint64_t *read_len, uint64_t nreads, int nprocs, uint64_t *counts);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) -------------------------------------- */
+#define HSK_UNIQUE_ID_BYTES 128
+int hsk_comm_get_unique_id(void *id128);                       /* rank 0, then broadcast by the caller */
+int hsk_comm_init(hsk_ctx *ctx, int nranks, int rank, const void *id128);
+int hsk_comm_destroy(hsk_ctx *ctx);
+
+/* ---- synthetic reads, generated in HBM (bench / tests) ------------------------------------ */
+/* S-reads(G, c) of BASELINE.md: random genome of genome_len bases, error-free reads of read_len
+ * bases sampled uniformly, strand 50/50.  Outputs device pointers owned by the ctx (freed by
+ * hsk_synth_free or hsk_destroy).  The same generator exists in numpy (hysortk_amd/synth.py). */
+int hsk_synth_reads(hsk_ctx *ctx, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed,
+                    void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
+int hsk_synth_free(hsk_ctx *ctx, void *d_packed, void *d_read_byte_off, void *d_read_len);
+int hsk_memcpy_d2h(hsk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSK_H_ */
