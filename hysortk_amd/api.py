@@ -1,0 +1,441 @@
+"""Host-side mirror of the reference's public interface (include/hysortk.hpp:10-16) on top of the
+C ABI of libhsk.so.  Same names, argument meaning and error behaviour as the reference:
+
+    read_dna_buffer(fasta_fname, comm)        reference src/hysortk.cpp:18-33
+    kmer_count(mydna, comm)                   reference src/hysortk.cpp:36-96
+    print_kmer_histogram(kmerlist, comm)      reference src/hysortk.cpp:98-136
+    write_output_file(kmerlist, outdir, comm) reference src/hysortk.cpp:138-164
+    DnaBuffer / DnaSeq                        reference include/dnabuffer.hpp:14, include/dnaseq.hpp:33
+    KmerList (= KmerListS)                    reference include/kmer.hpp:368-410
+
+The reference's compile-time macros (KMER_SIZE, MINIMIZER_SIZE, LOWER/UPPER_KMER_FREQ, EXTENSION,
+Makefile:1-46) are keyword arguments with the Makefile's defaults.  `comm` is a torch.distributed
+process group wrapper (hysortk_amd.dist.Comm) or None for one process; every function is
+collective over it, like the reference over its MPI_Comm.  All computation happens in libhsk.so
+on the GPU; this module only moves buffers and formats text.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import _lib
+
+# reference include/dnaseq.hpp:138-157: A/a/N/n -> 0, C/c -> 1, G/g -> 2, T/t -> 3, other -> 4
+_CODETAB = np.full(256, 4, dtype=np.uint8)
+for _ch, _c in (("A", 0), ("a", 0), ("N", 0), ("n", 0), ("C", 1), ("c", 1), ("G", 2), ("g", 2), ("T", 3), ("t", 3)):
+    _CODETAB[ord(_ch)] = _c
+
+
+class HskError(RuntimeError):
+    """Raised where the reference throws std::runtime_error / aborts."""
+
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _lib.load().hsk_strerror(status).decode()
+        super().__init__(msg + (": " + detail if detail else ""))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def pack_sequence(seq):
+    """2-bit packs one read exactly like DnaSeq::compress (reference src/dnaseq.cpp:9-31): base i in
+    byte i/4 at shift 6-2*(i%4); tail bits zero; a non-ACGTN byte yields code 4 whose shifted value
+    (truncated to 8 bits) is OR-ed in, as in the reference."""
+    raw = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    n = raw.size
+    nb = (n + 3) // 4
+    codes = np.zeros(nb * 4, dtype=np.uint16)
+    codes[:n] = _CODETAB[raw]
+    codes = codes.reshape(nb, 4)
+    sh = np.array([6, 4, 2, 0], dtype=np.uint16)
+    return (np.bitwise_or.reduce((codes << sh) & 0xFF, axis=1)).astype(np.uint8)
+
+
+class DnaSeq:
+    """Non-owning view of one packed read (reference include/dnaseq.hpp:33)."""
+
+    def __init__(self, length, mem):
+        self._len, self._mem = int(length), mem
+
+    def size(self):
+        return self._len
+
+    def numbytes(self):
+        return (self._len + 3) // 4
+
+    def data(self):
+        return self._mem
+
+    def __getitem__(self, i):
+        return int(self._mem[i // 4] >> (6 - 2 * (i % 4))) & 3
+
+    def ascii(self):
+        b = np.asarray(self._mem[: self.numbytes()], dtype=np.uint8)
+        codes = np.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], axis=1).reshape(-1)[: self._len]
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes().decode()
+
+
+class DnaBuffer:
+    """Owning contiguous 2-bit buffer + read index (reference include/dnabuffer.hpp:14).
+    Every read starts on a byte boundary (src/dnabuffer.cpp:24-31)."""
+
+    def __init__(self, bufsize=0):
+        self._chunks = []
+        self._lens = []
+        self._buf = None
+        self._off = None
+        self._bufsize = bufsize
+
+    @classmethod
+    def from_arrays(cls, packed, read_off, read_len):
+        b = cls()
+        b._buf = np.ascontiguousarray(packed, dtype=np.uint8)
+        b._off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        b._lens = list(np.asarray(read_len, dtype=np.uint32))
+        return b
+
+    @classmethod
+    def from_sequences(cls, seqs):
+        b = cls()
+        for s in seqs:
+            b.push_back(s)
+        return b
+
+    def push_back(self, s, length=None):
+        if length is not None:
+            s = s[:length]
+        self._chunks.append(pack_sequence(s))
+        self._lens.append(len(s))
+        self._buf = None
+
+    def _finalize(self):
+        if self._buf is None:
+            self._buf = np.concatenate(self._chunks) if self._chunks else np.zeros(0, dtype=np.uint8)
+            nb = np.array([c.size for c in self._chunks], dtype=np.uint64)
+            self._off = np.zeros(len(self._chunks), dtype=np.uint64)
+            if len(self._chunks):
+                self._off[1:] = np.cumsum(nb)[:-1]
+        return self._buf
+
+    def size(self):
+        return len(self._lens)
+
+    __len__ = size
+
+    def getbufsize(self):
+        return int(self._finalize().size)
+
+    def __getitem__(self, i):
+        buf = self._finalize()
+        o = int(self._off[i])
+        return DnaSeq(self._lens[i], buf[o:o + (int(self._lens[i]) + 3) // 4])
+
+    def arrays(self):
+        buf = self._finalize()
+        return buf, self._off, np.asarray(self._lens, dtype=np.uint32)
+
+
+class KmerList:
+    """KmerListS (reference include/kmer.hpp:410): parallel arrays instead of a vector of structs.
+    kmers[i] are the TKmer words (longs[0..nw)), cnt[i] the count; with EXTENSION entry i owns
+    pos/rid[payload_off[i]:payload_off[i+1]] (KmerListEntryS::pos / ::rid)."""
+
+    def __init__(self, k, kmers, cnt, task_off, payload_off=None, pos=None, rid=None, histo=None, info=None):
+        self.k = k
+        self.kmers, self.cnt, self.task_off = kmers, cnt, task_off
+        self.payload_off, self.pos, self.rid = payload_off, pos, rid
+        self.histo = histo
+        self.info = info or {}
+
+    def __len__(self):
+        return int(self.cnt.size)
+
+    def kmer_string(self, i):
+        w = self.kmers[i]
+        return "".join("ACGT"[(int(w[j // 32]) >> (2 * (31 - j % 32))) & 3] for j in range(self.k))
+
+    def strings(self):
+        n = len(self)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        cols = [lut[((self.kmers[:, j // 32] >> np.uint64(2 * (31 - j % 32))) & np.uint64(3)).astype(np.int64)] for j in range(self.k)]
+        arr = np.stack(cols, axis=1) if n else np.zeros((0, self.k), dtype=np.uint8)
+        return [r.tobytes().decode() for r in arr]
+
+
+class Context:
+    """One hsk_ctx (one process, one GPU)."""
+
+    def __init__(self, K=31, M=17, L=15, U=40, EXT=0, ntasks=0, device=0, plain_dispatcher=0, radix_bits=8, profile=False, keep_device=False):
+        self.lib = _lib.load()
+        cfg = _lib.Config()
+        self.lib.hsk_config_default(C.byref(cfg))
+        cfg.kmer_size, cfg.minimizer_size, cfg.lower_freq, cfg.upper_freq = K, M, L, U
+        cfg.extension, cfg.ntasks, cfg.device, cfg.plain_dispatcher, cfg.radix_bits = EXT, ntasks, device, plain_dispatcher, radix_bits
+        cfg.flags = (_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_KEEP_DEVICE if keep_device else 0)
+        self.cfg = cfg
+        self.K, self.EXT = K, EXT
+        self.nw = (K + 31) // 32
+        h = C.c_void_p()
+        rc = self.lib.hsk_init(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise HskError(rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HskError(rc, self.lib.hsk_last_error(self.h).decode())
+
+    # ---- multi-GPU -----------------------------------------------------------------------------
+    def comm_init(self, comm):
+        """comm: hysortk_amd.dist.Comm; rank 0 creates the RCCL id, it is broadcast over comm."""
+        if comm is None or comm.size == 1:
+            return
+        ident = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+        if comm.rank == 0:
+            self._check(self.lib.hsk_comm_get_unique_id(ident))
+        raw = comm.bcast_bytes(bytes(ident), root=0)
+        buf = (C.c_char * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
+        self._check(self.lib.hsk_comm_init(self.h, comm.size, comm.rank, buf))
+
+    # ---- the hot path -----------------------------------------------------------------------------
+    def _wrap(self, res):
+        n, nw, nt = int(res.n), int(res.nw), int(res.ntasks)
+        info = dict(total_kmers=int(res.total_kmers), total_supermers=int(res.total_supermers),
+                    total_supermer_bytes=int(res.total_supermer_bytes), ntasks=nt,
+                    ms_total=res.ms_total, ms_parse=res.ms_parse, ms_exchange=res.ms_exchange, ms_extract=res.ms_extract,
+                    ms_sort=res.ms_sort, ms_count=res.ms_count, ms_d2h=res.ms_d2h)
+        task_off = np.ctypeslib.as_array(res.task_off, shape=(nt + 1,)).copy()
+        histo = np.ctypeslib.as_array(res.histo, shape=(int(res.histo_len),)).copy()
+        kmers = cnt = payoff = pos = rid = None
+        if res.entries:
+            e = np.ctypeslib.as_array(res.entries, shape=(max(n, 1) * (nw + 1),))[: n * (nw + 1)].reshape(n, nw + 1)
+            kmers, cnt = e[:, :nw].copy(), e[:, nw].copy()
+            if res.payload_off:
+                payoff = np.ctypeslib.as_array(res.payload_off, shape=(n + 1,)).copy()
+                P = int(payoff[n])
+                pos = np.ctypeslib.as_array(res.pos, shape=(max(P, 1),))[:P].copy()
+                rid = np.ctypeslib.as_array(res.rid, shape=(max(P, 1),))[:P].copy()
+        else:
+            info["n"] = n
+        self.lib.hsk_result_free(self.h, C.byref(res))
+        if kmers is None:
+            kmers, cnt = np.zeros((0, nw), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        return KmerList(self.K, kmers, cnt, task_off, payoff, pos, rid, histo, info)
+
+    def count(self, dna, rid_base=0):
+        packed, off, lens = dna.arrays() if isinstance(dna, DnaBuffer) else dna
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        res = _lib.Result()
+        self._check(self.lib.hsk_count(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, rid_base, C.byref(res)))
+        return self._wrap(res)
+
+    def count_device(self, d_packed, packed_bytes, d_off, d_len, nreads, rid_base=0):
+        res = _lib.Result()
+        self._check(self.lib.hsk_count_device(self.h, d_packed, packed_bytes, d_off, d_len, nreads, rid_base, C.byref(res)))
+        return self._wrap(res)
+
+    def stats(self, reset=True):
+        s = _lib.Stats()
+        self._check(self.lib.hsk_get_stats(self.h, C.byref(s), 1 if reset else 0))
+        return {k: getattr(s, k) for k, _ in _lib.Stats._fields_ if k != "reserved"}
+
+    # ---- stages -------------------------------------------------------------------------------------
+    def stage_destinations(self, dna):
+        packed, off, lens = dna.arrays() if isinstance(dna, DnaBuffer) else dna
+        packed = np.ascontiguousarray(packed, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.uint64); lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        total = int(np.maximum(lens.astype(np.int64) - self.K + 1, 0).sum())
+        dest = np.zeros(max(total, 1), dtype=np.int32)
+        doff = np.zeros(lens.size + 1, dtype=np.uint64)
+        self._check(self.lib.hsk_stage_destinations(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, _p(dest), total, _p(doff)))
+        return dest[:total], doff
+
+    def stage_task_kmers(self, dna, task, rid_base=0):
+        packed, off, lens = dna.arrays() if isinstance(dna, DnaBuffer) else dna
+        packed = np.ascontiguousarray(packed, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.uint64); lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        cap = int(np.maximum(lens.astype(np.int64) - self.K + 1, 0).sum())
+        keys = np.zeros((max(cap, 1), self.nw), dtype=np.uint64)
+        pos = np.zeros(max(cap, 1), dtype=np.uint32)
+        rid = np.zeros(max(cap, 1), dtype=np.int32)
+        n = C.c_uint64(0)
+        self._check(self.lib.hsk_stage_task_kmers(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, rid_base, task,
+                                                  _p(keys), _p(pos), _p(rid), cap, C.byref(n)))
+        n = int(n.value)
+        return keys[:n], pos[:n], rid[:n]
+
+    def stage_sort(self, keys, vals=None):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        if keys.ndim == 1:
+            keys = keys.reshape(-1, 1)
+        n, nw = keys.shape
+        out = keys.copy()
+        v = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint64).copy()
+        self._check(self.lib.hsk_stage_sort(self.h, _p(out), _p(v), n, nw))
+        return (out, v) if vals is not None else out
+
+    def stage_count_sorted(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        if keys.ndim == 1:
+            keys = keys.reshape(-1, 1)
+        n, nw = keys.shape
+        out = np.zeros((max(n, 1), nw + 1), dtype=np.uint64)
+        m = C.c_uint64(0)
+        self._check(self.lib.hsk_stage_count_sorted(self.h, _p(keys), n, nw, _p(out), n, C.byref(m)))
+        m = int(m.value)
+        return out[:m, :nw].copy(), out[:m, nw].copy()
+
+    # ---- synthetic reads in HBM ------------------------------------------------------------------------
+    def synth_reads(self, genome_len, read_len, nreads, seed):
+        dp, do, dl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb = C.c_uint64(0)
+        self._check(self.lib.hsk_synth_reads(self.h, genome_len, read_len, nreads, seed, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
+        return dp, int(nb.value), do, dl
+
+    def synth_free(self, dp, do, dl):
+        self.lib.hsk_synth_free(self.h, dp, do, dl)
+
+    def d2h(self, dptr, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        self._check(self.lib.hsk_memcpy_d2h(self.h, _p(out), dptr, nbytes))
+        return out
+
+
+# ---- pure-host planning (no GPU needed) ------------------------------------------------------------------
+def plan_tot_tasks(omp_max_threads, nprocs, thread_per_worker=4, avg_task_per_worker=3):
+    return _lib.load().hsk_plan_tot_tasks(omp_max_threads, thread_per_worker, avg_task_per_worker, nprocs)
+
+
+def plan_classify(task_kmers, unbalanced_ratio=2.3):
+    a = np.ascontiguousarray(task_kmers, dtype=np.uint64)
+    out = np.zeros(a.size, dtype=np.int32)
+    rc = _lib.load().hsk_plan_classify(_p(a), a.size, unbalanced_ratio, _p(out))
+    if rc:
+        raise HskError(rc)
+    return out
+
+
+def plan_dispatch(task_bytes, nprocs, plain=False, upper_coe=1.5, step=0.05):
+    a = np.ascontiguousarray(task_bytes, dtype=np.uint64)
+    out = np.zeros(a.size, dtype=np.int32)
+    rc = _lib.load().hsk_plan_dispatch(_p(a), a.size, nprocs, 1 if plain else 0, upper_coe, step, _p(out))
+    if rc:
+        raise HskError(rc)          # "Cannot dispatch tasks. May be too unbalanced." (kmerops.cpp:1319)
+    return out
+
+
+def plan_partition_reads(read_len, nprocs):
+    a = np.ascontiguousarray(read_len, dtype=np.uint64)
+    out = np.zeros(nprocs, dtype=np.uint64)
+    rc = _lib.load().hsk_plan_partition_reads(_p(a), a.size, nprocs, _p(out))
+    if rc:
+        raise HskError(rc)
+    return out
+
+
+# ---- the four reference functions ---------------------------------------------------------------------------
+def read_fai(path):
+    """Parses <fasta>.fai records: name, length, byte offset of first base, bases per line
+    (reference src/fastaindex.cpp:118-123 reads the first four columns)."""
+    recs = []
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            if len(p) >= 4:
+                recs.append((p[0], int(p[1]), int(p[2]), int(p[3])))
+    return recs
+
+
+def read_dna_buffer(fasta_fname, comm=None):
+    """FASTA + .fai -> this rank's DnaBuffer: rank r gets a contiguous run of records chosen by
+    FastaIndex::getpartition (reference src/fastaindex.cpp:52-100), 2-bit packed."""
+    recs = read_fai(fasta_fname + ".fai")
+    size = 1 if comm is None else comm.size
+    rank = 0 if comm is None else comm.rank
+    counts = plan_partition_reads([r[1] for r in recs], size) if size > 1 else np.array([len(recs)], dtype=np.uint64)
+    first = int(counts[:rank].sum())
+    mine = recs[first:first + int(counts[rank])]
+    buf = DnaBuffer()
+    buf.first_read_id = first
+    if not mine:
+        return buf
+    with open(fasta_fname, "rb") as f:
+        for _, length, pos, linebases in mine:
+            nlines = (length + linebases - 1) // linebases if linebases else 0
+            f.seek(pos)
+            raw = f.read(length + nlines)
+            buf.push_back(raw.replace(b"\n", b"")[:length].decode())
+    return buf
+
+
+_CTX_CACHE = {}
+
+
+def kmer_count(mydna, comm=None, K=31, M=17, L=15, U=40, EXT=0, ntasks=0, device=None):
+    """The path the reference times as "Overall kmer counting (Excluding I/O)" (src/hysortk.cpp:91)."""
+    if device is None:
+        device = 0 if comm is None else comm.local_rank
+    key = (K, M, L, U, EXT, ntasks, device, None if comm is None else id(comm))
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None:
+        ctx = Context(K=K, M=M, L=L, U=U, EXT=EXT, ntasks=ntasks, device=device)
+        ctx.comm_init(comm)
+        _CTX_CACHE[key] = ctx
+    rid_base = 0
+    if comm is not None and comm.size > 1:
+        rid_base = comm.exscan_sum(mydna.size())        # MPI_Exscan, reference src/kmerops.cpp:65-71
+    return ctx.count(mydna, rid_base=rid_base)
+
+
+def histogram_text(histo):
+    """Text of print_kmer_histogram (reference src/hysortk.cpp:122-131); 64-bit bins (the reference's
+    int bins overflow beyond 2^31-1 k-mers per count)."""
+    lines = ["#count\tnumkmers"]
+    for i in range(1, len(histo)):
+        if histo[i] > 0:
+            lines.append("%d\t%d" % (i, int(histo[i])))
+    return "\n".join(lines) + "\n\n"
+
+
+def print_kmer_histogram(kmerlist, comm=None, file=None):
+    histo = np.asarray(kmerlist.histo, dtype=np.uint64)
+    if comm is not None and comm.size > 1:
+        histo = comm.allreduce_sum(histo)                # MPI_Allreduce, reference src/hysortk.cpp:115
+    if comm is None or comm.rank == 0:
+        (file or sys.stdout).write(histogram_text(histo))
+    if comm is not None:
+        comm.barrier()
+
+
+def write_output_file(kmerlist, output_dir, comm=None):
+    """<output_dir>/<rank>.out with lines "KMER\\tcount" (reference src/hysortk.cpp:138-164)."""
+    rank = 0 if comm is None else comm.rank
+    fname = os.path.join(output_dir, "%d.out" % rank)
+    try:
+        f = open(fname, "w")
+    except OSError:
+        raise HskError(1, "cannot open output file " + fname)
+    with f:
+        strs = kmerlist.strings()
+        f.write("".join("%s\t%d\n" % (s, int(c)) for s, c in zip(strs, kmerlist.cnt)))

@@ -325,8 +325,8 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
     a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_bytes = st.sm_bytes; a.sm_pos = st.sm_pos; a.sm_rid = st.sm_rid;
     if (st.tot_sup) {
-        if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 2 * 8, c->stream, a);
-        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 2 * 8, c->stream, a);
+        if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
@@ -338,8 +338,6 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
 // ------------------------------------------------------------------------------------------------
 // stage: expand one task (a11)
 // ------------------------------------------------------------------------------------------------
-struct TaskSegs { std::vector<ExpSeg> segs; u64 ntiles = 0; u64 nkmers = 0; };
-
 static void finalize_segs(TaskSegs &ts)
 {
     u64 tile = 0;

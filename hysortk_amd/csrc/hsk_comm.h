@@ -1,0 +1,231 @@
+// hsk_comm.h -- the minimizer-bucket exchange across the GPUs of one node: RCCL over xGMI.
+//
+// Replaces the reference's MPI exchange (one process per GPU here, one MPI rank there):
+//   size matrix     MPI_Alltoallv of per-task counts      reference src/kmerops.cpp:751-811
+//   payload         fixed-slot MPI_Ialltoall rounds        reference src/kmerops.cpp:814-1008
+//   task sizes      MPI_Reduce + MPI_Bcast for dispatch    reference src/kmerops.cpp:1287,1325
+// The reference streams 80 000-byte slots through double buffers because MPI buffers live in host
+// RAM; on MI355X the whole supermer store of a rank is a few GB of a 288 GB HBM, so the payload
+// moves as ONE grouped send/recv per peer and array (a direct all-to-all-v: xGMI is a full mesh,
+// every pair has its own link, all seven peers transfer concurrently).  Tasks are stored grouped
+// by owner rank (hsk_parse.h), so each peer's share is one contiguous range: no packing kernel.
+//
+// RCCL is loaded lazily with dlopen so that the single-GPU path has no RCCL dependency at all and
+// a process that already carries a copy (PyTorch) shares it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hsk_expand.h"
+
+namespace hsk {
+
+struct UidByValue { char internal[128]; };
+
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ UidByValue, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+constexpr int RCCL_UINT8 = 1, RCCL_UINT64 = 5, RCCL_SUM = 0, RCCL_MAX = 2;
+
+inline RcclApi *rccl_api(std::string *err)
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (api.lib) return &api;
+    if (tried) { if (err) *err = "librccl not loadable"; return nullptr; }
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { if (err) *err = std::string("dlopen(librccl) failed: ") + dlerror(); return nullptr; }
+#define HSK_SYM(field, name) *(void **)(&api.field) = dlsym(h, name); if (!api.field) { if (err) *err = std::string("missing RCCL symbol ") + name; return nullptr; }
+    HSK_SYM(GetUniqueId, "ncclGetUniqueId") HSK_SYM(CommInitRank, "ncclCommInitRank") HSK_SYM(CommDestroy, "ncclCommDestroy")
+    HSK_SYM(AllReduce, "ncclAllReduce") HSK_SYM(Send, "ncclSend") HSK_SYM(Recv, "ncclRecv")
+    HSK_SYM(GroupStart, "ncclGroupStart") HSK_SYM(GroupEnd, "ncclGroupEnd") HSK_SYM(GetErrorString, "ncclGetErrorString")
+#undef HSK_SYM
+    api.lib = h;
+    return &api;
+}
+
+template <typename Pool>
+struct PoolBuf {
+    Pool &pool; void *p;
+    PoolBuf(Pool &pl, size_t bytes) : pool(pl), p(pl.alloc(bytes)) {}
+    ~PoolBuf() { pool.release(p); }
+};
+
+struct Comm {
+    RcclApi *api = nullptr;
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+    std::string last_error;
+
+    bool active() const { return comm != nullptr && nranks > 1; }
+
+    static int get_unique_id(void *id128)
+    {
+        std::string e; RcclApi *a = rccl_api(&e);
+        if (!a) return -1;
+        return a->GetUniqueId(id128);
+    }
+    int init(int nranks_, int rank_, const void *id128)
+    {
+        destroy();
+        nranks = nranks_; rank = rank_;
+        if (nranks_ == 1) return 0;
+        api = rccl_api(&last_error);
+        if (!api) return -1;
+        UidByValue id; memcpy(id.internal, id128, 128);
+        int rc = api->CommInitRank(&comm, nranks_, id, rank_);
+        if (rc) { last_error = std::string("ncclCommInitRank: ") + api->GetErrorString(rc); comm = nullptr; return rc; }
+        return 0;
+    }
+    void destroy()
+    {
+        if (comm && api) api->CommDestroy(comm);
+        comm = nullptr; nranks = 1; rank = 0;
+    }
+    int check(int rc, const char *what)
+    {
+        if (rc) last_error = std::string(what) + ": " + (api ? api->GetErrorString(rc) : "?");
+        return rc;
+    }
+
+    template <typename Pool>
+    int allreduce_u64(uint64_t *host, size_t n, int op, hipStream_t s, Pool &pool)
+    {
+        if (!active()) return 0;
+        PoolBuf<Pool> b(pool, n * 8);
+        if (!b.p) { last_error = "oom"; return -1; }
+        if (hipMemcpyAsync(b.p, host, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+        if (hipStreamSynchronize(s) != hipSuccess) return -2;
+        int rc = check(api->AllReduce(b.p, b.p, n, RCCL_UINT64, op, comm, s), "ncclAllReduce");
+        if (rc) return rc;
+        if (hipMemcpyAsync(host, b.p, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return -2;
+        if (hipStreamSynchronize(s) != hipSuccess) return -2;
+        return 0;
+    }
+    template <typename Pool> int allreduce_sum_u64(uint64_t *h, size_t n, hipStream_t s, Pool &p) { return allreduce_u64(h, n, RCCL_SUM, s, p); }
+    template <typename Pool> int allreduce_max_u64(uint64_t *h, size_t n, hipStream_t s, Pool &p) { return allreduce_u64(h, n, RCCL_MAX, s, p); }
+};
+
+struct ExchangeBuffers {
+    uint8_t *len = nullptr; uint8_t *bytes = nullptr; uint32_t *pos = nullptr; int32_t *rid = nullptr;
+    template <typename Pool> void release(Pool &pool)
+    {
+        pool.release(len); pool.release(bytes); pool.release(pos); pool.release(rid);
+        len = bytes = nullptr; pos = nullptr; rid = nullptr;
+    }
+};
+
+// Host-side plan of the all-to-all-v (pure arithmetic; also used by the CPU multi-rank tests
+// through hsk_plan_exchange): given the full size matrix M[src][task] = {supermers, bytes, kmers}
+// and the owner table, computes what `rank` sends to / receives from every peer and where the
+// (src, task) segments land in the receive arrays laid out [src][owned task ascending].
+struct ExchangePlan {
+    std::vector<uint64_t> send_sup, send_bytes, send_sup_off, send_byte_off;   // per peer
+    std::vector<uint64_t> recv_sup, recv_bytes, recv_sup_off, recv_byte_off;   // per peer
+    uint64_t recv_tot_sup = 0, recv_tot_bytes = 0;
+};
+
+inline void plan_exchange(int nranks, int rank, uint32_t ntasks, const std::vector<int32_t> &owner, const std::vector<uint32_t> &order,
+                          const std::vector<uint64_t> &M /* [nranks][ntasks][3] */, const std::vector<uint64_t> &task_base /* mine [ntasks][3] */,
+                          ExchangePlan &pl, std::vector<TaskSegs> &segs)
+{
+    pl.send_sup.assign(nranks, 0); pl.send_bytes.assign(nranks, 0); pl.send_sup_off.assign(nranks, 0); pl.send_byte_off.assign(nranks, 0);
+    pl.recv_sup.assign(nranks, 0); pl.recv_bytes.assign(nranks, 0); pl.recv_sup_off.assign(nranks, 0); pl.recv_byte_off.assign(nranks, 0);
+    const uint64_t *mine = &M[(size_t)rank * ntasks * 3];
+    std::vector<char> seen(nranks, 0);
+    for (uint32_t i = 0; i < ntasks; ++i) {                 // storage order: grouped by owner
+        const uint32_t t = order[i]; const int q = owner[t];
+        if (!seen[q]) { seen[q] = 1; pl.send_sup_off[q] = task_base[3 * t]; pl.send_byte_off[q] = task_base[3 * t + 1]; }
+        pl.send_sup[q] += mine[3 * t]; pl.send_bytes[q] += mine[3 * t + 1];
+    }
+    uint64_t so = 0, bo = 0;
+    for (int p = 0; p < nranks; ++p) {
+        pl.recv_sup_off[p] = so; pl.recv_byte_off[p] = bo;
+        for (uint32_t t = 0; t < ntasks; ++t) if (owner[t] == rank) { pl.recv_sup[p] += M[((size_t)p * ntasks + t) * 3]; pl.recv_bytes[p] += M[((size_t)p * ntasks + t) * 3 + 1]; }
+        so += pl.recv_sup[p]; bo += pl.recv_bytes[p];
+    }
+    pl.recv_tot_sup = so; pl.recv_tot_bytes = bo;
+    segs.assign(ntasks, TaskSegs());
+    std::vector<uint64_t> cs(nranks), cb(nranks);
+    for (int p = 0; p < nranks; ++p) { cs[p] = pl.recv_sup_off[p]; cb[p] = pl.recv_byte_off[p]; }
+    for (uint32_t t = 0; t < ntasks; ++t) {
+        if (owner[t] != rank) continue;
+        uint64_t koff = 0;
+        for (int p = 0; p < nranks; ++p) {
+            const uint64_t *m = &M[((size_t)p * ntasks + t) * 3];
+            if (m[0]) { ExpSeg s; s.sup_off = cs[p]; s.n_sup = m[0]; s.byte_off = cb[p]; s.kmer_off = koff; s.tile_start = 0; segs[t].segs.push_back(s); }
+            cs[p] += m[0]; cb[p] += m[1]; koff += m[2];
+        }
+        segs[t].nkmers = koff;
+    }
+}
+
+template <typename Pool>
+inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int /*K*/, uint32_t ntasks, const std::vector<int32_t> &owner,
+                              const std::vector<uint32_t> &order, const std::vector<uint64_t> &task_tot, const std::vector<uint64_t> &task_base,
+                              const uint8_t *sm_len, const uint8_t *sm_bytes, const uint32_t *sm_pos, const int32_t *sm_rid,
+                              ExchangeBuffers &xb, std::vector<TaskSegs> &segs)
+{
+    const int nr = cm.nranks, me = cm.rank;
+    // 1. size matrix: every rank contributes its row, the sum is the full matrix
+    std::vector<uint64_t> M((size_t)nr * ntasks * 3, 0);
+    for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)me * ntasks * 3 + i] = task_tot[i];
+    int rc = cm.allreduce_sum_u64(M.data(), M.size(), s, pool);
+    if (rc) return rc;
+    ExchangePlan pl;
+    plan_exchange(nr, me, ntasks, owner, order, M, task_base, pl, segs);
+    xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);
+    xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64);
+    if (ext) { xb.pos = (uint32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); xb.rid = (int32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); }
+    if (!xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid))) { cm.last_error = "oom"; return -1; }
+    // 2. payload: one grouped send/recv per peer and array (self: device copy)
+    if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return rc;
+    for (int q = 0; q < nr; ++q) {
+        if (q == me) continue;
+        if (pl.send_sup[q]) {
+            if ((rc = cm.check(cm.api->Send(sm_len + pl.send_sup_off[q], pl.send_sup[q], RCCL_UINT8, q, cm.comm, s), "ncclSend(len)"))) return rc;
+            if ((rc = cm.check(cm.api->Send(sm_bytes + pl.send_byte_off[q], pl.send_bytes[q], RCCL_UINT8, q, cm.comm, s), "ncclSend(bytes)"))) return rc;
+            if (ext) {
+                if ((rc = cm.check(cm.api->Send(sm_pos + pl.send_sup_off[q], pl.send_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclSend(pos)"))) return rc;
+                if ((rc = cm.check(cm.api->Send(sm_rid + pl.send_sup_off[q], pl.send_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclSend(rid)"))) return rc;
+            }
+        }
+        if (pl.recv_sup[q]) {
+            if ((rc = cm.check(cm.api->Recv(xb.len + pl.recv_sup_off[q], pl.recv_sup[q], RCCL_UINT8, q, cm.comm, s), "ncclRecv(len)"))) return rc;
+            if ((rc = cm.check(cm.api->Recv(xb.bytes + pl.recv_byte_off[q], pl.recv_bytes[q], RCCL_UINT8, q, cm.comm, s), "ncclRecv(bytes)"))) return rc;
+            if (ext) {
+                if ((rc = cm.check(cm.api->Recv(xb.pos + pl.recv_sup_off[q], pl.recv_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclRecv(pos)"))) return rc;
+                if ((rc = cm.check(cm.api->Recv(xb.rid + pl.recv_sup_off[q], pl.recv_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclRecv(rid)"))) return rc;
+            }
+        }
+    }
+    if ((rc = cm.check(cm.api->GroupEnd(), "ncclGroupEnd"))) return rc;
+    if (pl.send_sup[me]) {
+        if (hipMemcpyAsync(xb.len + pl.recv_sup_off[me], sm_len + pl.send_sup_off[me], pl.send_sup[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+        if (hipMemcpyAsync(xb.bytes + pl.recv_byte_off[me], sm_bytes + pl.send_byte_off[me], pl.send_bytes[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+        if (ext) {
+            if (hipMemcpyAsync(xb.pos + pl.recv_sup_off[me], sm_pos + pl.send_sup_off[me], pl.send_sup[me] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+            if (hipMemcpyAsync(xb.rid + pl.recv_sup_off[me], sm_rid + pl.send_sup_off[me], pl.send_sup[me] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+        }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return -2;
+    return 0;
+}
+
+} // namespace hsk

@@ -10,6 +10,7 @@
 // A task's supermers arrive as `nseg` segments (one per source rank; one on a single GPU).  Three
 // launches: tile sums (bytes, k-mers per 2048 supermers) -> per-segment exclusive scan -> expand.
 #pragma once
+#include <vector>
 #include "hsk_device.h"
 
 namespace hsk {
@@ -25,6 +26,9 @@ struct ExpSeg {
     u64 kmer_off;    // first output record of this segment, relative to the task's key array
     u64 tile_start;  // index of this segment's first tile in the task's tile list
 };
+
+// host-side description of one task's input: its segments, tile count and k-mer total
+struct TaskSegs { std::vector<ExpSeg> segs; u64 ntiles = 0; u64 nkmers = 0; };
 
 __device__ __forceinline__ int seg_of_tile(const ExpSeg *segs, int nseg, u64 tile)
 {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
     __shared__ u64 s_hash[PARSE_HMAX];
     __shared__ u16 s_dest[PARSE_TILE + 8];   // sizes of the statics are multiples of 16 B (dynamic LDS base stays aligned)
     __shared__ u64 s_rng[2];
-    extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // COUNT: 3*ntasks counters, EMIT: 2*ntasks cursors
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // COUNT: 3*ntasks counters, EMIT: 2*ntasks bases + ntasks cursors
 
     const int tid = threadIdx.x;
     const int K = a.k, M = a.m, W = K - M + 1;
@@ -89,8 +89,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
     if (MODE == PARSE_COUNT) {
         for (u32 i = tid; i < 3 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
     } else if (MODE == PARSE_EMIT) {
+        // s_cur[0 .. 2*ntasks) = absolute {slot, byte} bases of this workgroup, s_cur[2*ntasks + t] = packed
+        // running cursor of task t: supermers << 36 | bytes.  ONE atomic reserves both, so that slot order
+        // and byte order agree (the expander derives byte offsets from a prefix sum over the slots).
         for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS)
             s_cur[i] = a.blk_base[(u64)blockIdx.x * 2 * a.ntasks + i];
+        for (u32 i = tid; i < a.ntasks; i += PARSE_THREADS) s_cur[2 * a.ntasks + i] = 0;
     }
     __syncthreads();
 
@@ -205,8 +209,9 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                     atomicAdd((unsigned long long *)&s_cur[3 * d + 1], (unsigned long long)nb);
                     atomicAdd((unsigned long long *)&s_cur[3 * d + 2], (unsigned long long)nk);
                 } else {
-                    const u64 slot = atomicAdd((unsigned long long *)&s_cur[2 * d + 0], 1ULL);
-                    const u64 bo = atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)nb);
+                    const u64 cur = atomicAdd((unsigned long long *)&s_cur[2 * a.ntasks + d], (1ULL << 36) | (unsigned long long)nb);
+                    const u64 slot = s_cur[2 * d + 0] + (cur >> 36);
+                    const u64 bo = s_cur[2 * d + 1] + (cur & ((1ULL << 36) - 1));
                     a.sm_len[slot] = (u8)len;
                     if (EXT) {
                         a.sm_pos[slot] = posr[i];

@@ -1,0 +1,314 @@
+"""Parity of the HIP path (through the C ABI of libhsk.so) against the oracle and the golden
+fixtures produced by the real reference.  Bit-exact: everything here is integer/byte work."""
+import io
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import hsk_oracle
+    return hsk_oracle
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hysortk_amd
+    return hysortk_amd
+
+
+def _ctx(H, variant, **kw):
+    cfg = util.VARIANTS[variant]
+    args = dict(K=cfg["k"], M=cfg["m"], L=cfg["L"], U=cfg["U"], EXT=cfg["ext"])
+    args.update(kw)
+    return H.Context(**args)
+
+
+def _small_reads(H):
+    seqs = util.read_fasta(util.GOLDEN + "/reads_small.fa")
+    return seqs, H.DnaBuffer.from_sequences(seqs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1: packing (host code of the shim, checked here against the reference's bytes as well)
+# ---------------------------------------------------------------------------------------------------
+def test_pack_matches_reference_bytes(H):
+    g = util.load_json("stages_k31.json")
+    for rd in g["reads"]:
+        assert H.pack_sequence(rd["seq"]).tobytes().hex() == rd["packed"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# a4: destinations
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,tot", [("k31", 5), ("k31", 47), ("k51", 5), ("k21", 47)])
+def test_stage_destinations_golden(H, variant, tot):
+    g = util.load_json("stages_%s.json" % variant)
+    seqs = [rd["seq"] for rd in g["reads"]]
+    dna = H.DnaBuffer.from_sequences(seqs)
+    with _ctx(H, variant, ntasks=tot) as c:
+        dest, doff = c.stage_destinations(dna)
+    for r, rd in enumerate(g["reads"]):
+        want = rd["tasks"][str(tot)]["dest"]
+        got = dest[int(doff[r]):int(doff[r + 1])].tolist()
+        assert got == want, "read %d" % r
+
+
+def test_stage_destinations_vs_oracle_reads(H, O):
+    seqs, dna = _small_reads(H)
+    packed, off, lens = dna.arrays()
+    with _ctx(H, "k31", ntasks=13) as c:
+        dest, doff = c.stage_destinations(dna)
+    for r in range(len(seqs)):
+        want = O.dests(packed[int(off[r]):], int(lens[r]), 31, 17, 13)
+        assert np.array_equal(dest[int(doff[r]):int(doff[r + 1])], want), r
+
+
+# ---------------------------------------------------------------------------------------------------
+# a5 + a11: per-task canonical k-mers (supermer split + extraction); order unspecified
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["k31", "k51", "k21", "k31ext"])
+def test_stage_task_kmers_vs_oracle(H, O, variant):
+    cfg = util.VARIANTS[variant]
+    seqs, dna = _small_reads(H)
+    packed, off, lens = dna.arrays()
+    ntasks = 7
+    ores = O.count(packed, off, lens, k=cfg["k"], m=cfg["m"], L=1, U=65535, ext=cfg["ext"], ntasks=ntasks, rid_base=100)
+    with _ctx(H, variant, ntasks=ntasks) as c:
+        for t in range(ntasks):
+            keys, pos, rid = c.stage_task_kmers(dna, t, rid_base=100)
+            a, b = int(ores.task_off[t]), int(ores.task_off[t + 1])
+            okeys = np.repeat(ores.keys[a:b], ores.cnt[a:b].astype(np.int64), axis=0)
+            assert keys.shape == okeys.shape
+            if cfg["ext"]:
+                pa, pb = int(ores.payoff[a]), int(ores.payoff[b])
+                got = sorted(zip(map(tuple, keys.tolist()), rid.tolist(), pos.tolist()))
+                want = sorted(zip(map(tuple, okeys.tolist()), ores.rid[pa:pb].tolist(), ores.pos[pa:pb].tolist()))
+                assert got == want
+            else:
+                order = np.lexsort(keys.T[::-1])
+                oorder = np.lexsort(okeys.T[::-1])
+                assert np.array_equal(keys[order], okeys[oorder])
+
+
+# ---------------------------------------------------------------------------------------------------
+# a12: sort_task
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nw", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 63, 4096, 4097, 100003, 1 << 20])
+def test_stage_sort(H, nw, n):
+    rng = np.random.default_rng(n * 7 + nw)
+    keys = rng.integers(0, 1 << 63, size=(n, nw), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, nw), dtype=np.uint64)
+    if n > 100:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]          # plenty of duplicates
+        keys[::7, nw - 1] &= np.uint64(0xFF)                  # skewed high digits
+    with H.Context(K=31 if nw == 1 else (51 if nw == 2 else 80)) as c:
+        out = c.stage_sort(keys)
+        vals = np.arange(n, dtype=np.uint64)
+        out2, v2 = c.stage_sort(keys, vals)
+    # little-endian multiword order: word nw-1 most significant
+    order = np.lexsort([keys[:, w] for w in range(nw)])
+    assert np.array_equal(out, keys[order])
+    assert np.array_equal(out2, keys[order])
+    assert np.array_equal(v2, vals[order])                    # LSD radix is stable, lexsort too
+
+
+def test_stage_sort_all_equal_and_sorted_inputs(H):
+    with H.Context() as c:
+        k = np.full(10000, 0x1234567800000000, dtype=np.uint64)
+        assert np.array_equal(c.stage_sort(k).reshape(-1), k)
+        k = np.arange(50000, dtype=np.uint64) * np.uint64(0x100000001)
+        assert np.array_equal(c.stage_sort(k[::-1].copy()).reshape(-1), k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a13: count_sorted_kmers
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,U", [(1, 65535), (2, 5), (15, 40)])
+@pytest.mark.parametrize("nw", [1, 2])
+def test_stage_count_sorted(H, L, U, nw):
+    rng = np.random.default_rng(L * 100 + U + nw)
+    distinct = np.unique(rng.integers(0, 1 << 62, size=(3000, nw), dtype=np.uint64), axis=0)
+    reps = rng.integers(1, 60, size=distinct.shape[0])
+    reps[5] = 70000                                           # a run longer than U and than a tile
+    reps[17] = 5000
+    keys = np.repeat(distinct, reps, axis=0)
+    order = np.lexsort([keys[:, w] for w in range(nw)])
+    keys = keys[order]
+    with H.Context(K=31 if nw == 1 else 51, L=L, U=U) as c:
+        k, cnt = c.stage_count_sorted(keys)
+    u, ucnt = np.unique(keys, axis=0, return_counts=True)
+    uo = np.lexsort([u[:, w] for w in range(nw)])
+    u, ucnt = u[uo], ucnt[uo]
+    keep = (ucnt >= L) & (ucnt <= U)
+    assert np.array_equal(k, u[keep])
+    assert np.array_equal(cnt, ucnt[keep].astype(np.uint64))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the whole path against the reference's own output
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["k31", "k31f", "k21", "k51"])
+def test_count_golden_raw_order(H, variant):
+    """ntasks = 5 (what the reference used: 1 rank x 8 threads): the raw KmerListS is reproduced
+    element for element, and so is the printed histogram."""
+    cfg = util.VARIANTS[variant]
+    _, dna = _small_reads(H)
+    with _ctx(H, variant, ntasks=5) as c:
+        res = c.count(dna)
+    gold = util.load_count("count_%s.txt" % variant)
+    assert res.strings() == [g[0] for g in gold]
+    assert res.cnt.tolist() == [g[1] for g in gold]
+    assert H.histogram_text(res.histo) == open(util.GOLDEN + "/hist_%s.txt" % variant).read()
+    buf = io.StringIO()
+    H.print_kmer_histogram(res, file=buf)
+    assert buf.getvalue() == open(util.GOLDEN + "/hist_%s.txt" % variant).read()
+
+
+def test_count_golden_k51_paradis_multiset(H):
+    _, dna = _small_reads(H)
+    with _ctx(H, "k51p", ntasks=5) as c:
+        res = c.count(dna)
+    gold = util.load_count("count_k51p.txt")
+    assert sorted(zip(res.strings(), res.cnt.tolist())) == sorted((g[0], g[1]) for g in gold)
+
+
+def test_count_golden_extension(H):
+    _, dna = _small_reads(H)
+    with _ctx(H, "k31ext", ntasks=5) as c:
+        res = c.count(dna)
+    gold = util.load_count("count_k31ext.txt")
+    assert res.strings() == [g[0] for g in gold]
+    assert res.cnt.tolist() == [g[1] for g in gold]
+    assert int(res.payload_off[-1]) == sum(g[1] for g in gold)
+    for i, g in enumerate(gold):
+        a, b = int(res.payload_off[i]), int(res.payload_off[i + 1])
+        assert sorted(zip(res.rid[a:b].tolist(), res.pos[a:b].tolist())) == sorted(zip(g[3], g[2])), g[0]
+
+
+@pytest.mark.parametrize("ntasks", [1, 2, 9, 64, 0])
+def test_count_any_task_count_same_multiset(H, ntasks):
+    """The content must not depend on tot_tasks (SURVEY 8a ordering contract)."""
+    _, dna = _small_reads(H)
+    with _ctx(H, "k31", ntasks=ntasks) as c:
+        res = c.count(dna)
+    gold = util.load_count("count_k31.txt")
+    assert sorted(zip(res.strings(), res.cnt.tolist())) == sorted((g[0], g[1]) for g in gold)
+    # per-task ascending runs
+    for t in range(res.info["ntasks"]):
+        seg = res.kmers[int(res.task_off[t]):int(res.task_off[t + 1]), 0]
+        assert np.all(seg[1:] > seg[:-1])
+
+
+def test_write_output_file(H, tmp_path):
+    _, dna = _small_reads(H)
+    with _ctx(H, "k31", ntasks=5) as c:
+        res = c.count(dna)
+    H.write_output_file(res, str(tmp_path))
+    lines = open(tmp_path / "0.out").read().splitlines()
+    gold = util.load_count("count_k31.txt")
+    assert lines == ["%s\t%d" % (g[0], g[1]) for g in gold]
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases the reference handles (or trips over)
+# ---------------------------------------------------------------------------------------------------
+def test_edge_cases(H, O):
+    cases = {
+        "empty": [],
+        "all_short": ["ACGT", "A" * 30, ""],
+        "exactly_k": ["ACGTTGCAAGGCTTAACCGGTTACGATCGAT"],
+        "with_n": ["ACGTNNNNACGTTGCAAGGCTTAACCGGTTACGATCGATNACGTTGCA"],
+        "poly_a": ["A" * 700],
+        "mixed_empty": ["", "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGGCTAAGC", "", "", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", ""],
+        "one_byte_reads": ["A", "C", "G", "T"] * 50 + ["ACGTTGCAAGGCTTAACCGGTTACGATCGATCG"],
+    }
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=3) as c:
+        for name, seqs in cases.items():
+            dna = H.DnaBuffer.from_sequences(seqs)
+            res = c.count(dna)
+            packed, off, lens = O.pack_reads(seqs)
+            ores = O.count(packed, off, lens, k=31, m=17, L=1, U=65535, ntasks=3)
+            assert res.kmers.shape == ores.keys.shape, name
+            assert np.array_equal(res.kmers, ores.keys), name
+            assert np.array_equal(res.cnt, ores.cnt), name
+            assert np.array_equal(res.task_off, ores.task_off), name
+            assert res.info["total_kmers"] == ores.stats["total_kmers"], name
+
+
+def test_invalid_config_is_rejected(H):
+    for kw in (dict(K=32), dict(K=2), dict(K=96), dict(M=31, K=31), dict(L=0), dict(L=5, U=4), dict(U=70000), dict(EXT=2)):
+        with pytest.raises(H.HskError):
+            H.Context(**kw)
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic reads: device generator == numpy twin; path == oracle on them
+# ---------------------------------------------------------------------------------------------------
+def test_synth_device_equals_numpy(H):
+    from hysortk_amd import synth
+    with H.Context() as c:
+        dp, nb, do, dl = c.synth_reads(50000, 150, 3000, 42)
+        got = c.d2h(dp, nb)
+        c.synth_free(dp, do, dl)
+    packed, off, lens = synth.packed_reads(50000, 150, 3000, 42)
+    assert np.array_equal(got, packed)
+    seqs = synth.reads(50000, 150, 40, 42)
+    nbr = (150 + 3) // 4
+    for r, s in enumerate(seqs):
+        assert H.pack_sequence(s).tobytes() == packed[r * nbr:(r + 1) * nbr].tobytes()
+
+
+@pytest.mark.parametrize("variant,EXT", [("k31", 0), ("k31", 1), ("k51", 0)])
+def test_count_synth_vs_oracle(H, O, variant, EXT):
+    from hysortk_amd import synth
+    cfg = util.VARIANTS[variant]
+    packed, off, lens = synth.packed_reads(200000, 150, 20000, 7)      # 15x of a 200 kbp genome, 2.4 M k-mers
+    ores = O.count(packed, off, lens, k=cfg["k"], m=cfg["m"], L=2, U=40, ext=EXT, ntasks=6, fast=True)
+    with H.Context(K=cfg["k"], M=cfg["m"], L=2, U=40, EXT=EXT, ntasks=6) as c:
+        dp, nb, do, dl = c.synth_reads(200000, 150, 20000, 7)
+        res = c.count_device(dp, nb, do, dl, 20000)
+        c.synth_free(dp, do, dl)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert res.info["total_kmers"] == ores.stats["total_kmers"] == 20000 * (150 - cfg["k"] + 1)
+    if EXT:
+        assert np.array_equal(res.payload_off, ores.payoff)
+        # stable LSD sort + deterministic-content payload: compare as sets per k-mer
+        for i in range(0, len(res), 997):
+            a, b = int(res.payload_off[i]), int(res.payload_off[i + 1])
+            assert sorted(zip(res.rid[a:b].tolist(), res.pos[a:b].tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist()))
+        assert sorted(zip(res.rid.tolist(), res.pos.tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at a size the oracle does not run in seconds
+# ---------------------------------------------------------------------------------------------------
+def test_large_properties(H):
+    G, RL, NR = 20_000_000, 150, 4_000_000            # 600 Mbp, 480 M k-mers, 30x
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=0) as c:
+        dp, nb, do, dl = c.synth_reads(G, RL, NR, 99)
+        res = c.count_device(dp, nb, do, dl, NR)
+        c.synth_free(dp, do, dl)
+    total = NR * (RL - 31 + 1)
+    assert res.info["total_kmers"] == total
+    assert int(res.cnt.sum()) == total                                  # checksum of counts (L=1: nothing filtered)
+    assert int((res.histo * np.arange(res.histo.size, dtype=np.uint64)).sum()) == total
+    assert int(res.histo.sum()) == len(res)
+    for t in range(res.info["ntasks"]):                                 # sortedness / uniqueness inside every task
+        seg = res.kmers[int(res.task_off[t]):int(res.task_off[t + 1]), 0]
+        assert np.all(seg[1:] > seg[:-1])
+    assert np.unique(res.kmers[:, 0]).size == len(res)                  # no k-mer in two tasks
+    assert np.all((res.kmers[:, 0] & np.uint64(3)) == 0)                # K=31: two low bits unused
+    # idempotence: counting again gives the identical list
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=0) as c:
+        dp, nb, do, dl = c.synth_reads(G, RL, NR, 99)
+        res2 = c.count_device(dp, nb, do, dl, NR)
+        c.synth_free(dp, do, dl)
+    assert np.array_equal(res.kmers, res2.kmers) and np.array_equal(res.cnt, res2.cnt)
