@@ -100,7 +100,7 @@ def load():
     L.hsk_comm_get_unique_id.argtypes = [vp]
     L.hsk_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.hsk_comm_destroy.argtypes = [vp]
-    L.hsk_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+    L.hsk_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hsk_synth_free.argtypes = [vp, vp, vp, vp]
     L.hsk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]

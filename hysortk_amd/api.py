@@ -307,10 +307,10 @@ class Context:
         return out[:m, :nw].copy(), out[:m, nw].copy()
 
     # ---- synthetic reads in HBM ------------------------------------------------------------------------
-    def synth_reads(self, genome_len, read_len, nreads, seed):
+    def synth_reads(self, genome_len, read_len, nreads, seed, first_read=0):
         dp, do, dl = C.c_void_p(), C.c_void_p(), C.c_void_p()
         nb = C.c_uint64(0)
-        self._check(self.lib.hsk_synth_reads(self.h, genome_len, read_len, nreads, seed, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
+        self._check(self.lib.hsk_synth_reads(self.h, genome_len, read_len, nreads, seed, first_read, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
         return dp, int(nb.value), do, dl
 
     def synth_free(self, dp, do, dl):

@@ -24,12 +24,12 @@ def genome_codes(genome_len, seed):
     return codes[:genome_len]
 
 
-def reads(genome_len, read_len, nreads, seed):
+def reads(genome_len, read_len, nreads, seed, first_read=0):
     """Returns (list of ASCII reads) identical to what hsk_synth_reads writes (after 2-bit packing)."""
     g = genome_codes(genome_len, seed)
     seed2 = splitmix64(np.uint64(seed) ^ np.uint64(0xABCDEF12345))
     with np.errstate(over="ignore"):
-        h = splitmix64(seed2 + np.arange(nreads, dtype=np.uint64))
+        h = splitmix64(seed2 + np.uint64(first_read) + np.arange(nreads, dtype=np.uint64))
     start = (h >> np.uint64(1)) % np.uint64(genome_len - read_len + 1)
     rc = (h & np.uint64(1)).astype(bool)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -43,12 +43,12 @@ def reads(genome_len, read_len, nreads, seed):
     return out
 
 
-def packed_reads(genome_len, read_len, nreads, seed):
+def packed_reads(genome_len, read_len, nreads, seed, first_read=0):
     """Vectorised: (packed uint8[nreads*nb], read_off uint64[nreads], read_len uint32[nreads])."""
     g = genome_codes(genome_len, seed)
     seed2 = splitmix64(np.uint64(seed) ^ np.uint64(0xABCDEF12345))
     with np.errstate(over="ignore"):
-        h = splitmix64(seed2 + np.arange(nreads, dtype=np.uint64))
+        h = splitmix64(seed2 + np.uint64(first_read) + np.arange(nreads, dtype=np.uint64))
     start = ((h >> np.uint64(1)) % np.uint64(genome_len - read_len + 1)).astype(np.int64)
     rc = (h & np.uint64(1)).astype(bool)
     nb = (read_len + 3) // 4

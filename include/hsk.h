@@ -184,6 +184,7 @@ int hsk_comm_destroy(hsk_ctx *ctx);
  * bases sampled uniformly, strand 50/50.  Outputs device pointers owned by the ctx (freed by
  * hsk_synth_free or hsk_destroy).  The same generator exists in numpy (hysortk_amd/synth.py). */
 int hsk_synth_reads(hsk_ctx *ctx, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed,
+                    uint64_t first_read, /* index of read 0 in the global read stream (rank * nreads for weak scaling) */
                     void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
 int hsk_synth_free(hsk_ctx *ctx, void *d_packed, void *d_read_byte_off, void *d_read_len);
 int hsk_memcpy_d2h(hsk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
