@@ -142,7 +142,7 @@ class DnaBuffer:
 class KmerList:
     """KmerListS (reference include/kmer.hpp:410): parallel arrays instead of a vector of structs.
     kmers[i] are the TKmer words (longs[0..nw)), cnt[i] the count; with EXTENSION entry i owns
-    pos/rid[payload_off[i]:payload_off[i+1]] (KmerListEntryS::pos / ::rid)."""
+    pos/rid[payload_off[i]:payload_off[i]+cnt[i]] (KmerListEntryS::pos / ::rid); see payload(i)."""
 
     def __init__(self, k, kmers, cnt, task_off, payload_off=None, pos=None, rid=None, histo=None, info=None):
         self.k = k
@@ -153,6 +153,11 @@ class KmerList:
 
     def __len__(self):
         return int(self.cnt.size)
+
+    def payload(self, i):
+        """(pos, rid) arrays of entry i (EXTENSION)."""
+        a = int(self.payload_off[i]); b = a + int(self.cnt[i])
+        return self.pos[a:b], self.rid[a:b]
 
     def kmer_string(self, i):
         w = self.kmers[i]

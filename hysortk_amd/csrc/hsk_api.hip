@@ -497,36 +497,31 @@ static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n
     const bool ext = vals != nullptr;
     const u64 ntiles = (n + CNT_TILE - 1) / CNT_TILE;
     u64 *d_tile_cnt, *d_total;
-    DALLOC(c, d_tile_cnt, u64 *, ntiles * 16);
+    DALLOC(c, d_tile_cnt, u64 *, ntiles * 8);
     DALLOC(c, d_total, u64 *, 256);
     CountArgs a; memset(&a, 0, sizeof a);
-    a.keys = keys; a.vals = vals; a.n = n; a.lower = (u32)c->cfg.lower_freq; a.upper = (u32)c->cfg.upper_freq;
-    a.tile_cnt = d_tile_cnt; a.histo = d_histo; a.histo_len = histo_len;
+    a.keys = keys; a.n = n; a.lower = (u32)c->cfg.lower_freq; a.upper = (u32)c->cfg.upper_freq;
+    a.tile_cnt = d_tile_cnt; a.histo = d_histo; a.histo_len = histo_len; a.payoff_add = payoff_add;
     hipLaunchKernelGGL((count_kernel<NW, false, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile_cnt, ntiles, d_total);
     u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
-    HIPCHK(c, hipMemcpyAsync(tot, d_total, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    out.n = tot[0]; out.npay = ext ? tot[1] : 0;
+    out.n = tot[0]; out.npay = ext ? n : 0;
+    if (ext) {
+        // the payload of a kept run is its slice of the sorted payload array: split the whole array once
+        DALLOC(c, out.pos, u32 *, n * 4);
+        DALLOC(c, out.rid, int32_t *, n * 4);
+        hipLaunchKernelGGL(payload_split_kernel, dim3((u32)std::min<u64>((n + 255) / 256, 4096)), dim3(256), 0, c->stream, vals, n, out.pos, out.rid);
+    }
     if (out.n) {
         DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
-        if (ext) {
-            DALLOC(c, out.payoff, u64 *, out.n * 8);
-            DALLOC(c, out.pos, u32 *, out.npay * 4);
-            DALLOC(c, out.rid, int32_t *, out.npay * 4);
-        }
-        a.entries = out.entries; a.payoff = out.payoff; a.pos = out.pos; a.rid = out.rid; a.pay_base = 0;
-        // payoff values are made global by adding the payload count of the preceding tasks
-        a.tile_cnt = d_tile_cnt;
-        if (ext) {
-            // shift the per-tile payload offsets by payoff_add so that payoff[] is global, while pos/rid stay task-local
-            a.pay_base = 0;
-        }
+        if (ext) DALLOC(c, out.payoff, u64 *, out.n * 8);
+        a.entries = out.entries; a.run_start = out.payoff;
         if (ext) hipLaunchKernelGGL((count_kernel<NW, true, true>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((count_kernel<NW, true, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
-    (void)payoff_add;
     c->pool.release(d_tile_cnt); c->pool.release(d_total);
     return HSK_OK;
 }
@@ -694,17 +689,15 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         }
     }
     u64 o = 0, po = 0;
-    std::vector<std::pair<u64, u64>> pay_fix;      // (entry offset, payload base) per task, EXT
     for (u32 t = 0; t < ntasks; ++t) {
         out->task_off[t] = o;
         TaskOut &to = touts[t];
-        if (to.n && !keep) {
-            HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (ext) {
-                HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (!keep) {
+            if (to.n) HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.n) HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.npay) {
                 HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipMemcpyAsync(out->rid + po, to.rid, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
-                pay_fix.push_back({o, po});
             }
         }
         o += to.n; po += to.npay;
@@ -713,15 +706,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     pt.end(PH_D2H);
     pt.end(PH_TOTAL);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ext && !keep) {
-        // per-task payload offsets -> global offsets (tasks were counted independently)
-        for (size_t i = 0; i < pay_fix.size(); ++i) {
-            const u64 e0 = pay_fix[i].first, base = pay_fix[i].second;
-            const u64 e1 = (i + 1 < pay_fix.size()) ? pay_fix[i + 1].first : n_total;
-            if (base) for (u64 e = e0; e < e1; ++e) out->payload_off[e] += base;
-        }
-        out->payload_off[n_total] = pay_total;
-    }
+    if (ext && !keep) out->payload_off[n_total] = pay_total;
     if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
     else for (auto &to : touts) free_task_out(c, to);
     c->pool.release(d_histo);

@@ -36,6 +36,7 @@ constexpr int MAX_K = 95;
 constexpr int HSK_MAX_TASKS = 1024;
 constexpr int PARSE_WORDS = PARSE_TILE / 16 + 12;     // 128 tile words + halo (K-1 <= 94 bases = 6 words) + overread
 constexpr int PARSE_HMAX = PARSE_TILE + 96;           // hashes for TILE + (K-M) positions
+constexpr int PARSE_RWIN = 64;                        // reads looked at per tile by the wave-parallel index search
 
 struct ParseArgs {
     const u8 *packed;          // 4-byte aligned; nothing beyond packed_bytes is read
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
     __shared__ u32 s_words[PARSE_WORDS];
     __shared__ u64 s_hash[PARSE_HMAX];
     __shared__ u16 s_dest[PARSE_TILE + 8];   // sizes of the statics are multiples of 16 B (dynamic LDS base stays aligned)
-    __shared__ u64 s_rng[2];
+    __shared__ u64 s_rng[4];                 // r0, r1 (first / last read overlapping the tile), window base, fast-path flag
+    __shared__ u64 s_roff[PARSE_RWIN];       // roff[rb + i]: the read index window of this tile (one coalesced load)
+    __shared__ u32 s_rlen[PARSE_RWIN];
     extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // COUNT: 3*ntasks counters, EMIT: 2*ntasks bases + ntasks cursors
 
     const int tid = threadIdx.x;
@@ -99,6 +102,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
     __syncthreads();
 
     const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    // The read index is searched ONCE per workgroup; afterwards every tile starts from where the
+    // previous one ended (tiles of a workgroup are consecutive) with one 64-wide coalesced probe.
+    if (tid == 0) s_rng[1] = (tile0 < a.ntiles) ? find_read(a.roff, 0, a.nreads - 1, (tile0 * PARSE_TILE) >> 2) : 0;
+    __syncthreads();
+    const u64 RINF = ~0ULL >> 2;
     for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
         const u64 tile = tile0 + ti;
         if (tile >= a.ntiles) break;
@@ -118,13 +126,26 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                 s_words[i] = wv;
             }
         }
-        // tile-level read range (reads overlapping [bbase, bbase + 512 + halo))
-        if (tid == 0) {
-            u64 r0 = find_read(a.roff, 0, a.nreads - 1, bbase);
+        // tile-level read range (reads overlapping [bbase, bbase + 512)): wave 0 probes 64 index entries
+        if (tid < PARSE_RWIN) {
+            const u64 rb = s_rng[1];                                   // <= r0 of this tile (offsets are monotone)
             u64 blast = bbase + PARSE_TILE / 4 - 1;
             if (blast >= a.packed_bytes) blast = a.packed_bytes - 1;
-            u64 r1 = find_read(a.roff, r0, a.nreads - 1, blast);
-            s_rng[0] = r0; s_rng[1] = r1;
+            const u64 idx = rb + tid;
+            const u64 off = (idx <= a.nreads) ? a.roff[idx] : RINF;
+            s_roff[tid] = off;
+            s_rlen[tid] = (idx < a.nreads) ? a.rlen[idx] : 0;
+            const u32 c0 = (u32)__popcll(__ballot(idx < a.nreads && off <= bbase));
+            const u32 c1 = (u32)__popcll(__ballot(idx < a.nreads && off <= blast));
+            if (tid == 0) {
+                u64 r0 = rb + c0 - 1, r1 = rb + c1 - 1;
+                const bool fast = c1 < PARSE_RWIN;                     // r1 + 1 is still inside the window
+                if (!fast) {                                           // > 62 reads start in this tile (tiny reads): generic search
+                    r0 = find_read(a.roff, rb, a.nreads - 1, bbase);
+                    r1 = find_read(a.roff, r0, a.nreads - 1, blast);
+                }
+                s_rng[0] = r0; s_rng[1] = r1; s_rng[2] = rb; s_rng[3] = fast ? 1 : 0;
+            }
         }
         __syncthreads();
 
@@ -162,17 +183,27 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
         u32 posr[PARSE_PPT]; u32 ridx[PARSE_PPT];   // pos in read / read index relative to s_rng[0]
         {
             const u64 g0 = gbase + p0;
-            const u64 rlo = s_rng[0], rhi = s_rng[1];
-            u64 r = find_read(a.roff, rlo, rhi, g0 >> 2);
-            u64 rstart = a.roff[r] * 4;
-            u64 rend = rstart + a.rlen[r];
-            u64 nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+            const u64 rlo = s_rng[0], rhi = s_rng[1], rb = s_rng[2];
+            const bool fast = s_rng[3] != 0;
+            u64 r, rstart, rend, nxt;
+            if (fast) {                                                // everything this lane needs is in the LDS window
+                u32 lo = (u32)(rlo - rb), hi = (u32)(rhi - rb);
+                const u64 b0 = g0 >> 2;
+                while (lo < hi) { u32 mid = (lo + hi + 1) >> 1; if (s_roff[mid] <= b0) lo = mid; else hi = mid - 1; }
+                r = rb + lo; rstart = s_roff[lo] * 4; rend = rstart + s_rlen[lo];
+                nxt = (r + 1 < a.nreads) ? s_roff[lo + 1] * 4 : ~0ULL;
+            } else {
+                r = find_read(a.roff, rlo, rhi, g0 >> 2);
+                rstart = a.roff[r] * 4; rend = rstart + a.rlen[r];
+                nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+            }
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 const u64 g = g0 + i;
                 while (g >= nxt) {
-                    ++r; rstart = nxt; rend = rstart + a.rlen[r];
-                    nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+                    ++r; rstart = nxt;
+                    if (fast) { const u32 j = (u32)(r - rb); rend = rstart + s_rlen[j]; nxt = (r + 1 < a.nreads) ? s_roff[j + 1] * 4 : ~0ULL; }
+                    else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
                 }
                 const bool valid = (g < total_pos) && (g + K <= rend);
                 const u32 d = fastmod64(mn[i], a.fm);

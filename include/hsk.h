@@ -69,7 +69,9 @@ typedef struct hsk_ctx hsk_ctx;
  *   order:   ascending task id over the tasks this rank owns (copy_results, kmerops.cpp:883-904);
  *            inside a task ascending as a little-endian multi-word integer (= sort_task,
  *            kmerops.cpp:1382, RADULS order; for K <= 32 this is plain ascending uint64).
- *   EXTENSION == 1: CSR payload; entry i owns pos/rid[payload_off[i] .. payload_off[i+1]).
+ *   EXTENSION == 1: entry i owns pos/rid[payload_off[i] .. payload_off[i] + cnt_i): its slice of the
+ *            task's sorted payload array (slices of filtered-out k-mers stay in pos/rid as unused
+ *            gaps; payload_off[n] = total payload length).
  */
 typedef struct {
     uint64_t n;               /* number of (k-mer, count) entries */
@@ -77,9 +79,9 @@ typedef struct {
     int32_t  ntasks;          /* tot_tasks actually used */
     uint64_t *entries;        /* host (pinned) n * (nw+1) words; NULL with HSK_FLAG_KEEP_DEVICE */
     uint64_t *task_off;       /* host, ntasks+1: entry range of each task id (empty if not owned) */
-    uint64_t *payload_off;    /* host, n+1 (EXTENSION) */
-    uint32_t *pos;            /* host, payload_off[n] (EXTENSION): PosInRead */
-    int32_t  *rid;            /* host, payload_off[n] (EXTENSION): ReadId */
+    uint64_t *payload_off;    /* host, n+1 (EXTENSION): first payload of entry i; [n] = length of pos/rid */
+    uint32_t *pos;            /* host, payload_off[n] values (EXTENSION): PosInRead */
+    int32_t  *rid;            /* host, payload_off[n] values (EXTENSION): ReadId */
     uint64_t *histo;          /* host, histo_len bins: histo[c] = #entries with cnt == c */
     uint64_t histo_len;
     void     *entries_dev;    /* device copy when HSK_FLAG_KEEP_DEVICE (owned by the ctx) */
