@@ -395,7 +395,8 @@ struct SortScratch {
 template <int NW, bool HAS_VAL, typename LB>
 static void launch_onesweep(hsk_ctx *c, const SortArgs &a, u32 ntiles)
 {
-    hipLaunchKernelGGL((onesweep_kernel<NW, HAS_VAL, LB>), dim3(ntiles), dim3(SORT_THREADS), 0, c->stream, a);
+    static const int pad = getenv("HSK_SORT_LDS_PAD") ? atoi(getenv("HSK_SORT_LDS_PAD")) : 0;   // experiment knob: extra LDS per workgroup lowers residency
+    hipLaunchKernelGGL((onesweep_kernel<NW, HAS_VAL, LB>), dim3(ntiles), dim3(SORT_THREADS), (size_t)pad, c->stream, a);
 }
 
 // Sorts n records in bufA (keys) / valA using bufB / valB as the ping-pong buffer.  On return
@@ -1048,5 +1049,19 @@ extern "C" int hsk_memcpy_d2h(hsk_ctx *c, void *dst, const void *d_src, uint64_t
     if (!c || !dst || !d_src) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HSK_OK;
+}
+
+// diagnostic build only: phase clock sums of the onesweep kernel (zeros in the product build)
+extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
+{
+    if (!out || n < 1 || n > 32) return HSK_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(unsigned long long) * n);
+#ifdef HSK_DIAG
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_diag), sizeof(unsigned long long) * n) != hipSuccess) return HSK_ERR_HIP;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hsk::g_diag), z, sizeof z) != hipSuccess) return HSK_ERR_HIP; }
+#else
+    (void)reset;
+#endif
     return HSK_OK;
 }

@@ -87,6 +87,16 @@ struct SortArgs {
 };
 
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
+constexpr int LB_WIN = 8;                 // predecessors inspected per look-back step
+
+// Diagnostic build only (-DHSK_DIAG): per-phase shader-clock sums of the onesweep kernel, one
+// stamp set per workgroup (thread 0).  Never compiled into the product library.
+#ifdef HSK_DIAG
+__device__ unsigned long long g_diag[32];
+#define DIAG_STAMP(i) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); diag_t[i] = t_; } } while (0)
+#else
+#define DIAG_STAMP(i) do { } while (0)
+#endif
 
 template <int NW, bool HAS_VAL, typename LB>
 __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
@@ -103,9 +113,14 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
     __shared__ u32 s_tile[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HSK_DIAG
+    unsigned long long diag_t[10];
+#endif
+    DIAG_STAMP(0);
     if (tid == 0) s_tile[0] = atomicAdd(a.ticket, 1u);
-    for (int i = tid; i < SORT_WAVES * 256; i += SORT_THREADS) s_whist[i] = 0;
+    for (int i = tid; i < SORT_WAVES * 256; i += SORT_THREADS) { s_whist[i] = 0; s_keys[i] = 0; }
     __syncthreads();
+    DIAG_STAMP(1);
     const u64 tile = s_tile[0];
     const u64 base = tile * TILE;
     const u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
@@ -125,28 +140,37 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
         dig[j] = (u32)(pick_word<NW>(key[j], a.word) >> a.shift) & dmask;
     }
 
+#ifdef HSK_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    DIAG_STAMP(2);
     // ---- rank inside the wave (stable) ----------------------------------------------------------
-    volatile u32 *wh = s_whist + wave * 256;
-    const u64 lt_mask = (1ULL << lane) - 1;
+    // "match" without ballots: every lane ORs its lane bit into a wave-private 64-bit word per digit
+    // (LDS atomic OR: commutative, so the result does not depend on the order lanes are served in),
+    // reads the word back = the set of lanes holding the same digit, and ranks itself by popcount.
+    // The words alias the key staging area, which is not written before the permute phase.
+    u32 *wh = s_whist + wave * 256;
+    u64 *wm = s_keys + wave * 256;
+    const u64 lane_bit = 1ULL << lane;
+    const u64 lt_mask = lane_bit - 1;
     u32 rank[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const u32 d = dig[j];
-        u64 peers = ~0ULL;
-        for (int b = 0; b < a.bits; ++b) {
-            const bool bit = (d >> b) & 1;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+        __hip_atomic_fetch_or(&wm[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const u64 peers = __hip_atomic_load(&wm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u32 old = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const u32 before = (u32)__popcll(peers & lt_mask);
         const u32 cnt = (u32)__popcll(peers);
-        const u32 old = wh[d];
-        __builtin_amdgcn_wave_barrier();
-        if (before == 0) wh[d] = old + cnt;
-        __builtin_amdgcn_wave_barrier();
+        if (before == 0) { __hip_atomic_store(&wm[d], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); __hip_atomic_store(&wh[d], old + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         rank[j] = old + before;
     }
+    DIAG_STAMP(3);
     __syncthreads();
+    DIAG_STAMP(4);
 
     // ---- digit totals, cross-wave exclusive prefix, digit start inside the tile ----------------
     u32 total;
@@ -161,8 +185,9 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
     s_dstart[tid] = dstart;
 
     // ---- publish this tile's digit count ---------------------------------------------------------
-    LB *lb = reinterpret_cast<LB *>(a.lookback);
-    LB *mine = lb + tile * 256 + tid;
+    typedef __attribute__((address_space(1))) LB GLB;          // global (not flat) accesses for the look-back words
+    GLB *lb = (GLB *)a.lookback;
+    GLB *mine = lb + tile * 256 + tid;
     if (tile == 0) __hip_atomic_store(mine, (LB)(L::INCL | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(mine, (LB)(L::AGG | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -177,27 +202,52 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
         if (HAS_VAL) s_vals[lpos] = val[j];
     }
 
+    DIAG_STAMP(5);
     // ---- decoupled look-back: exclusive prefix of digit `tid` over all earlier tiles ----------
     u64 excl = 0;
     if (tile > 0) {
+        // A window of LB_WIN predecessors is fetched with independent loads per step (the walk is
+        // latency-bound: with ~1000 tiles in flight most predecessors only carry an aggregate, and
+        // a one-load-per-step walk serialises hundreds of L2 round trips).
         long long t = (long long)tile - 1;
         u32 spins = 0;
-        while (t >= 0) {
-            const LB v = __hip_atomic_load(lb + (u64)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const LB f = v & L::FMASK;
-            if (f == 0) {
+        bool done = false;
+#ifdef HSK_DIAG
+        u32 dg_steps = 0;
+#endif
+        while (!done) {
+#ifdef HSK_DIAG
+            ++dg_steps;
+#endif
+            LB v[LB_WIN];
+#pragma unroll
+            for (int i = 0; i < LB_WIN; ++i)
+                v[i] = (t - i >= 0) ? __hip_atomic_load(lb + (u64)(t - i) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (LB)L::INCL;
+            int used = 0;
+#pragma unroll
+            for (int i = 0; i < LB_WIN; ++i) {
+                if (done || used < i) continue;              // stop at the first entry that is not ready
+                const LB f = v[i] & L::FMASK;
+                if (f == 0) continue;
+                excl += (u64)(v[i] & L::VMASK);
+                ++used;
+                if (f == L::INCL) done = true;
+            }
+            t -= used;
+            if (!done && used < LB_WIN) {                    // ran into an unpublished entry: back off and retry from it
                 if (++spins > LOOKBACK_SPIN_LIMIT) { atomicOr(a.err, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
-                continue;
             }
-            excl += (u64)(v & L::VMASK);
-            if (f == L::INCL) break;
-            --t;
         }
         __hip_atomic_store(mine, (LB)(L::INCL | (LB)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef HSK_DIAG
+        if (tid == 0) { atomicAdd(&g_diag[10], (unsigned long long)dg_steps); atomicAdd(&g_diag[11], (unsigned long long)spins); atomicAdd(&g_diag[12], (unsigned long long)(tile - 1 - t)); }
+#endif
     }
     s_delta[tid] = (long long)(a.gbase[tid] + excl) - (long long)dstart;
+    DIAG_STAMP(6);
     __syncthreads();
+    DIAG_STAMP(7);
 
     // ---- coalesced scatter -----------------------------------------------------------------------
     for (u32 i = tid; i < nvalid; i += SORT_THREADS) {
@@ -210,6 +260,15 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
         for (int w = 0; w < NW; ++w) a.keys_out[o * NW + w] = k[w];
         if (HAS_VAL) a.vals_out[o] = s_vals[i];
     }
+#ifdef HSK_DIAG
+    DIAG_STAMP(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DIAG_STAMP(9);
+    if (tid == 0) {
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_diag[i], diag_t[i + 1] - diag_t[i]);
+        atomicAdd(&g_diag[16], 1ULL);
+    }
+#endif
 }
 
 } // namespace hsk
