@@ -5,7 +5,7 @@ RCCL supermer exchange) lives in libhsk.so (csrc/, C ABI in include/hsk.h); this
 Python host mirror of the reference's four public functions and types.
 """
 from .api import (Context, DnaBuffer, DnaSeq, HskError, KmerList, histogram_text, kmer_count, pack_sequence,  # noqa: F401
-                  plan_classify, plan_dispatch, plan_partition_reads, plan_tot_tasks, print_kmer_histogram,
+                  plan_classify, plan_dispatch, plan_exchange, plan_partition_reads, plan_tot_tasks, print_kmer_histogram,
                   read_dna_buffer, read_fai, write_output_file)
 
 __version__ = "0.1.0"

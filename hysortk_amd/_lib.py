@@ -48,7 +48,7 @@ SYMBOLS = [
     "hsk_abi_version", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
     "hsk_count", "hsk_count_device", "hsk_result_free", "hsk_get_stats",
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
-    "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads",
+    "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
     "hsk_comm_get_unique_id", "hsk_comm_init", "hsk_comm_destroy",
     "hsk_synth_reads", "hsk_synth_free", "hsk_memcpy_d2h",
 ]
@@ -97,6 +97,7 @@ def load():
     L.hsk_plan_classify.argtypes = [vp, C.c_int, C.c_double, vp]
     L.hsk_plan_dispatch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
     L.hsk_plan_partition_reads.argtypes = [vp, C.c_uint64, C.c_int, vp]
+    L.hsk_plan_exchange.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.hsk_comm_get_unique_id.argtypes = [vp]
     L.hsk_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.hsk_comm_destroy.argtypes = [vp]

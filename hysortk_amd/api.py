@@ -359,6 +359,21 @@ def plan_partition_reads(read_len, nprocs):
     return out
 
 
+def plan_exchange(nranks, rank, owner, size_matrix):
+    """All-to-all-v plan of the supermer exchange for `rank` (see hsk_plan_exchange in include/hsk.h).
+    Returns (send_recv [nranks, 8], segs [ntasks, nranks, 4])."""
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    M = np.ascontiguousarray(size_matrix, dtype=np.uint64)
+    ntasks = owner.size
+    assert M.shape == (nranks, ntasks, 3)
+    sr = np.zeros((nranks, 8), dtype=np.uint64)
+    segs = np.zeros((ntasks, nranks, 4), dtype=np.uint64)
+    rc = _lib.load().hsk_plan_exchange(nranks, rank, ntasks, _p(owner), _p(M), _p(sr), _p(segs))
+    if rc:
+        raise HskError(rc)
+    return sr, segs
+
+
 # ---- the four reference functions ---------------------------------------------------------------------------
 def read_fai(path):
     """Parses <fasta>.fai records: name, length, byte offset of first base, bases per line

@@ -300,6 +300,12 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
                        int64_t rid_base, u32 ntasks, const std::vector<u32> &order, SupermerStore &st)
 {
     const bool ext = c->cfg.extension != 0;
+    if (nreads == 0 || packed_bytes == 0) {              // nothing to parse on this rank
+        st = SupermerStore();
+        st.ntasks = ntasks; st.order = order;
+        st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0);
+        return HSK_OK;
+    }
     u32 nblocks = 0;
     ParseArgs a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &nblocks);
     st.ntasks = ntasks; st.nblocks = nblocks; st.order = order;
@@ -587,7 +593,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // ---- parse ------------------------------------------------------------------------------------
     SupermerStore st;
     pt.begin(PH_PARSE);
-    if (nreads > 0 && packed_bytes > 0) {
+    {
         if (nranks > 1) {
             // dispatch needs global task sizes first: COUNT once with identity order, exchange sizes,
             // decide owners, then run the full parse with tasks grouped by owner.
@@ -605,8 +611,6 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         }
         int rc = parse_phase(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, order, st);
         if (rc) return rc;
-    } else {
-        st.ntasks = ntasks; st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0); st.order = order;
     }
     pt.end(PH_PARSE);
     out->total_supermers = st.tot_sup; out->total_supermer_bytes = st.tot_bytes + st.tot_sup * (ext ? 9 : 1);
@@ -985,6 +989,49 @@ extern "C" int hsk_plan_partition_reads(const uint64_t *read_len, uint64_t nread
 {
     if (!counts || nprocs < 1 || (nreads && !read_len)) return HSK_ERR_INVALID_ARG;
     return plan_partition_reads(read_len, nreads, nprocs, counts) == 0 ? HSK_OK : HSK_ERR_INVALID_ARG;
+}
+
+extern "C" int hsk_plan_exchange(int nranks, int rank, int ntasks, const int32_t *owner, const uint64_t *size_matrix,
+                                 uint64_t *send_recv, uint64_t *segs_out)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || ntasks < 1 || !owner || !size_matrix || !send_recv || !segs_out) return HSK_ERR_INVALID_ARG;
+    std::vector<int32_t> own(owner, owner + ntasks);
+    for (int t = 0; t < ntasks; ++t) if (own[t] < 0 || own[t] >= nranks) return HSK_ERR_INVALID_ARG;
+    std::vector<u32> order(ntasks);
+    for (int t = 0; t < ntasks; ++t) order[t] = (u32)t;
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return own[x] < own[y]; });
+    std::vector<u64> M(size_matrix, size_matrix + (size_t)nranks * ntasks * 3);
+    // storage bases of this rank's own supermers: exclusive prefix over the storage order
+    std::vector<u64> base((size_t)ntasks * 3, 0);
+    u64 s0 = 0, b0 = 0, k0 = 0;
+    for (int i = 0; i < ntasks; ++i) {
+        const u32 t = order[i];
+        base[3 * t] = s0; base[3 * t + 1] = b0; base[3 * t + 2] = k0;
+        const u64 *m = &M[((size_t)rank * ntasks + t) * 3];
+        s0 += m[0]; b0 += m[1]; k0 += m[2];
+    }
+    ExchangePlan pl; std::vector<TaskSegs> segs;
+    plan_exchange(nranks, rank, (u32)ntasks, own, order, M, base, pl, segs);
+    for (int q = 0; q < nranks; ++q) {
+        u64 *o = send_recv + (size_t)q * 8;
+        o[0] = pl.send_sup[q]; o[1] = pl.send_bytes[q]; o[2] = pl.send_sup_off[q]; o[3] = pl.send_byte_off[q];
+        o[4] = pl.recv_sup[q]; o[5] = pl.recv_bytes[q]; o[6] = pl.recv_sup_off[q]; o[7] = pl.recv_byte_off[q];
+    }
+    memset(segs_out, 0, sizeof(u64) * (size_t)ntasks * nranks * 4);
+    for (int t = 0; t < ntasks; ++t) {
+        if (own[t] != rank) continue;
+        // plan_exchange drops empty segments; re-derive the per-source rows so that the table is dense
+        u64 koff = 0;
+        size_t si = 0;
+        for (int p = 0; p < nranks; ++p) {
+            const u64 *m = &M[((size_t)p * ntasks + t) * 3];
+            u64 *o = segs_out + ((size_t)t * nranks + p) * 4;
+            if (m[0]) { const ExpSeg &sg = segs[t].segs[si++]; o[0] = sg.sup_off; o[1] = sg.n_sup; o[2] = sg.byte_off; o[3] = sg.kmer_off; }
+            else { o[3] = koff; }
+            koff += m[2];
+        }
+    }
+    return HSK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

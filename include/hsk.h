@@ -175,6 +175,16 @@ int hsk_plan_dispatch(const uint64_t *task_bytes, int ntasks, int nprocs, int pl
 /* FastaIndex::getpartition (fastaindex.cpp:52-100): contiguous split of reads by bases. */
 int hsk_plan_partition_reads(const uint64_t *read_len, uint64_t nreads, int nprocs, uint64_t *counts);
 
+/* The all-to-all-v plan of the supermer exchange (csrc/hsk_comm.h), as pure arithmetic: given the
+ * owner table and the full size matrix M[src][task] = {supermers, bytes, kmers}, what `rank` sends
+ * to / receives from each peer (counts and offsets in supermers and bytes; a rank's tasks are stored
+ * grouped by owner, ascending task id) and where every (task, src) segment lands in the receive
+ * arrays.  send_recv: [nranks][8] = send_sup, send_bytes, send_sup_off, send_byte_off, recv_sup,
+ * recv_bytes, recv_sup_off, recv_byte_off.  segs: [ntasks][nranks][4] = sup_off, n_sup, byte_off,
+ * kmer_off (zero rows for tasks `rank` does not own). */
+int hsk_plan_exchange(int nranks, int rank, int ntasks, const int32_t *owner, const uint64_t *size_matrix,
+                      uint64_t *send_recv, uint64_t *segs);
+
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) -------------------------------------- */
 #define HSK_UNIQUE_ID_BYTES 128
 int hsk_comm_get_unique_id(void *id128);                       /* rank 0, then broadcast by the caller */

@@ -1,0 +1,73 @@
+// dnabuffer.hpp -- owning, contiguous 2-bit read buffer: the input type of hysortk::kmer_count().
+// Same observable behaviour as the reference's DnaBuffer (include/dnabuffer.hpp:14,
+// src/dnabuffer.cpp:7-31): every read starts on a byte boundary, reads are stored back to back,
+// the (bufsize, numreads, buf, readlens) constructor ADOPTS `buf` (released with delete[]), the
+// copy constructor deep-copies.
+#pragma once
+#include <cassert>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "dnaseq.hpp"
+
+namespace hysortk {
+
+class DnaBuffer {
+public:
+    explicit DnaBuffer(size_t bufsize) : head_(0), cap_(bufsize), buf_(new uint8_t[bufsize ? bufsize : 1]) {}
+
+    DnaBuffer(size_t bufsize, size_t numreads, uint8_t *buf, const size_t *readlens) : head_(0), cap_(bufsize), buf_(buf)
+    {
+        seqs_.reserve(numreads);
+        for (size_t i = 0; i < numreads; ++i) {
+            seqs_.emplace_back(readlens[i], buf_ + head_);
+            head_ += DnaSeq::bytesneeded(readlens[i]);
+        }
+    }
+
+    DnaBuffer(const DnaBuffer &o) : head_(o.head_), cap_(o.cap_), buf_(new uint8_t[o.cap_ ? o.cap_ : 1])
+    {
+        std::memcpy(buf_, o.buf_, o.cap_);
+        seqs_.reserve(o.size());
+        size_t off = 0;
+        for (size_t i = 0; i < o.size(); ++i) { seqs_.emplace_back(o[i].size(), buf_ + off); off += o[i].numbytes(); }
+    }
+    DnaBuffer &operator=(const DnaBuffer &) = delete;
+    ~DnaBuffer() { delete[] buf_; }
+
+    void push_back(const char *s, size_t len)
+    {
+        const size_t nb = DnaSeq::bytesneeded(len);
+        assert(head_ + nb <= cap_);
+        seqs_.emplace_back(s, len, buf_ + head_);
+        head_ += nb;
+    }
+
+    size_t size() const { return seqs_.size(); }
+    size_t getbufsize() const { return cap_; }
+    size_t getusedbytes() const { return head_; }
+    const uint8_t *getbufoffset(size_t i) const { return seqs_[i].data(); }
+    const uint8_t *data() const { return buf_; }
+    const DnaSeq &operator[](size_t i) const { return seqs_[i]; }
+    size_t getrangebufsize(size_t start, size_t count) const
+    {
+        if (count == 0) return 0;
+        const DnaSeq &last = seqs_[start + count - 1];
+        return static_cast<size_t>((last.data() + last.numbytes()) - seqs_[start].data());
+    }
+
+    static size_t computebufsize(const std::vector<size_t> &seqlens)
+    {
+        size_t n = 0;
+        for (size_t l : seqlens) n += DnaSeq::bytesneeded(l);
+        return n;
+    }
+
+private:
+    size_t head_;
+    const size_t cap_;
+    uint8_t *buf_;
+    std::vector<DnaSeq> seqs_;
+};
+
+} // namespace hysortk

@@ -1,0 +1,194 @@
+// hysortk.hpp -- the four public functions of the reference library (include/hysortk.hpp:10-16),
+// implemented on top of the C ABI of libhsk.so (include/hsk.h).  Header-only: a client that was
+// built against the reference switches by pointing -I at this directory and linking -lhsk instead
+// of obj/libhysortk.o; the -D macros (KMER_SIZE, MINIMIZER_SIZE, LOWER/UPPER_KMER_FREQ, EXTENSION)
+// keep their names and meaning.
+//
+//   read_dna_buffer(fasta, comm)          reference src/hysortk.cpp:18-33  (+ fastaindex.cpp)
+//   kmer_count(mydna, comm)               reference src/hysortk.cpp:36-96  -> hsk_count()
+//   print_kmer_histogram(list, comm)      reference src/hysortk.cpp:98-136 (64-bit bins here)
+//   write_output_file(list, outdir, comm) reference src/hysortk.cpp:138-164
+//
+// Errors: C-ABI status codes become std::runtime_error (the reference throws / aborts).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../hsk.h"
+#include "compiletime.h"
+#include "dnabuffer.hpp"
+#include "kmer.hpp"
+
+namespace hysortk {
+
+namespace detail {
+
+struct Ranks { int rank = 0, size = 1; };
+inline Ranks ranks_of(MPI_Comm comm)
+{
+    Ranks r;
+#ifdef HSK_WITH_MPI
+    MPI_Comm_rank(comm, &r.rank); MPI_Comm_size(comm, &r.size);
+#else
+    (void)comm;
+#endif
+    return r;
+}
+
+inline void check(int status, hsk_ctx *ctx, const char *what)
+{
+    if (status == HSK_OK) return;
+    std::string msg = std::string(what) + ": " + hsk_strerror(status);
+    if (ctx && hsk_last_error(ctx)[0]) msg += std::string(" (") + hsk_last_error(ctx) + ")";
+    throw std::runtime_error(msg);
+}
+
+// one hsk_ctx per process, created on first use with the compile-time configuration
+inline hsk_ctx *context(MPI_Comm comm)
+{
+    static hsk_ctx *ctx = nullptr;
+    if (ctx) return ctx;
+    const Ranks r = ranks_of(comm);
+    hsk_config cfg;
+    hsk_config_default(&cfg);
+    cfg.kmer_size = KMER_SIZE; cfg.minimizer_size = MINIMIZER_SIZE;
+    cfg.lower_freq = LOWER_KMER_FREQ; cfg.upper_freq = UPPER_KMER_FREQ; cfg.extension = EXTENSION;
+#ifdef PLAIN_DISPATCHER
+    cfg.plain_dispatcher = PLAIN_DISPATCHER;
+#endif
+    int ndev = 1;
+    if (const char *e = std::getenv("HSK_GPUS_PER_NODE")) ndev = std::max(1, atoi(e));
+    else if (r.size > 1) ndev = 8;
+    cfg.device = r.rank % ndev;                                  // one rank per GPU
+    check(hsk_init(&cfg, &ctx), nullptr, "hsk_init");
+#ifdef HSK_WITH_MPI
+    if (r.size > 1) {
+        char id[HSK_UNIQUE_ID_BYTES];
+        if (r.rank == 0) check(hsk_comm_get_unique_id(id), ctx, "hsk_comm_get_unique_id");
+        MPI_Bcast(id, HSK_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm);
+        check(hsk_comm_init(ctx, r.size, r.rank, id), ctx, "hsk_comm_init");
+    }
+#endif
+    return ctx;
+}
+
+struct FaiRecord { size_t len, pos, bases; };
+
+} // namespace detail
+
+// FASTA + .fai -> the calling rank's DnaBuffer (contiguous run of records balanced by bases).
+inline std::shared_ptr<DnaBuffer> read_dna_buffer(const std::string &fasta_fname, MPI_Comm comm)
+{
+    const detail::Ranks r = detail::ranks_of(comm);
+    std::vector<detail::FaiRecord> recs;
+    {
+        std::ifstream fai(fasta_fname + ".fai");
+        if (!fai) throw std::runtime_error("cannot open " + fasta_fname + ".fai");
+        std::string line;
+        while (std::getline(fai, line)) {
+            std::istringstream is(line);
+            std::string name; detail::FaiRecord rec{};
+            if (is >> name >> rec.len >> rec.pos >> rec.bases) recs.push_back(rec);
+        }
+    }
+    std::vector<uint64_t> lens(recs.size()), counts(r.size, 0);
+    for (size_t i = 0; i < recs.size(); ++i) lens[i] = recs[i].len;
+    if (r.size > 1) detail::check(hsk_plan_partition_reads(lens.data(), lens.size(), r.size, counts.data()), nullptr, "partition");
+    else counts[0] = recs.size();
+    size_t first = 0;
+    for (int p = 0; p < r.rank; ++p) first += counts[p];
+    const size_t mine = counts[r.rank];
+    std::vector<size_t> mylens(mine);
+    for (size_t i = 0; i < mine; ++i) mylens[i] = recs[first + i].len;
+    auto buf = std::make_shared<DnaBuffer>(DnaBuffer::computebufsize(mylens));
+    std::ifstream fa(fasta_fname, std::ios::binary);
+    if (!fa) throw std::runtime_error("cannot open " + fasta_fname);
+    std::string raw, seq;
+    for (size_t i = 0; i < mine; ++i) {
+        const detail::FaiRecord &rec = recs[first + i];
+        const size_t nlines = rec.bases ? (rec.len + rec.bases - 1) / rec.bases : 0;
+        raw.resize(rec.len + nlines);
+        fa.clear(); fa.seekg(static_cast<std::streamoff>(rec.pos));
+        fa.read(&raw[0], static_cast<std::streamsize>(raw.size()));
+        raw.resize(static_cast<size_t>(fa.gcount()));
+        seq.clear();
+        for (char ch : raw) if (ch != '\n' && ch != '\r' && seq.size() < rec.len) seq.push_back(ch);
+        buf->push_back(seq.data(), seq.size());
+    }
+    return buf;
+}
+
+// The hot path.  Collective over comm.
+inline std::unique_ptr<KmerListS> kmer_count(const DnaBuffer &mydna, MPI_Comm comm)
+{
+    hsk_ctx *ctx = detail::context(comm);
+    const size_t nreads = mydna.size();
+    std::vector<uint64_t> off(nreads);
+    std::vector<uint32_t> len(nreads);
+    for (size_t i = 0; i < nreads; ++i) { off[i] = static_cast<uint64_t>(mydna.getbufoffset(i) - mydna.data()); len[i] = static_cast<uint32_t>(mydna[i].size()); }
+    int64_t rid_base = 0;
+#ifdef HSK_WITH_MPI
+    {
+        long long n = static_cast<long long>(nreads), before = 0;
+        MPI_Exscan(&n, &before, 1, MPI_LONG_LONG, MPI_SUM, comm);           // reference src/kmerops.cpp:65-71
+        if (detail::ranks_of(comm).rank == 0) before = 0;
+        rid_base = before;
+    }
+#endif
+    hsk_result res;
+    detail::check(hsk_count(ctx, mydna.data(), mydna.getusedbytes(), off.data(), len.data(), nreads, rid_base, &res), ctx, "hsk_count");
+    std::unique_ptr<KmerListS> list(new KmerListS(res.n));
+#if EXTENSION == 0
+    if (res.n) std::memcpy(static_cast<void *>(list->data()), res.entries, res.n * sizeof(KmerListEntryS));
+#else
+    const int nw = res.nw;
+    for (uint64_t i = 0; i < res.n; ++i) {
+        KmerListEntryS &e = (*list)[i];
+        e.kmer.CopyDataFrom(res.entries + i * (nw + 1));
+        e.cnt = res.entries[i * (nw + 1) + nw];
+        const uint64_t a = res.payload_off[i];
+        e.pos.assign(res.pos + a, res.pos + a + e.cnt);
+        e.rid.assign(res.rid + a, res.rid + a + e.cnt);
+    }
+#endif
+    hsk_result_free(ctx, &res);
+    return list;
+}
+
+inline void print_kmer_histogram(const KmerListS &kmerlist, MPI_Comm comm)
+{
+    uint64_t maxcount = 0;
+    for (const auto &e : kmerlist) maxcount = std::max<uint64_t>(maxcount, e.cnt);
+#ifdef HSK_WITH_MPI
+    MPI_Allreduce(MPI_IN_PLACE, &maxcount, 1, MPI_UNSIGNED_LONG_LONG, MPI_MAX, comm);
+#endif
+    std::vector<unsigned long long> histo(maxcount + 1, 0);
+    for (const auto &e : kmerlist) histo[e.cnt]++;
+#ifdef HSK_WITH_MPI
+    MPI_Allreduce(MPI_IN_PLACE, histo.data(), static_cast<int>(histo.size()), MPI_UNSIGNED_LONG_LONG, MPI_SUM, comm);
+#endif
+    if (detail::ranks_of(comm).rank == 0) {
+        std::cout << "#count\tnumkmers" << std::endl;
+        for (size_t i = 1; i < histo.size(); ++i) if (histo[i] > 0) std::cout << i << "\t" << histo[i] << std::endl;
+        std::cout << std::endl;
+    }
+#ifdef HSK_WITH_MPI
+    MPI_Barrier(comm);
+#endif
+}
+
+inline void write_output_file(const KmerListS &kmerlist, const std::string &output_dir, MPI_Comm comm)
+{
+    const std::string fname = output_dir + "/" + std::to_string(detail::ranks_of(comm).rank) + ".out";
+    std::ofstream ofs(fname);
+    if (!ofs) throw std::runtime_error("Error: cannot open output file " + fname);
+    for (const auto &e : kmerlist) ofs << e.kmer << "\t" << e.cnt << "\n";
+}
+
+} // namespace hysortk
