@@ -267,7 +267,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 // ------------------------------------------------------------------------------------------------
 struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
-    u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
+    u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
     u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
     std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
@@ -276,8 +276,8 @@ struct SupermerStore {
 
 static void free_store(hsk_ctx *c, SupermerStore &s)
 {
-    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid);
-    s.sm_len = s.sm_bytes = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr;
+    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid);
+    s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr;
 }
 
 static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen,
@@ -317,8 +317,10 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
     HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
     a.blk_cnt = d_blk_cnt;
-    if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
-    else hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
+    // task id per base position, kept from COUNT to EMIT (2 B x 4 x packed_bytes); optional: without it EMIT re-hashes
+    u16 *d_dest_cache = (u16 *)c->pool.alloc((size_t)a.ntiles * PARSE_TILE * 2);
+    a.dest_cache = d_dest_cache;
+    hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
     hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, d_blk_cnt, nblocks, ntasks, d_order, d_task_tot, d_task_base, d_blk_base);
     st.task_tot.resize((size_t)ntasks * 3); st.task_base.resize((size_t)ntasks * 3);
     HIPCHK(c, hipMemcpyAsync(st.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -327,17 +329,19 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     st.tot_sup = st.tot_bytes = st.tot_kmers = 0;
     for (u32 t = 0; t < ntasks; ++t) { st.tot_sup += st.task_tot[3 * t]; st.tot_bytes += st.task_tot[3 * t + 1]; st.tot_kmers += st.task_tot[3 * t + 2]; }
     DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
-    DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
+    DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);          // reference mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
-    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_bytes = st.sm_bytes; a.sm_pos = st.sm_pos; a.sm_rid = st.sm_rid;
+    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos;
     if (st.tot_sup) {
-        if (ext) hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
-        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 3 * 8, c->stream, a);
+        hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                                    st.sm_gpos, st.tot_sup, d_roff, nreads, rid_base, st.sm_pos, st.sm_rid);
     }
     HIPCHK(c, hipGetLastError());
     // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
     // every later user of these blocks is enqueued on the same stream)
     c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order);
+    c->pool.release(d_dest_cache);
     return HSK_OK;
 }
 
@@ -351,27 +355,72 @@ static void finalize_segs(TaskSegs &ts)
     ts.ntiles = tile;
 }
 
+// where the bases of a task's supermers live
+struct BaseSource {
+    const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
+    const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
+};
+static BaseSource source_from_packed(const u8 *d_packed, u64 packed_bytes, const u64 *gpos)
+{
+    BaseSource b; const uintptr_t p = (uintptr_t)d_packed;
+    b.src8 = (const u64 *)(p & ~(uintptr_t)7); b.bit0 = 8 * (u64)(p & 7); b.nwords = ((p & 7) + packed_bytes + 7) / 8; b.gpos = gpos;
+    return b;
+}
+static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
+{
+    BaseSource b; b.src8 = (const u64 *)bytes; b.bit0 = 0; b.nwords = (nbytes + 7) / 8 + 1; b.gpos = nullptr;   // pool blocks are padded
+    return b;
+}
+
+struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr; };
+
+static int expand_prepare(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, ExpandScratch &x)
+{
+    const int nseg = (int)ts.segs.size();
+    DALLOC(c, x.d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
+    DALLOC(c, x.d_tile_sum, u64 *, ts.ntiles * 16);
+    DALLOC(c, x.d_tile_off, u64 *, ts.ntiles * 16);
+    HIPCHK(c, hipMemcpyAsync(x.d_segs, ts.segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len, c->cfg.kmer_size, x.d_tile_sum);
+    hipLaunchKernelGGL(expand_scan_kernel, dim3(nseg), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, ts.ntiles, x.d_tile_sum, x.d_tile_off);
+    return HSK_OK;
+}
+static void expand_release(hsk_ctx *c, ExpandScratch &x) { c->pool.release(x.d_segs); c->pool.release(x.d_tile_sum); c->pool.release(x.d_tile_off); x = ExpandScratch(); }
+
 template <int NW>
-static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const u8 *sm_bytes, const u32 *sm_pos, const int32_t *sm_rid,
+static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const BaseSource &src, const u32 *sm_pos, const int32_t *sm_rid,
                        u64 *d_keys, u64 *d_vals)
 {
     if (ts.ntiles == 0) return HSK_OK;
     const bool ext = c->cfg.extension != 0;
     const int nseg = (int)ts.segs.size();
-    ExpSeg *d_segs; u64 *d_tile_sum, *d_tile_off;
-    DALLOC(c, d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
-    DALLOC(c, d_tile_sum, u64 *, ts.ntiles * 16);
-    DALLOC(c, d_tile_off, u64 *, ts.ntiles * 16);
-    HIPCHK(c, hipMemcpyAsync(d_segs, ts.segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
+    ExpandScratch x;
+    int rc = expand_prepare(c, ts, sm_len, x); if (rc) return rc;
     // (ts.segs is host memory owned by the caller and stays alive until the next sync)
-    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len, c->cfg.kmer_size, d_tile_sum);
-    hipLaunchKernelGGL(expand_scan_kernel, dim3(nseg), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, ts.ntiles, d_tile_sum, d_tile_off);
-    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len,
-                                (const u64 *)sm_bytes, sm_pos, sm_rid, d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
-    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, d_segs, nseg, sm_len,
-                            (const u64 *)sm_bytes, sm_pos, sm_rid, d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
+    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len,
+                                src.src8, src.bit0, src.nwords, src.gpos, sm_pos, sm_rid, x.d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
+    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len,
+                            src.src8, src.bit0, src.nwords, src.gpos, sm_pos, sm_rid, x.d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
     HIPCHK(c, hipGetLastError());
-    c->pool.release(d_segs); c->pool.release(d_tile_sum); c->pool.release(d_tile_off);
+    expand_release(c, x);
+    return HSK_OK;
+}
+
+// multi-GPU: bytes of all supermers of the store, in storage order (what the exchange sends)
+static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src)
+{
+    DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
+    if (st.tot_sup == 0) return HSK_OK;
+    TaskSegs all; ExpSeg s; s.sup_off = 0; s.n_sup = st.tot_sup; s.byte_off = 0; s.kmer_off = 0; s.tile_start = 0;
+    all.segs.push_back(s);
+    all.ntiles = (st.tot_sup + EXP_TILE - 1) / EXP_TILE;
+    ExpandScratch x;
+    int rc = expand_prepare(c, all, st.sm_len, x); if (rc) return rc;
+    hipLaunchKernelGGL(pack_kernel, dim3((u32)all.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, 1, st.sm_len, src.src8, src.bit0, src.nwords,
+                       st.sm_gpos, x.d_tile_off, st.sm_bytes);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // `all` lives on this stack frame
+    expand_release(c, x);
     return HSK_OK;
 }
 
@@ -618,14 +667,17 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // ---- exchange (multi-GPU) ---------------------------------------------------------------------
     // After this block `segs[t]` lists where the supermers of owned task t live.
     std::vector<TaskSegs> segs(ntasks);
-    const u8 *x_len = st.sm_len; const u8 *x_bytes = st.sm_bytes; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
+    const u8 *x_len = st.sm_len; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
+    BaseSource x_src = source_from_packed(d_packed, packed_bytes, st.sm_gpos);
     ExchangeBuffers xb;
     pt.begin(PH_EXCH);
     if (nranks > 1) {
-        int rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
+        int rc = pack_store_bytes(c, st, x_src); if (rc) return rc;
+        rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
                                     st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
         if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
-        x_len = xb.len; x_bytes = xb.bytes; x_pos = xb.pos; x_rid = xb.rid;
+        x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
+        x_src = source_from_bytes(xb.bytes, xb.nbytes);
         free_store(c, st);
     } else {
         for (u32 t = 0; t < ntasks; ++t) {
@@ -656,7 +708,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         if (owner[t] != rank || segs[t].nkmers == 0) continue;
         const u64 n = segs[t].nkmers;
         pt.begin(PH_EXTRACT);
-        int rc = expand_task<NW>(c, segs[t], x_len, x_bytes, x_pos, x_rid, keysA, valsA); if (rc) return rc;
+        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, keysA, valsA); if (rc) return rc;
         pt.end(PH_EXTRACT);
         pt.begin(PH_SORT);
         u64 *sk, *sv;
@@ -863,7 +915,7 @@ static int stage_task_kmers_impl(hsk_ctx *c, const DevInput &d, uint64_t packed_
         u64 *dk, *dv = nullptr;
         DALLOC(c, dk, u64 *, ts.nkmers * NW * 8 + 64);
         if (ext) DALLOC(c, dv, u64 *, ts.nkmers * 8 + 64);
-        rc = expand_task<NW>(c, ts, st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, dk, dv);
+        rc = expand_task<NW>(c, ts, st.sm_len, source_from_packed(d.packed, packed_bytes, st.sm_gpos), st.sm_pos, st.sm_rid, dk, dv);
         if (rc == HSK_OK) {
             HIPCHK(c, hipMemcpyAsync(keys, dk, ts.nkmers * NW * 8, hipMemcpyDeviceToHost, c->stream));
             std::vector<u64> hv;

@@ -123,7 +123,7 @@ struct Comm {
 };
 
 struct ExchangeBuffers {
-    uint8_t *len = nullptr; uint8_t *bytes = nullptr; uint32_t *pos = nullptr; int32_t *rid = nullptr;
+    uint8_t *len = nullptr; uint8_t *bytes = nullptr; uint32_t *pos = nullptr; int32_t *rid = nullptr; uint64_t nbytes = 0;
     template <typename Pool> void release(Pool &pool)
     {
         pool.release(len); pool.release(bytes); pool.release(pos); pool.release(rid);
@@ -191,7 +191,7 @@ inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int
     ExchangePlan pl;
     plan_exchange(nr, me, ntasks, owner, order, M, task_base, pl, segs);
     xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);
-    xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64);
+    xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64); xb.nbytes = pl.recv_tot_bytes;
     if (ext) { xb.pos = (uint32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); xb.rid = (int32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); }
     if (!xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid))) { cm.last_error = "oom"; return -1; }
     // 2. payload: one grouped send/recv per peer and array (self: device copy)

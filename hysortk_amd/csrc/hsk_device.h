@@ -118,6 +118,15 @@ __device__ __forceinline__ u64 bits64_bytes(const u64 *p8, u64 bit)
     u64 lo = __builtin_bswap64(p8[i + 1]);
     return (hi << s) | (lo >> (64 - s));
 }
+// same, never reading a word at or beyond index `nwords` (bits past the buffer read as zero)
+__device__ __forceinline__ u64 bits64_bytes_clamped(const u64 *p8, u64 bit, u64 nwords)
+{
+    u64 i = bit >> 6; u32 s = (u32)(bit & 63);
+    u64 hi = i < nwords ? __builtin_bswap64(p8[i]) : 0;
+    if (!s) return hi;
+    u64 lo = (i + 1 < nwords) ? __builtin_bswap64(p8[i + 1]) : 0;
+    return (hi << s) | (lo >> (64 - s));
+}
 
 // ---- x % d for a runtime-constant 32-bit d without a 64-bit division --------------------------
 // (GetMinimizerOwner, kmerops.cpp:1044: hash % tot_tasks).  Lemire fastmod for 32-bit operands,

@@ -85,9 +85,13 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_scan_kernel(const ExpSeg *
     }
 }
 
+// Source of the bases: either the re-aligned byte stream of received supermers (sm_gpos == null;
+// byte offsets come from the prefix sums) or, for supermers that never left this GPU, the rank's
+// packed reads themselves (sm_gpos[s] = position of the supermer's first base; `src8` = packed reads
+// rounded down to 8 bytes, `src_bit0` = bit offset of the first read base inside src8).
 template <int NW, bool EXT>
-__global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *sm_bytes8,
-                                                              const u32 *sm_pos, const int32_t *sm_rid, const u64 *tile_off,
+__global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *src8, u64 src_bit0, u64 src_words,
+                                                              const u64 *sm_gpos, const u32 *sm_pos, const int32_t *sm_rid, const u64 *tile_off,
                                                               int k, u64 *keys_out, u64 *vals_out)
 {
     __shared__ u32 s_boff[EXP_TILE + 1];
@@ -133,10 +137,11 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
             if (s_koff[mid] <= j) lo = mid; else hi = mid - 1;
         }
         const u32 i = j - s_koff[lo];
-        const u64 bit = 8 * (byte_abs + s_boff[lo]) + 2 * (u64)i;
+        const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[seg.sup_off + first + lo] + (u64)i))
+                                : (8 * (byte_abs + s_boff[lo]) + 2 * (u64)i);
         Mer<NW> mer;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) mer.w[w] = bits64_bytes(sm_bytes8, bit + 64 * w);
+        for (int w = 0; w < NW; ++w) mer.w[w] = bits64_bytes_clamped(src8, bit + 64 * w, src_words);
         mer.w[NW - 1] &= lastmask;
         Mer<NW> c = canonical<NW>(mer, k);
         const u64 o = kbase + j;
@@ -146,6 +151,48 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
             const u64 sa = seg.sup_off + first + lo;
             vals_out[o] = (u64)(sm_pos[sa] + i) | ((u64)(u32)sm_rid[sa] << 32);
         }
+    }
+}
+
+// Multi-GPU only: materialise the re-aligned byte stream of reference-mode supermers for the
+// exchange.  One lane per output byte (coalesced), the supermer of a byte is found by binary search
+// over the tile's byte prefix sums; layout identical to what parse_kernel's copy mode writes.
+__global__ __launch_bounds__(EXP_THREADS) void pack_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *src8, u64 src_bit0, u64 src_words,
+                                                            const u64 *sm_gpos, const u64 *tile_off, u8 *bytes_out)
+{
+    __shared__ u32 s_boff[EXP_TILE + 1];
+    __shared__ u32 s_scr[8];
+    const u64 tile = blockIdx.x;
+    const int sg = seg_of_tile(segs, nseg, tile);
+    const ExpSeg seg = segs[sg];
+    const u64 first = (tile - seg.tile_start) * EXP_TILE;
+    const u32 ns = (u32)((seg.n_sup - first) < (u64)EXP_TILE ? (seg.n_sup - first) : (u64)EXP_TILE);
+    const int tid = threadIdx.x;
+    u32 nb[EXP_SPT], sb = 0;
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) {
+        u32 s = tid * EXP_SPT + i;
+        u32 len = (s < ns) ? sm_len[seg.sup_off + first + s] : 0;
+        nb[i] = (s < ns) ? ((len + 3) >> 2) : 0;
+        sb += nb[i];
+    }
+    u32 totb;
+    u32 eb = block_excl_scan_256<u32>(sb, s_scr, &totb);
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) { s_boff[tid * EXP_SPT + i] = eb; eb += nb[i]; }
+    if (tid == EXP_THREADS - 1) s_boff[EXP_TILE] = eb;
+    __syncthreads();
+    const u64 byte_abs = tile_off[2 * tile];
+    for (u32 b = tid; b < totb; b += EXP_THREADS) {
+        u32 lo = 0, hi = ns - 1;
+        while (lo < hi) { u32 mid = (lo + hi + 1) >> 1; if (s_boff[mid] <= b) lo = mid; else hi = mid - 1; }
+        const u32 jb = b - s_boff[lo];
+        const u32 len = sm_len[seg.sup_off + first + lo];
+        const u64 bit = src_bit0 + 2 * sm_gpos[seg.sup_off + first + lo] + 8 * (u64)jb;
+        u8 byte = (u8)(bits64_bytes_clamped(src8, bit, src_words) >> 56);
+        const u32 nbs = (len + 3) >> 2;
+        if (jb == nbs - 1 && (len & 3)) byte &= (u8)(0xFF << (2 * (4 - (len & 3))));
+        bytes_out[byte_abs + b] = byte;
     }
 }
 

@@ -55,11 +55,12 @@ struct ParseArgs {
     // EMIT: blk_base[block][task][2] = {first supermer slot, first byte} (absolute)
     const u64 *blk_base;
     u8 *sm_len;                // supermer length in bases (one byte each)
-    u8 *sm_bytes;              // re-aligned 2-bit bases, (len+3)/4 bytes per supermer
-    u32 *sm_pos;               // EXTENSION: PosInRead of the supermer's first base
-    int32_t *sm_rid;           // EXTENSION: ReadId
+    u64 *sm_gpos;              // position of the supermer's first base in the rank's packed base stream
     // DUMP (stage test): dest per base position, -1 where no k-mer starts
     int32_t *dump_dest;
+    // optional: task id per base position (0xFFFF = no k-mer starts there), written by COUNT and read
+    // by EMIT so that the minimizer hashes are computed once; 16-byte aligned, 2 B per position
+    u16 *dest_cache;
 };
 
 enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
@@ -79,25 +80,22 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
     __shared__ u64 s_hash[PARSE_HMAX];
-    __shared__ u16 s_dest[PARSE_TILE + 8];   // sizes of the statics are multiples of 16 B (dynamic LDS base stays aligned)
+    __shared__ __attribute__((aligned(16))) u16 s_dest[PARSE_TILE + 8];   // sizes of the statics are multiples of 16 B (dynamic LDS base stays aligned)
     __shared__ u64 s_rng[4];                 // r0, r1 (first / last read overlapping the tile), window base, fast-path flag
     __shared__ u64 s_roff[PARSE_RWIN];       // roff[rb + i]: the read index window of this tile (one coalesced load)
     __shared__ u32 s_rlen[PARSE_RWIN];
-    extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // COUNT: 3*ntasks counters, EMIT: 2*ntasks bases + ntasks cursors
+    __shared__ u32 s_scan[12];               // [0..8) block-scan scratch, [8] records in this tile (48 B keeps the dynamic base 16-B aligned)
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // 16 B per task: COUNT {supermers<<40|k-mers, bytes}; EMIT {slot cursor, u32 tile count, u32 tile prefix}
 
     const int tid = threadIdx.x;
     const int K = a.k, M = a.m, W = K - M + 1;
     const u64 total_pos = a.packed_bytes * 4;
 
     if (MODE == PARSE_COUNT) {
-        for (u32 i = tid; i < 3 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
+        for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;      // [task] = {supermers << 40 | k-mers, bytes}
     } else if (MODE == PARSE_EMIT) {
-        // s_cur[0 .. 2*ntasks) = absolute {slot, byte} bases of this workgroup, s_cur[2*ntasks + t] = packed
-        // running cursor of task t: supermers << 36 | bytes.  ONE atomic reserves both, so that slot order
-        // and byte order agree (the expander derives byte offsets from a prefix sum over the slots).
-        for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS)
-            s_cur[i] = a.blk_base[(u64)blockIdx.x * 2 * a.ntasks + i];
-        for (u32 i = tid; i < a.ntasks; i += PARSE_THREADS) s_cur[2 * a.ntasks + i] = 0;
+        // s_cur[task] = absolute slot cursor of this workgroup; then u32 tile counts and prefixes (see step 4)
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] = a.blk_base[((u64)blockIdx.x * a.ntasks + t) * 2];
     }
     __syncthreads();
 
@@ -111,10 +109,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
         const u64 tile = tile0 + ti;
         if (tile >= a.ntiles) break;
         const u64 gbase = tile * PARSE_TILE;            // first base position of the tile
+        const bool cached_emit = (MODE == PARSE_EMIT) && a.dest_cache != nullptr;   // uniform: EMIT only replays the task ids
         const u64 bbase = gbase >> 2;                   // first byte
 
         // ---- 1. stage bytes (big-endian words) ------------------------------------------------
-        {
+        if (!cached_emit) {
             const u32 *src = reinterpret_cast<const u32 *>(a.packed + bbase);   // bbase % 512 == 0, base 4-B aligned
             const u64 left = a.packed_bytes - bbase;                            // bytes readable from bbase
             for (int i = tid; i < PARSE_WORDS; i += PARSE_THREADS) {
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
             }
         }
         // tile-level read range (reads overlapping [bbase, bbase + 512)): wave 0 probes 64 index entries
-        if (tid < PARSE_RWIN) {
+        if (!cached_emit && tid < PARSE_RWIN) {
             const u64 rb = s_rng[1];                                   // <= r0 of this tile (offsets are monotone)
             u64 blast = bbase + PARSE_TILE / 4 - 1;
             if (blast >= a.packed_bytes) blast = a.packed_bytes - 1;
@@ -149,19 +148,25 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
         }
         __syncthreads();
 
+        const int p0 = tid * PARSE_PPT;
+        const bool cached = cached_emit;
         // ---- 2. canonical m-mer hashes for positions [0, TILE + W - 1) ---------------------------
         const u64 mmask = ~0ULL << (64 - 2 * M);
-        for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) {
-            u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
-            u64 tw = twin1(fw, M);
-            s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+        if (!cached) {
+            for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) {
+                u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
+                u64 tw = twin1(fw, M);
+                s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+            }
         }
         __syncthreads();
 
         // ---- 3. window minima, dest, validity -------------------------------------------------
-        const int p0 = tid * PARSE_PPT;
         u64 mn[PARSE_PPT];
-        if (W >= PARSE_PPT) {
+        if (cached) {
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) mn[i] = 0;
+        } else if (W >= PARSE_PPT) {
             u64 c = ~0ULL;
             for (int j = PARSE_PPT - 1; j <= W - 1; ++j) { u64 v = s_hash[p0 + j]; c = v < c ? v : c; }
             u64 suf = ~0ULL;
@@ -180,8 +185,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
             }
         }
         // read tracking for this lane's 8 positions (2 bytes)
-        u32 posr[PARSE_PPT]; u32 ridx[PARSE_PPT];   // pos in read / read index relative to s_rng[0]
-        {
+        if (!cached) {
             const u64 g0 = gbase + p0;
             const u64 rlo = s_rng[0], rhi = s_rng[1], rb = s_rng[2];
             const bool fast = s_rng[3] != 0;
@@ -206,11 +210,17 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                     else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
                 }
                 const bool valid = (g < total_pos) && (g + K <= rend);
-                const u32 d = fastmod64(mn[i], a.fm);
-                s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
-                posr[i] = (u32)(g - rstart);
-                ridx[i] = (u32)(r - rlo);
+                if (!cached) {
+                    const u32 d = fastmod64(mn[i], a.fm);
+                    s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
+                }
             }
+        }
+        if (cached) {                                   // 8 task ids = one 16-byte load per lane
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.dest_cache + gbase + p0);
+            *reinterpret_cast<uint4 *>(&s_dest[p0]) = v;
+        } else if (MODE == PARSE_COUNT && a.dest_cache != nullptr) {
+            *reinterpret_cast<uint4 *>(a.dest_cache + gbase + p0) = *reinterpret_cast<const uint4 *>(&s_dest[p0]);
         }
         __syncthreads();
 
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                 u64 g = gbase + p0 + i;
                 if (g < total_pos) { u16 d = s_dest[p0 + i]; a.dump_dest[g] = d == 0xFFFF ? -1 : (int32_t)d; }
             }
-        } else {
+        } else if (MODE == PARSE_COUNT) {
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 const int p = p0 + i;
@@ -233,40 +243,84 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                 int q = p + 1;
                 while (q < lim && s_dest[q] == d) ++q;
                 const u32 nk = (u32)(q - p);
-                const u32 len = nk + K - 1;
-                const u32 nb = (len + 3) >> 2;
-                if (MODE == PARSE_COUNT) {
-                    atomicAdd((unsigned long long *)&s_cur[3 * d + 0], 1ULL);
-                    atomicAdd((unsigned long long *)&s_cur[3 * d + 1], (unsigned long long)nb);
-                    atomicAdd((unsigned long long *)&s_cur[3 * d + 2], (unsigned long long)nk);
-                } else {
-                    const u64 cur = atomicAdd((unsigned long long *)&s_cur[2 * a.ntasks + d], (1ULL << 36) | (unsigned long long)nb);
-                    const u64 slot = s_cur[2 * d + 0] + (cur >> 36);
-                    const u64 bo = s_cur[2 * d + 1] + (cur & ((1ULL << 36) - 1));
-                    a.sm_len[slot] = (u8)len;
-                    if (EXT) {
-                        a.sm_pos[slot] = posr[i];
-                        a.sm_rid[slot] = (int32_t)(a.rid_base + (int64_t)(s_rng[0] + ridx[i]));
-                    }
-                    u8 *out = a.sm_bytes + bo;
-                    for (u32 j = 0; j < nb; j += 8) {
-                        u64 x = bits64_be32(s_words, 2u * (u32)p + 8u * j);
-                        const u32 lim8 = (nb - j) < 8 ? (nb - j) : 8;
-                        for (u32 b = 0; b < lim8; ++b) {
-                            u8 byte = (u8)(x >> (56 - 8 * b));
-                            if (j + b == nb - 1 && (len & 3)) byte &= (u8)(0xFF << (2 * (4 - (len & 3))));
-                            out[j + b] = byte;
-                        }
-                    }
-                }
+                const u32 nb = (nk + K - 1 + 3) >> 2;
+                atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);   // supermers << 40 | k-mers
+                atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)nb);
             }
+        } else {
+            // EMIT.  A supermer is the record {length, position of its first base}: the bases stay in the
+            // packed reads (resident in HBM); bytes are materialised only for supermers that leave the GPU
+            // (pack_kernel).  The tile's records are counting-sorted by task in LDS first, so that the global
+            // stores of one wave instruction cover a few contiguous runs instead of 64 scattered slots.
+            u32 *s_srt = reinterpret_cast<u32 *>(s_hash);                 // s_hash is dead here (>= 8 KB)
+            u32 *s_tcnt = reinterpret_cast<u32 *>(s_cur + a.ntasks);       // [ntasks] records of this tile per task
+            u32 *s_tpre = s_tcnt + a.ntasks;                               // [ntasks] exclusive prefix
+            for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_tcnt[t] = 0;
+            __syncthreads();
+            u32 rec[PARSE_PPT], rnk[PARSE_PPT];
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const int p = p0 + i;
+                const u16 d = s_dest[p];
+                rec[i] = 0xFFFFFFFFu;
+                if (d == 0xFFFF) continue;
+                const bool start = ((p & (SUPERMER_CUT - 1)) == 0) || (s_dest[p - 1] != d);
+                if (!start) continue;
+                const int lim = (p | (SUPERMER_CUT - 1)) + 1;
+                int q = p + 1;
+                while (q < lim && s_dest[q] == d) ++q;
+                rec[i] = (u32)p | ((u32)(q - p - 1) << 11) | ((u32)d << 18);
+                rnk[i] = atomicAdd(&s_tcnt[d], 1u);
+            }
+            __syncthreads();
+            {   // exclusive prefix of the per-task counts: 4 consecutive tasks per lane
+                u32 c4[4], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; c4[j] = t < a.ntasks ? s_tcnt[t] : 0; sum += c4[j]; }
+                u32 tot;
+                u32 e = block_excl_scan_256<u32>(sum, s_scan, &tot);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; if (t < a.ntasks) s_tpre[t] = e; e += c4[j]; }
+                if (tid == 0) s_scan[8] = tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i)
+                if (rec[i] != 0xFFFFFFFFu) s_srt[s_tpre[rec[i] >> 18] + rnk[i]] = rec[i];
+            __syncthreads();
+            const u32 nrec = s_scan[8];
+            for (u32 i = tid; i < nrec; i += PARSE_THREADS) {
+                const u32 r = s_srt[i];
+                const u32 d = r >> 18;
+                const u64 slot = s_cur[d] + (i - s_tpre[d]);
+                a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);             // nk - 1 + K = bases in the supermer
+                a.sm_gpos[slot] = gbase + (u64)(r & 2047);
+            }
+            __syncthreads();
+            for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
         }
         __syncthreads();
     }
 
     if (MODE == PARSE_COUNT) {
-        for (u32 i = tid; i < 3 * a.ntasks; i += PARSE_THREADS)
-            a.blk_cnt[(u64)blockIdx.x * 3 * a.ntasks + i] = s_cur[i];
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
+            u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
+            const u64 pk = s_cur[2 * t];
+            o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
+        }
+    }
+}
+
+// EXTENSION: (PosInRead, ReadId) of every supermer from its base position (one index search per supermer;
+// the reference carries them in length_t, include/kmer.hpp:350-360)
+__global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *roff, u64 nreads, int64_t rid_base, u32 *sm_pos, int32_t *sm_rid)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) {
+        const u64 g = sm_gpos[s];
+        const u64 r = find_read(roff, 0, nreads - 1, g >> 2);
+        sm_pos[s] = (u32)(g - roff[r] * 4);
+        sm_rid[s] = (int32_t)(rid_base + (int64_t)r);
     }
 }
 
