@@ -501,6 +501,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         SortArgs a; memset(&a, 0, sizeof a);
         a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout; a.n = n;
         a.word = h.pass[p].word; a.shift = h.pass[p].shift; a.bits = h.pass[p].bits;
+        a.ntiles = ntiles;
         a.gbase = sc.gbase + (size_t)p * 256;
         a.lookback = (char *)sc.lookback + i * (size_t)ntiles * 256 * lbw;
         a.ticket = sc.tickets + i; a.err = c->d_err;
@@ -513,6 +514,105 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
     HIPCHK(c, hipGetLastError());
     *out_keys = kin; *out_vals = vin;
     return HSK_OK;
+}
+
+// ---- eight tasks at a time, one per XCD (onesweep_multi_kernel) -----------------------------------------
+struct BatchTask { u64 n = 0; u64 *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr; u64 *out_k = nullptr, *out_v = nullptr; };
+constexpr int XCD_BATCH = 8;
+
+template <int NW, bool HAS_VAL, typename LB>
+static void launch_onesweep_multi(hsk_ctx *c, const MultiSortArgs &m, u32 grid)
+{
+    hipLaunchKernelGGL((onesweep_multi_kernel<NW, HAS_VAL, LB>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, m);
+}
+
+template <int NW>
+static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const bool has_val = bt[0].vA != nullptr;
+    constexpr int TILE = SortTile<NW>::TILE;
+    u64 *d_ghist, *d_gbase; u32 *d_tickets;
+    DALLOC(c, d_ghist, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    DALLOC(c, d_gbase, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    DALLOC(c, d_tickets, u32 *, (size_t)XCD_BATCH * MAX_PASSES * 4 + 256);
+    HIPCHK(c, hipMemsetAsync(d_ghist, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4, c->stream));
+    PassDesc plan[MAX_PASSES];
+    const int npass = make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+    u64 ntot = 0; bool wide = false;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
+        ntot += bt[i].n; if (bt[i].n >= (1ULL << 30)) wide = true;
+        if (bt[i].n == 0) continue;
+        HistArgs h; memset(&h, 0, sizeof h);
+        h.keys = bt[i].kA; h.n = bt[i].n; h.npass = npass; memcpy(h.pass, plan, sizeof(PassDesc) * npass);
+        h.ghist = d_ghist + (size_t)i * MAX_PASSES * 256;
+        const u32 hblocks = (u32)std::min<u64>((bt[i].n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16), 2048);
+        EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 1; hp.bytes = bt[i].n * NW * 8; (void)hipEventRecord(hp.a, c->stream); }
+        hipLaunchKernelGGL((hist_kernel<NW>), dim3(hblocks), dim3(SORT_THREADS), (size_t)npass * 256 * 4, c->stream, h);
+        if (profile) { (void)hipEventRecord(hp.b, c->stream); c->ev_pending.push_back(hp); }
+    }
+    std::vector<u64> hh((size_t)XCD_BATCH * MAX_PASSES * 256), hb((size_t)XCD_BATCH * MAX_PASSES * 256, 0);
+    HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> todo;
+    for (int p = 0; p < npass; ++p) {
+        bool all_trivial = true;
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            if (bt[i].n < 2) continue;
+            bool trivial = false; u64 run = 0;
+            const size_t o = ((size_t)i * MAX_PASSES + p) * 256;
+            for (int d = 0; d < 256; ++d) { if (hh[o + d] == bt[i].n) trivial = true; hb[o + d] = run; run += hh[o + d]; }
+            if (!trivial) all_trivial = false;
+        }
+        if (!all_trivial) todo.push_back(p);
+    }
+    int rc = HSK_OK;
+    void *d_lookback = nullptr;
+    if (!todo.empty()) {
+        HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
+        const size_t lbw = wide ? 8 : 4;
+        size_t lb_off[XCD_BATCH + 1]; lb_off[0] = 0;
+        u64 ntiles[XCD_BATCH];
+        for (int i = 0; i < XCD_BATCH; ++i) { ntiles[i] = bt[i].n < 2 ? 0 : (bt[i].n + TILE - 1) / TILE; lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * lbw; }
+        const size_t per_pass = lb_off[XCD_BATCH];
+        u64 max_tiles = 0; for (int i = 0; i < XCD_BATCH; ++i) max_tiles = std::max(max_tiles, ntiles[i]);
+        const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
+        d_lookback = c->pool.alloc(per_pass * todo.size() + 256);
+        if (!d_lookback) return fail(c, HSK_ERR_OOM, "look-back table of %zu bytes", per_pass * todo.size());
+        HIPCHK(c, hipMemsetAsync(d_lookback, 0, per_pass * todo.size(), c->stream));
+        u64 *kin[XCD_BATCH], *kout[XCD_BATCH], *vin[XCD_BATCH], *vout[XCD_BATCH];
+        for (int i = 0; i < XCD_BATCH; ++i) { kin[i] = bt[i].kA; kout[i] = bt[i].kB; vin[i] = bt[i].vA; vout[i] = bt[i].vB; }
+        for (size_t j = 0; j < todo.size(); ++j) {
+            const int p = todo[j];
+            MultiSortArgs m; memset(&m, 0, sizeof m);
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                SortArgs &a = m.t[i];
+                a.keys_in = kin[i]; a.keys_out = kout[i]; a.vals_in = vin[i]; a.vals_out = vout[i]; a.n = bt[i].n; a.ntiles = ntiles[i];
+                a.word = plan[p].word; a.shift = plan[p].shift; a.bits = plan[p].bits;
+                a.gbase = d_gbase + ((size_t)i * MAX_PASSES + p) * 256;
+                a.lookback = (char *)d_lookback + j * per_pass + lb_off[i];
+                a.ticket = d_tickets + (size_t)i * MAX_PASSES + j; a.err = c->d_err;
+            }
+            EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * (NW * 8 + (has_val ? 8 : 0)); (void)hipEventRecord(ep.a, c->stream); }
+            if (has_val) { if (wide) launch_onesweep_multi<NW, true, u64>(c, m, grid); else launch_onesweep_multi<NW, true, u32>(c, m, grid); }
+            else { if (wide) launch_onesweep_multi<NW, false, u64>(c, m, grid); else launch_onesweep_multi<NW, false, u32>(c, m, grid); }
+            if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+            for (int i = 0; i < XCD_BATCH; ++i) { if (ntiles[i]) { std::swap(kin[i], kout[i]); std::swap(vin[i], vout[i]); } }
+        }
+        HIPCHK(c, hipGetLastError());
+        for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = kin[i]; bt[i].out_v = vin[i]; }
+        // every XCD must have drained its task: ticket counters are >= tile counts
+        std::vector<u32> tk((size_t)XCD_BATCH * MAX_PASSES);
+        HIPCHK(c, hipMemcpyAsync(tk.data(), d_tickets, tk.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
+            for (size_t j = 0; j < todo.size(); ++j)
+                if (tk[(size_t)i * MAX_PASSES + j] < ntiles[i]) { rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (pass %zu: %u of %llu tiles)", i, j, tk[(size_t)i * MAX_PASSES + j], (unsigned long long)ntiles[i]); break; }
+    }
+    c->pool.release(d_lookback); c->pool.release(d_ghist); c->pool.release(d_gbase); c->pool.release(d_tickets);
+    return rc;
 }
 
 static int alloc_sort_scratch(hsk_ctx *c, SortScratch &sc)
@@ -611,6 +711,9 @@ static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
     u64 est = packed_bytes * 4 * (u64)std::max(nranks, 1);
     u64 t = (est + (1ULL << 28) - 1) >> 28;
     t = std::max<u64>(t, (u64)std::max(nranks, 1));
+    // tasks are sorted eight at a time (one per XCD): give every rank a multiple of eight when there are that many
+    const u64 per = 8ULL * (u64)std::max(nranks, 1);
+    if (t >= per) t = (t + per - 1) / per * per;
     return (u32)std::min<u64>(std::max<u64>(t, 1), HSK_MAX_TASKS);
 }
 
@@ -695,34 +798,67 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     const u32 histo_len = (u32)c->cfg.upper_freq + 1;
     u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
     HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
-    u64 *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr;
+    // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
+    // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
+    static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    std::vector<u32> mine;
+    for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
+    const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
+    const int nsets = batch ? XCD_BATCH : 1;
+    u64 *kA[XCD_BATCH] = {nullptr}, *kB[XCD_BATCH] = {nullptr}, *vA[XCD_BATCH] = {nullptr}, *vB[XCD_BATCH] = {nullptr};
     SortScratch sc;
     if (max_task) {
-        DALLOC(c, keysA, u64 *, max_task * NW * 8 + 64); DALLOC(c, keysB, u64 *, max_task * NW * 8 + 64);
-        if (ext) { DALLOC(c, valsA, u64 *, max_task * 8 + 64); DALLOC(c, valsB, u64 *, max_task * 8 + 64); }
+        for (int i = 0; i < nsets; ++i) {
+            DALLOC(c, kA[i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kB[i], u64 *, max_task * NW * 8 + 64);
+            if (ext) { DALLOC(c, vA[i], u64 *, max_task * 8 + 64); DALLOC(c, vB[i], u64 *, max_task * 8 + 64); }
+        }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
     std::vector<TaskOut> touts(ntasks);
     u64 n_total = 0, pay_total = 0;
-    for (u32 t = 0; t < ntasks; ++t) {
-        if (owner[t] != rank || segs[t].nkmers == 0) continue;
+    // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
+    std::vector<u64> pay_before(ntasks, 0);
+    { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
+    size_t pos = 0;
+    while (batch && pos + XCD_BATCH <= mine.size()) {
+        BatchTask bt[XCD_BATCH];
+        pt.begin(PH_EXTRACT);
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[pos + i];
+            bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
+            int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[i], vA[i]); if (rc) return rc;
+        }
+        pt.end(PH_EXTRACT);
+        pt.begin(PH_SORT);
+        { int rc = sort_batch_device<NW>(c, bt, K); if (rc) return rc; }
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[pos + i];
+            int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+        }
+        pt.end(PH_COUNT);
+        pos += XCD_BATCH;
+    }
+    for (; pos < mine.size(); ++pos) {
+        const u32 t = mine[pos];
         const u64 n = segs[t].nkmers;
         pt.begin(PH_EXTRACT);
-        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, keysA, valsA); if (rc) return rc;
+        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[0], vA[0]); if (rc) return rc;
         pt.end(PH_EXTRACT);
         pt.begin(PH_SORT);
         u64 *sk, *sv;
-        rc = sort_task_device<NW>(c, keysA, keysB, valsA, valsB, n, K, sc, &sk, &sv); if (rc) return rc;
+        rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
-        rc = count_task_device<NW>(c, sk, sv, n, pay_total, d_histo, histo_len, touts[t]); if (rc) return rc;
+        rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
         pt.end(PH_COUNT);
-        n_total += touts[t].n; pay_total += touts[t].npay;
     }
+    for (u32 t : mine) { n_total += touts[t].n; pay_total += touts[t].npay; }
     {
         int rc = check_device_error(c); if (rc) return rc;
     }
-    c->pool.release(keysA); c->pool.release(keysB); c->pool.release(valsA); c->pool.release(valsB);
+    for (int i = 0; i < nsets; ++i) { c->pool.release(kA[i]); c->pool.release(kB[i]); c->pool.release(vA[i]); c->pool.release(vB[i]); }
     free_sort_scratch(c, sc);
     if (nranks > 1) xb.release(c->pool); else free_store(c, st);
 

@@ -79,6 +79,7 @@ struct SortArgs {
     const u64 *keys_in; u64 *keys_out;
     const u64 *vals_in; u64 *vals_out;
     u64 n;
+    u64 ntiles;           // tiles of this task and pass
     int word, shift, bits;
     const u64 *gbase;     // [256] exclusive digit offsets of this pass
     void *lookback;       // [ntiles][256] LB words, zeroed
@@ -98,8 +99,12 @@ __device__ unsigned long long g_diag[32];
 #define DIAG_STAMP(i) do { } while (0)
 #endif
 
-template <int NW, bool HAS_VAL, typename LB>
-__global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
+// One tile of one pass.  LOCAL = the look-back words of this sort are only ever touched by workgroups of
+// ONE XCD (onesweep_multi_kernel): they are published with plain stores (which stay in that XCD's L2) and
+// polled with L1-bypassing loads, so the flag round trip never leaves the XCD.  !LOCAL = any placement:
+// agent-scope (sc1, write-through) stores and loads.
+template <int NW, bool HAS_VAL, typename LB, bool LOCAL>
+__device__ __forceinline__ void onesweep_tile(const SortArgs &a)
 {
     constexpr int KPT = SortTile<NW>::KPT;
     constexpr int TILE = SortTile<NW>::TILE;
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
     __syncthreads();
     DIAG_STAMP(1);
     const u64 tile = s_tile[0];
+    if (tile >= a.ntiles) return;                 // uniform: the whole workgroup leaves (multi kernel: task exhausted)
     const u64 base = tile * TILE;
     const u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
     const u32 dmask = (1u << a.bits) - 1;
@@ -188,8 +194,11 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
     typedef __attribute__((address_space(1))) LB GLB;          // global (not flat) accesses for the look-back words
     GLB *lb = (GLB *)a.lookback;
     GLB *mine = lb + tile * 256 + tid;
-    if (tile == 0) __hip_atomic_store(mine, (LB)(L::INCL | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(mine, (LB)(L::AGG | (LB)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const LB v0 = (LB)((tile == 0 ? L::INCL : L::AGG) | (LB)total);
+        if (LOCAL) __hip_atomic_store(mine, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(mine, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
 
     // ---- permute through LDS into digit order (overlaps the predecessors' progress) ------------
@@ -239,7 +248,8 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        __hip_atomic_store(mine, (LB)(L::INCL | (LB)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LOCAL) __hip_atomic_store(mine, (LB)(L::INCL | (LB)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(mine, (LB)(L::INCL | (LB)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef HSK_DIAG
         if (tid == 0) { atomicAdd(&g_diag[10], (unsigned long long)dg_steps); atomicAdd(&g_diag[11], (unsigned long long)spins); atomicAdd(&g_diag[12], (unsigned long long)(tile - 1 - t)); }
 #endif
@@ -269,6 +279,29 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
         atomicAdd(&g_diag[16], 1ULL);
     }
 #endif
+}
+
+// one task, any placement: one tile per workgroup
+template <int NW, bool HAS_VAL, typename LB>
+__global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
+{
+    onesweep_tile<NW, HAS_VAL, LB, false>(a);
+}
+
+// Eight independent tasks in one launch, one per XCD: a workgroup reads the id of the XCD it runs on
+// (HW_REG_XCC_ID) and only ever works on that XCD's task, so every look-back word is shared inside one
+// XCD (-> LOCAL flags).  The grid has (8 x the largest tile count) + 12 % workgroups; the dispatcher deals
+// them round-robin over the XCDs, a workgroup whose task has no tile left exits at once, and the host
+// verifies afterwards that every ticket counter passed its tile count (HSK_ERR_INTERNAL otherwise: the
+// results never silently depend on the placement).
+struct MultiSortArgs { SortArgs t[8]; };
+constexpr unsigned XCC_ID_GETREG = 20u | (0u << 6) | (3u << 11);     // HW_REG_XCC_ID, bits [3:0]
+
+template <int NW, bool HAS_VAL, typename LB>
+__global__ __launch_bounds__(SORT_THREADS) void onesweep_multi_kernel(MultiSortArgs m)
+{
+    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
+    onesweep_tile<NW, HAS_VAL, LB, true>(m.t[xcc]);       // leaves at once when the XCD's task has no tile left
 }
 
 } // namespace hsk
