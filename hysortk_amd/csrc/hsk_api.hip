@@ -674,8 +674,19 @@ static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n
         DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
         if (ext) DALLOC(c, out.payoff, u64 *, out.n * 8);
         a.entries = out.entries; a.run_start = out.payoff;
-        if (ext) hipLaunchKernelGGL((count_kernel<NW, true, true>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((count_kernel<NW, true, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
+        // persistent: one histogram flush per workgroup; exactly the resident workgroup count, so no ragged second wave
+        static int occ_e[2] = {0, 0};
+        int &occ = occ_e[ext ? 1 : 0];
+        if (!occ) {
+            int nb = 0;
+            hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_kernel<NW, true, true>, CNT_THREADS, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_kernel<NW, true, false>, CNT_THREADS, 0);
+            occ = (e == hipSuccess && nb > 0) ? nb : 4;
+        }
+        hipDeviceProp_t *pr = nullptr; (void)pr;
+        const u32 egrid = (u32)std::min<u64>(ntiles, (u64)occ * 256);
+        if (ext) hipLaunchKernelGGL((count_kernel<NW, true, true>), dim3(egrid), dim3(CNT_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((count_kernel<NW, true, false>), dim3(egrid), dim3(CNT_THREADS), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     c->pool.release(d_tile_cnt); c->pool.release(d_total);

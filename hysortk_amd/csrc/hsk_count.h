@@ -22,7 +22,8 @@ constexpr int CNT_THREADS = 256;
 constexpr int CNT_PPT = 8;
 constexpr int CNT_TILE = CNT_THREADS * CNT_PPT;
 constexpr int CNT_WORDS = CNT_TILE / 64;     // 32 mask words
-constexpr int CNT_LDS_HIST = 1024;           // counts below this are histogrammed in LDS
+constexpr int CNT_LDS_HIST = 256;            // counts below this are histogrammed in LDS
+constexpr int CNT_HALO = 256;                // records of the next tile staged too: the tile's last run usually ends there
 
 struct CountArgs {
     const u64 *keys;        // sorted, n * NW
@@ -48,18 +49,25 @@ __device__ __forceinline__ bool keys_equal(const u64 *a, const u64 *b)
 template <int NW, bool EMIT, bool EXT>
 __global__ __launch_bounds__(CNT_THREADS) void count_kernel(CountArgs a)
 {
-    __shared__ u64 s_k[(CNT_TILE + 1) * NW];     // [0] = record preceding the tile
+    __shared__ u64 s_k[(CNT_TILE + 1 + CNT_HALO) * NW];     // [0] = record preceding the tile, then the tile, then the halo
     __shared__ u64 s_head[CNT_WORDS];
     __shared__ u64 s_keep[CNT_WORDS];
     __shared__ u32 s_pre[CNT_WORDS + 1];
     __shared__ u32 s_hist[EMIT ? CNT_LDS_HIST : 1];
+    __shared__ u16 s_ocnt[EMIT ? CNT_TILE : 2];     // count of the e-th kept run of the tile (U <= 65535)
+    __shared__ u16 s_opos[EMIT ? CNT_TILE : 2];     // its first record
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 tile = blockIdx.x;
+    const u64 ntiles = (a.n + CNT_TILE - 1) / CNT_TILE;
+    if (EMIT) for (int i = tid; i < CNT_LDS_HIST; i += CNT_THREADS) s_hist[i] = 0;
+    // workgroups stride over the tiles: the LDS count histogram is flushed once per workgroup, not per tile
+    // (a per-tile flush is ~30 global atomics on the same few hot bins per 2048 records)
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += (EMIT ? (u64)gridDim.x : ntiles)) {     // COUNT: one tile per workgroup
     const u64 base = tile * CNT_TILE;
     const u32 tn = (u32)((a.n - base) < (u64)CNT_TILE ? (a.n - base) : (u64)CNT_TILE);
-
-    if (EMIT) for (int i = tid; i < CNT_LDS_HIST; i += CNT_THREADS) s_hist[i] = 0;
-    for (u32 i = tid; i < (tn + 1) * NW; i += CNT_THREADS) {          // records base-1 .. base+tn-1
+    if (EMIT) __syncthreads();
+    const u64 obase = EMIT ? a.tile_cnt[tile] : 0;             // issued early: not on the critical path at the end
+    const u32 hn = (u32)((a.n - base - tn) < (u64)CNT_HALO ? (a.n - base - tn) : (u64)CNT_HALO);   // halo records available
+    for (u32 i = tid; i < (tn + 1 + hn) * NW; i += CNT_THREADS) {     // records base-1 .. base+tn+hn-1
         const long long gi = (long long)(base * NW) + (long long)i - NW;
         s_k[i] = gi >= 0 ? a.keys[gi] : 0;
     }
@@ -89,9 +97,11 @@ __global__ __launch_bounds__(CNT_THREADS) void count_kernel(CountArgs a)
             if (m) c = (w << 6) + (u32)__builtin_ctzll(m) - p;
             else {                                            // last run of the tile: may continue in HBM
                 c = tn - p;
-                u64 g = base + tn;
                 const u64 *me = &s_k[(p + 1) * NW];
-                while (g < a.n && c <= a.upper) {
+                u32 h = 0;                                    // first the halo in LDS (a dependent HBM load per step is ~1 us)
+                while (h < hn && c <= a.upper && keys_equal<NW>(&s_k[(tn + 1 + h) * NW], me)) { ++h; ++c; }
+                u64 g = base + tn + h;
+                while (h == hn && g < a.n && c <= a.upper) {
                     u64 o[NW];
 #pragma unroll
                     for (int x = 0; x < NW; ++x) o[x] = a.keys[g * NW + x];
@@ -116,23 +126,32 @@ __global__ __launch_bounds__(CNT_THREADS) void count_kernel(CountArgs a)
 
     if (!EMIT) {
         if (tid == 0) a.tile_cnt[tile] = s_pre[CNT_WORDS];
-        return;
     } else {
-        const u64 obase = a.tile_cnt[tile];
+        // kept runs are first listed in LDS in output order (slot = popcount prefix), then the entries
+        // are written by consecutive lanes to consecutive records: coalesced 16/24/32-byte records
+        // instead of one scattered record per lane
 #pragma unroll
         for (int j = 0; j < CNT_PPT; ++j) {
             const u32 c = runlen[j];
             if (!c) continue;
             const u32 p = j * CNT_THREADS + tid;
             const u32 w = j * 4 + wave;
-            const u64 o = obase + s_pre[w] + (u32)__popcll(s_keep[w] & ((1ULL << lane) - 1));
-#pragma unroll
-            for (int x = 0; x < NW; ++x) a.entries[o * (NW + 1) + x] = s_k[(p + 1) * NW + x];
-            a.entries[o * (NW + 1) + NW] = c;
-            if (EXT) a.run_start[o] = a.payoff_add + base + p;
+            const u32 slot = s_pre[w] + (u32)__popcll(s_keep[w] & ((1ULL << lane) - 1));
+            s_opos[slot] = (u16)p; s_ocnt[slot] = (u16)c;
             if (c < CNT_LDS_HIST) atomicAdd(&s_hist[c], 1u);
             else if (c < a.histo_len) atomicAdd((unsigned long long *)&a.histo[c], 1ULL);
         }
+        __syncthreads();
+        const u32 nkept = s_pre[CNT_WORDS];
+        for (u32 i = tid; i < nkept * (NW + 1); i += CNT_THREADS) {      // one 8-byte word per lane, fully coalesced
+            const u32 e = i / (NW + 1), x = i - e * (NW + 1);
+            const u32 p = s_opos[e];
+            a.entries[(obase + e) * (NW + 1) + x] = (x < (u32)NW) ? s_k[(p + 1) * NW + x] : (u64)s_ocnt[e];
+        }
+        if (EXT) for (u32 e = tid; e < nkept; e += CNT_THREADS) a.run_start[obase + e] = a.payoff_add + base + s_opos[e];
+    }
+    }   // tile loop
+    if (EMIT) {
         __syncthreads();
         for (int i = tid; i < CNT_LDS_HIST; i += CNT_THREADS) {
             const u32 c = s_hist[i];
