@@ -125,6 +125,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HSK_FORCE_DEVICE") is not None:          # debugging aid: several ranks on one GPU
+        local = int(os.environ["HSK_FORCE_DEVICE"])
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))

@@ -262,6 +262,25 @@ class Context:
         self._check(self.lib.hsk_count_device(self.h, d_packed, packed_bytes, d_off, d_len, nreads, rid_base, C.byref(res)))
         return self._wrap(res)
 
+    def count_loopback(self, dnas):
+        """`len(dnas)` virtual ranks on this GPU (hsk_count_loopback): returns ([KmerList per rank], owner table)."""
+        R = len(dnas)
+        arrs = [d.arrays() if isinstance(d, DnaBuffer) else d for d in dnas]
+        pk = [np.ascontiguousarray(a[0], dtype=np.uint8) for a in arrs]
+        of = [np.ascontiguousarray(a[1], dtype=np.uint64) for a in arrs]
+        ln = [np.ascontiguousarray(a[2], dtype=np.uint32) for a in arrs]
+        PP = (C.c_void_p * R)(*[x.ctypes.data for x in pk])
+        OP = (C.c_void_p * R)(*[x.ctypes.data for x in of])
+        LP = (C.c_void_p * R)(*[x.ctypes.data for x in ln])
+        nb = np.array([x.size for x in pk], dtype=np.uint64)
+        nr = np.array([x.size for x in ln], dtype=np.uint64)
+        outs = (_lib.Result * R)()
+        owner = np.zeros(1024, dtype=np.int32)
+        self._check(self.lib.hsk_count_loopback(self.h, R, PP, _p(nb), OP, LP, _p(nr), outs, _p(owner), owner.size))
+        nt = int(outs[0].ntasks)
+        res = [self._wrap(outs[r]) for r in range(R)]
+        return res, owner[:nt].copy()
+
     def stats(self, reset=True):
         s = _lib.Stats()
         self._check(self.lib.hsk_get_stats(self.h, C.byref(s), 1 if reset else 0))

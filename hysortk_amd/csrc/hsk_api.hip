@@ -728,6 +728,134 @@ static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
     return (u32)std::min<u64>(std::max<u64>(t, 1), HSK_MAX_TASKS);
 }
 
+// Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
+// result of this rank.  `segs[t]` lists where the supermers of task t live (x_len / x_src / x_pos / x_rid).
+template <int NW>
+static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owner, int rank, std::vector<TaskSegs> &segs,
+                        const u8 *x_len, const BaseSource &x_src, const u32 *x_pos, const int32_t *x_rid,
+                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open)
+{
+    const bool ext = c->cfg.extension != 0;
+    const int K = c->cfg.kmer_size;
+    u64 max_task = 0, total_kmers = 0;
+    for (u32 t = 0; t < ntasks; ++t) { finalize_segs(segs[t]); max_task = std::max(max_task, segs[t].nkmers); total_kmers += segs[t].nkmers; }
+    out->total_kmers = total_kmers;
+
+    // ---- per task: expand, sort, count ---------------------------------------------------------------
+    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
+    u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
+    HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
+    // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
+    // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
+    static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    std::vector<u32> mine;
+    for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
+    const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
+    const int nsets = batch ? XCD_BATCH : 1;
+    u64 *kA[XCD_BATCH] = {nullptr}, *kB[XCD_BATCH] = {nullptr}, *vA[XCD_BATCH] = {nullptr}, *vB[XCD_BATCH] = {nullptr};
+    SortScratch sc;
+    if (max_task) {
+        for (int i = 0; i < nsets; ++i) {
+            DALLOC(c, kA[i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kB[i], u64 *, max_task * NW * 8 + 64);
+            if (ext) { DALLOC(c, vA[i], u64 *, max_task * 8 + 64); DALLOC(c, vB[i], u64 *, max_task * 8 + 64); }
+        }
+        int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    }
+    std::vector<TaskOut> touts(ntasks);
+    u64 n_total = 0, pay_total = 0;
+    // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
+    std::vector<u64> pay_before(ntasks, 0);
+    { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
+    size_t pos = 0;
+    while (batch && pos + XCD_BATCH <= mine.size()) {
+        BatchTask bt[XCD_BATCH];
+        pt.begin(PH_EXTRACT);
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[pos + i];
+            bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
+            int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[i], vA[i]); if (rc) return rc;
+        }
+        pt.end(PH_EXTRACT);
+        pt.begin(PH_SORT);
+        { int rc = sort_batch_device<NW>(c, bt, K); if (rc) return rc; }
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[pos + i];
+            int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+        }
+        pt.end(PH_COUNT);
+        pos += XCD_BATCH;
+    }
+    for (; pos < mine.size(); ++pos) {
+        const u32 t = mine[pos];
+        const u64 n = segs[t].nkmers;
+        pt.begin(PH_EXTRACT);
+        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[0], vA[0]); if (rc) return rc;
+        pt.end(PH_EXTRACT);
+        pt.begin(PH_SORT);
+        u64 *sk, *sv;
+        rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+        pt.end(PH_COUNT);
+    }
+    for (u32 t : mine) { n_total += touts[t].n; pay_total += touts[t].npay; }
+    {
+        int rc = check_device_error(c); if (rc) return rc;
+    }
+    for (int i = 0; i < nsets; ++i) { c->pool.release(kA[i]); c->pool.release(kB[i]); c->pool.release(vA[i]); c->pool.release(vB[i]); }
+    free_sort_scratch(c, sc);
+
+    // ---- result ----------------------------------------------------------------------------------------
+    pt.begin(PH_D2H);
+    out->n = n_total;
+    out->task_off = (uint64_t *)host_alloc(rp, (size_t)(ntasks + 1) * 8);
+    out->histo = (uint64_t *)host_alloc(rp, (size_t)histo_len * 8);
+    out->histo_len = histo_len;
+    if (!out->task_off || !out->histo) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+    HIPCHK(c, hipMemcpyAsync(out->histo, d_histo, (size_t)histo_len * 8, hipMemcpyDeviceToHost, c->stream));
+    const bool keep = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
+    if (!keep) {
+        out->entries = (uint64_t *)host_alloc(rp, n_total * (NW + 1) * 8);
+        if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
+        if (ext) {
+            out->payload_off = (uint64_t *)host_alloc(rp, (n_total + 1) * 8);
+            out->pos = (uint32_t *)host_alloc(rp, pay_total * 4);
+            out->rid = (int32_t *)host_alloc(rp, pay_total * 4);
+            if (!out->payload_off || !out->pos || !out->rid) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+        }
+    }
+    u64 o = 0, po = 0;
+    for (u32 t = 0; t < ntasks; ++t) {
+        out->task_off[t] = o;
+        TaskOut &to = touts[t];
+        if (!keep) {
+            if (to.n) HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.n) HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.npay) {
+                HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(out->rid + po, to.rid, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
+        o += to.n; po += to.npay;
+    }
+    out->task_off[ntasks] = o;
+    pt.end(PH_D2H);
+    if (pt_total_open) pt.end(PH_TOTAL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ext && !keep) out->payload_off[n_total] = pay_total;
+    if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
+    else for (auto &to : touts) free_task_out(c, to);
+    c->pool.release(d_histo);
+    if (pt_total_open) out->ms_total = pt.collect(PH_TOTAL);
+    out->ms_parse = pt.collect(PH_PARSE); out->ms_exchange = pt.collect(PH_EXCH);
+    out->ms_extract = pt.collect(PH_EXTRACT); out->ms_sort = pt.collect(PH_SORT); out->ms_count = pt.collect(PH_COUNT);
+    out->ms_d2h = pt.collect(PH_D2H);
+    return HSK_OK;
+}
+
 template <int NW>
 static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
                         int64_t rid_base, hsk_result *out)
@@ -801,122 +929,82 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         }
     }
     pt.end(PH_EXCH);
-    u64 max_task = 0, total_kmers = 0;
-    for (u32 t = 0; t < ntasks; ++t) { finalize_segs(segs[t]); max_task = std::max(max_task, segs[t].nkmers); total_kmers += segs[t].nkmers; }
-    out->total_kmers = total_kmers;
-
-    // ---- per task: expand, sort, count ---------------------------------------------------------------
-    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
-    u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
-    HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
-    // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
-    // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
-    static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
-    std::vector<u32> mine;
-    for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
-    const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
-    const int nsets = batch ? XCD_BATCH : 1;
-    u64 *kA[XCD_BATCH] = {nullptr}, *kB[XCD_BATCH] = {nullptr}, *vA[XCD_BATCH] = {nullptr}, *vB[XCD_BATCH] = {nullptr};
-    SortScratch sc;
-    if (max_task) {
-        for (int i = 0; i < nsets; ++i) {
-            DALLOC(c, kA[i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kB[i], u64 *, max_task * NW * 8 + 64);
-            if (ext) { DALLOC(c, vA[i], u64 *, max_task * 8 + 64); DALLOC(c, vB[i], u64 *, max_task * 8 + 64); }
-        }
-        int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
-    }
-    std::vector<TaskOut> touts(ntasks);
-    u64 n_total = 0, pay_total = 0;
-    // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
-    std::vector<u64> pay_before(ntasks, 0);
-    { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
-    size_t pos = 0;
-    while (batch && pos + XCD_BATCH <= mine.size()) {
-        BatchTask bt[XCD_BATCH];
-        pt.begin(PH_EXTRACT);
-        for (int i = 0; i < XCD_BATCH; ++i) {
-            const u32 t = mine[pos + i];
-            bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
-            int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[i], vA[i]); if (rc) return rc;
-        }
-        pt.end(PH_EXTRACT);
-        pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K); if (rc) return rc; }
-        pt.end(PH_SORT);
-        pt.begin(PH_COUNT);
-        for (int i = 0; i < XCD_BATCH; ++i) {
-            const u32 t = mine[pos + i];
-            int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
-        }
-        pt.end(PH_COUNT);
-        pos += XCD_BATCH;
-    }
-    for (; pos < mine.size(); ++pos) {
-        const u32 t = mine[pos];
-        const u64 n = segs[t].nkmers;
-        pt.begin(PH_EXTRACT);
-        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[0], vA[0]); if (rc) return rc;
-        pt.end(PH_EXTRACT);
-        pt.begin(PH_SORT);
-        u64 *sk, *sv;
-        rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
-        pt.end(PH_SORT);
-        pt.begin(PH_COUNT);
-        rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
-        pt.end(PH_COUNT);
-    }
-    for (u32 t : mine) { n_total += touts[t].n; pay_total += touts[t].npay; }
-    {
-        int rc = check_device_error(c); if (rc) return rc;
-    }
-    for (int i = 0; i < nsets; ++i) { c->pool.release(kA[i]); c->pool.release(kB[i]); c->pool.release(vA[i]); c->pool.release(vB[i]); }
-    free_sort_scratch(c, sc);
+    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true);
     if (nranks > 1) xb.release(c->pool); else free_store(c, st);
+    return rc;
+}
 
-    // ---- result ----------------------------------------------------------------------------------------
-    pt.begin(PH_D2H);
-    out->n = n_total;
-    out->task_off = (uint64_t *)host_alloc(rp, (size_t)(ntasks + 1) * 8);
-    out->histo = (uint64_t *)host_alloc(rp, (size_t)histo_len * 8);
-    out->histo_len = histo_len;
-    if (!out->task_off || !out->histo) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
-    HIPCHK(c, hipMemcpyAsync(out->histo, d_histo, (size_t)histo_len * 8, hipMemcpyDeviceToHost, c->stream));
-    const bool keep = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
-    if (!keep) {
-        out->entries = (uint64_t *)host_alloc(rp, n_total * (NW + 1) * 8);
-        if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
+// ------------------------------------------------------------------------------------------------
+// virtual ranks on one GPU: the multi-GPU data path (probe, dispatch, owner-grouped parse, pack,
+// all-to-all-v plan, multi-segment expand) with device-to-device copies in place of RCCL send/recv.
+// This is how the exchange logic is exercised on a single-GPU box (tests/test_gpu_multirank.py).
+// ------------------------------------------------------------------------------------------------
+struct DevInput { u8 *packed = nullptr; u64 *roff = nullptr; u32 *rlen = nullptr; };
+
+template <int NW>
+static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed_bytes, const u64 *nreads, hsk_result *outs, int32_t *owner_out, u32 *ntasks_out)
+{
+    const bool ext = c->cfg.extension != 0;
+    u64 tot_bytes = 0; for (int r = 0; r < R; ++r) tot_bytes += packed_bytes[r];
+    const u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : auto_ntasks(c, tot_bytes / (u64)R + 1, R);
+    *ntasks_out = ntasks;
+    std::vector<int64_t> rid_base(R, 0);
+    for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
+    std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    // 1. probe task sizes on every rank, sum, dispatch
+    std::vector<u64> bytes(ntasks, 0);
+    for (int r = 0; r < R; ++r) {
+        SupermerStore probe;
+        int rc = parse_phase(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, order, probe); if (rc) return rc;
+        free_store(c, probe);
+        for (u32 t = 0; t < ntasks; ++t) bytes[t] += probe.task_tot[3 * t + 1] + probe.task_tot[3 * t] * (ext ? 9 : 1);
+    }
+    std::vector<int32_t> owner(ntasks, 0);
+    if (plan_dispatch(bytes.data(), (int)ntasks, R, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data()))
+        return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
+    if (owner_out) memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks);
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
+    // 2. owner-grouped parse + byte materialisation on every rank
+    std::vector<SupermerStore> st(R);
+    std::vector<u64> M((size_t)R * ntasks * 3, 0);
+    for (int r = 0; r < R; ++r) {
+        int rc = parse_phase(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, order, st[r]); if (rc) return rc;
+        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) return rc;
+        for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
+    }
+    // 3. the exchange: same plan as hsk_comm.h, copies instead of send/recv
+    std::vector<ExchangePlan> pl(R);
+    std::vector<std::vector<TaskSegs>> segs(R);
+    std::vector<ExchangeBuffers> xb(R);
+    for (int d = 0; d < R; ++d) {
+        plan_exchange(R, d, ntasks, owner, order, M, st[d].task_base, pl[d], segs[d]);
+        xb[d].len = (u8 *)c->pool.alloc(pl[d].recv_tot_sup + 64); xb[d].bytes = (u8 *)c->pool.alloc(pl[d].recv_tot_bytes + 64); xb[d].nbytes = pl[d].recv_tot_bytes;
+        if (ext) { xb[d].pos = (u32 *)c->pool.alloc(pl[d].recv_tot_sup * 4 + 64); xb[d].rid = (int32_t *)c->pool.alloc(pl[d].recv_tot_sup * 4 + 64); }
+        if (!xb[d].len || !xb[d].bytes || (ext && (!xb[d].pos || !xb[d].rid))) return fail(c, HSK_ERR_OOM, "exchange buffers");
+    }
+    for (int d = 0; d < R; ++d) for (int sidx = 0; sidx < R; ++sidx) {
+        const u64 n = pl[sidx].send_sup[d], nb = pl[sidx].send_bytes[d];
+        if (n != pl[d].recv_sup[sidx] || nb != pl[d].recv_bytes[sidx]) return fail(c, HSK_ERR_INTERNAL, "exchange plan mismatch %d->%d", sidx, d);
+        if (!n) continue;
+        HIPCHK(c, hipMemcpyAsync(xb[d].len + pl[d].recv_sup_off[sidx], st[sidx].sm_len + pl[sidx].send_sup_off[d], n, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(xb[d].bytes + pl[d].recv_byte_off[sidx], st[sidx].sm_bytes + pl[sidx].send_byte_off[d], nb, hipMemcpyDeviceToDevice, c->stream));
         if (ext) {
-            out->payload_off = (uint64_t *)host_alloc(rp, (n_total + 1) * 8);
-            out->pos = (uint32_t *)host_alloc(rp, pay_total * 4);
-            out->rid = (int32_t *)host_alloc(rp, pay_total * 4);
-            if (!out->payload_off || !out->pos || !out->rid) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+            HIPCHK(c, hipMemcpyAsync(xb[d].pos + pl[d].recv_sup_off[sidx], st[sidx].sm_pos + pl[sidx].send_sup_off[d], n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(xb[d].rid + pl[d].recv_sup_off[sidx], st[sidx].sm_rid + pl[sidx].send_sup_off[d], n * 4, hipMemcpyDeviceToDevice, c->stream));
         }
     }
-    u64 o = 0, po = 0;
-    for (u32 t = 0; t < ntasks; ++t) {
-        out->task_off[t] = o;
-        TaskOut &to = touts[t];
-        if (!keep) {
-            if (to.n) HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (ext && to.n) HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
-            if (ext && to.npay) {
-                HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipMemcpyAsync(out->rid + po, to.rid, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
-            }
-        }
-        o += to.n; po += to.npay;
-    }
-    out->task_off[ntasks] = o;
-    pt.end(PH_D2H);
-    pt.end(PH_TOTAL);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ext && !keep) out->payload_off[n_total] = pay_total;
-    if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
-    else for (auto &to : touts) free_task_out(c, to);
-    c->pool.release(d_histo);
-    out->ms_total = pt.collect(PH_TOTAL); out->ms_parse = pt.collect(PH_PARSE); out->ms_exchange = pt.collect(PH_EXCH);
-    out->ms_extract = pt.collect(PH_EXTRACT); out->ms_sort = pt.collect(PH_SORT); out->ms_count = pt.collect(PH_COUNT);
-    out->ms_d2h = pt.collect(PH_D2H);
+    for (int r = 0; r < R; ++r) free_store(c, st[r]);
+    // 4. every rank finishes its own tasks
+    for (int r = 0; r < R; ++r) {
+        memset(&outs[r], 0, sizeof(hsk_result));
+        ResultPriv *rp = new ResultPriv();
+        outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
+        PhaseTimer pt(c);
+        int rc = process_rank<NW>(c, ntasks, owner, r, segs[r], xb[r].len, source_from_bytes(xb[r].bytes, xb[r].nbytes), xb[r].pos, xb[r].rid, &outs[r], rp, pt, false);
+        xb[r].release(c->pool);
+        if (rc) return rc;
+    }
     return HSK_OK;
 }
 
@@ -946,7 +1034,6 @@ extern "C" void hsk_result_free(hsk_ctx *c, hsk_result *r)
 }
 
 // Uploads the DnaBuffer description; returns device arrays with nreads+1 offsets.
-struct DevInput { u8 *packed = nullptr; u64 *roff = nullptr; u32 *rlen = nullptr; };
 
 static int upload_input(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
                         uint64_t nreads, DevInput &d)
@@ -1005,6 +1092,32 @@ extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packe
     HIPCHK(c, hipMemcpyAsync(roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
     int rc = dispatch_pipeline(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, rid_base, out);
     c->pool.release(roff);
+    return rc;
+}
+
+extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *packed, const uint64_t *packed_bytes, const uint64_t *const *off,
+                                  const uint32_t *const *len, const uint64_t *nreads, hsk_result *outs, int32_t *owner_out, int32_t owner_capacity)
+{
+    if (!c || nranks < 1 || nranks > 64 || !packed || !packed_bytes || !off || !len || !nreads || !outs) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<DevInput> in(nranks);
+    int rc = HSK_OK;
+    for (int r = 0; r < nranks && rc == HSK_OK; ++r) {
+        rc = check_host_index(c, packed_bytes[r], off[r], len[r], nreads[r]);
+        if (rc == HSK_OK) rc = upload_input(c, packed[r], packed_bytes[r], off[r], len[r], nreads[r], in[r]);
+    }
+    u32 ntasks = 0;
+    std::vector<int32_t> owner(HSK_MAX_TASKS, 0);
+    if (rc == HSK_OK) {
+        switch (c->nw) {
+        case 1: rc = run_loopback<1>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        case 2: rc = run_loopback<2>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        default: rc = run_loopback<3>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        }
+    }
+    if (rc == HSK_OK && owner_out) { if ((u32)owner_capacity < ntasks) rc = HSK_ERR_INVALID_ARG; else memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks); }
+    for (auto &d : in) free_input(c, d);
+    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); for (int r = 0; r < nranks; ++r) hsk_result_free(c, &outs[r]); }
     return rc;
 }
 

@@ -140,6 +140,14 @@ int hsk_count_device(hsk_ctx *ctx, const void *d_packed, uint64_t packed_bytes,
                      const void *d_read_byte_off, const void *d_read_len, uint64_t nreads,
                      int64_t rid_base, hsk_result *out);
 
+/* Test/diagnostic entry: `nranks` VIRTUAL ranks on the one GPU of this ctx.  Runs the multi-GPU data path
+ * (task-size probe, dispatch, owner-grouped parse, byte packing, all-to-all-v plan, multi-segment extraction)
+ * with device-to-device copies in place of the RCCL send/recv; outs[r] is what rank r would return.
+ * owner_out (optional, capacity in entries) receives the task -> rank table. */
+int hsk_count_loopback(hsk_ctx *ctx, int nranks, const uint8_t *const *packed, const uint64_t *packed_bytes,
+                       const uint64_t *const *read_byte_off, const uint32_t *const *read_len, const uint64_t *nreads,
+                       hsk_result *outs, int32_t *owner_out, int32_t owner_capacity);
+
 void hsk_result_free(hsk_ctx *ctx, hsk_result *res);
 int  hsk_get_stats(hsk_ctx *ctx, hsk_stats *out, int reset);
 

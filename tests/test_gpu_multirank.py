@@ -1,0 +1,69 @@
+"""The multi-GPU data path on ONE GPU: virtual ranks (hsk_count_loopback) run probe -> dispatch ->
+owner-grouped parse -> byte packing -> all-to-all-v plan -> multi-segment extraction -> sort -> count,
+with device copies in place of RCCL.  Results must equal the reference's multi-rank outputs."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(H, seqs, R):
+    counts = H.plan_partition_reads([len(s) for s in seqs], R) if R > 1 else np.array([len(seqs)])
+    parts, first = [], 0
+    for r in range(R):
+        parts.append(seqs[first:first + int(counts[r])])
+        first += int(counts[r])
+    return parts
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_loopback_equals_reference_multirank(R):
+    import hysortk_amd as H
+    seqs = util.read_fasta(util.GOLDEN + "/reads_small.fa")
+    parts = _split(H, seqs, R)
+    ntasks = H.plan_tot_tasks(2, R)                                   # the golden runs used 2 threads per rank
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=ntasks) as c:
+        res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])
+    assert len(owner) == ntasks and set(owner.tolist()) == set(range(R))
+    lines = []
+    for r, kl in enumerate(res):
+        for t in range(ntasks):
+            a, b = int(kl.task_off[t]), int(kl.task_off[t + 1])
+            if owner[t] != r:
+                assert a == b                                       # a rank only returns the tasks it owns
+            else:
+                seg = kl.kmers[a:b, 0]
+                assert np.all(seg[1:] > seg[:-1])
+        lines += ["%s\t%d" % (s, int(c_)) for s, c_ in zip(kl.strings(), kl.cnt)]
+    gold = open(util.GOLDEN + "/count_k31_np%d.txt" % R).read().splitlines()
+    assert sorted(lines) == gold
+    histo = sum(np.pad(kl.histo, (0, 65536 - kl.histo.size)) for kl in res)
+    assert H.histogram_text(histo) == util.load_json("dispatch_k31_np%d.json" % R)["histogram"]
+
+
+@pytest.mark.parametrize("variant,R", [("k31ext", 2), ("k51", 4), ("k31", 8)])
+def test_loopback_vs_oracle_with_owner_table(variant, R):
+    """Per-rank lists equal the oracle restricted to the rank's tasks (incl. EXTENSION payload with global read ids)."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    from oracle import hsk_oracle as O
+    cfg = util.VARIANTS[variant]
+    seqs = synth.reads(60000, 150, 6000, 11)
+    parts = _split(H, seqs, R)
+    ntasks = 3 * R
+    with H.Context(K=cfg["k"], M=cfg["m"], L=2, U=50, EXT=cfg["ext"], ntasks=ntasks) as c:
+        res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])
+    packed, off, lens = O.pack_reads(seqs)
+    for r in range(R):
+        ores = O.count(packed, off, lens, k=cfg["k"], m=cfg["m"], L=2, U=50, ext=cfg["ext"], ntasks=ntasks, task_owner=owner, my_rank=r)
+        kl = res[r]
+        assert np.array_equal(kl.kmers, ores.keys), r
+        assert np.array_equal(kl.cnt, ores.cnt), r
+        assert np.array_equal(kl.task_off, ores.task_off), r
+        if cfg["ext"]:
+            for i in range(0, len(kl), 53):
+                pos, rid = kl.payload(i)
+                a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+                assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist()))
