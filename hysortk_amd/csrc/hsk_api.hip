@@ -440,6 +440,23 @@ static int make_pass_plan(int K, int nw, int rb, PassDesc *out)
     return np;
 }
 
+// Hybrid plan (one-word keys without payload): only the top 32 bits (16 bases) are ordered by global passes
+// (digits at bit 32, 40, 48, 56, least significant first); binsort_kernel finishes the low bits inside each
+// bin.  With 32 prefix bits two different k-mers of one task rarely share a bin, so nearly every bin is the
+// copies of ONE k-mer and passes through untouched; 24 bits left 40 % of the records in multi-key bins whose
+// in-LDS ordering (serial, LDS-latency bound) cost more than the fourth pass.
+constexpr int HYBRID_SHIFT = 32;
+static int make_hybrid_plan(PassDesc *out)
+{
+    out[0] = PassDesc{0, 32, 8}; out[1] = PassDesc{0, 40, 8}; out[2] = PassDesc{0, 48, 8}; out[3] = PassDesc{0, 56, 8};
+    return 4;
+}
+static bool hybrid_enabled()
+{
+    static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
+    return on;
+}
+
 struct SortScratch {
     u64 *ghist = nullptr;      // [MAX_PASSES][256]
     u64 *gbase = nullptr;      // [MAX_PASSES][256]
@@ -458,14 +475,15 @@ static void launch_onesweep(hsk_ctx *c, const SortArgs &a, u32 ntiles)
 // *out_keys / *out_vals point at whichever buffer holds the sorted data.
 template <int NW>
 static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 *valsB, u64 n, int K, SortScratch &sc,
-                            u64 **out_keys, u64 **out_vals)
+                            u64 **out_keys, u64 **out_vals, bool allow_hybrid = true)
 {
     *out_keys = keysA; *out_vals = valsA;
     if (n < 2) return HSK_OK;
     const bool has_val = valsA != nullptr;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const bool hybrid = allow_hybrid && NW == 1 && !has_val && hybrid_enabled();
     HistArgs h; memset(&h, 0, sizeof h);
-    h.keys = keysA; h.n = n; h.npass = make_pass_plan(K, NW, c->cfg.radix_bits, h.pass); h.ghist = sc.ghist;
+    h.keys = keysA; h.n = n; h.npass = hybrid ? make_hybrid_plan(h.pass) : make_pass_plan(K, NW, c->cfg.radix_bits, h.pass); h.ghist = sc.ghist;
     HIPCHK(c, hipMemsetAsync(sc.ghist, 0, (size_t)MAX_PASSES * 256 * 8, c->stream));
     const u32 hblocks = (u32)std::min<u64>((n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16), 2048);
     EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 1; hp.bytes = n * NW * 8; (void)hipEventRecord(hp.a, c->stream); }
@@ -481,7 +499,9 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         for (int d = 0; d < 256; ++d) { if (hh[p * 256 + d] == n) trivial = true; hb[p * 256 + d] = run; run += hh[p * 256 + d]; }
         if (!trivial) todo.push_back(p);
     }
-    if (todo.empty()) return HSK_OK;
+    if (todo.empty() && !hybrid) return HSK_OK;
+    u64 *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
+    if (!todo.empty()) {
     HIPCHK(c, hipMemcpyAsync(sc.gbase, hb, (size_t)h.npass * 256 * 8, hipMemcpyHostToDevice, c->stream));
     constexpr int TILE = SortTile<NW>::TILE;
     const u32 ntiles = (u32)((n + TILE - 1) / TILE);
@@ -495,7 +515,6 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
     }
     HIPCHK(c, hipMemsetAsync(sc.lookback, 0, need, c->stream));
     HIPCHK(c, hipMemsetAsync(sc.tickets, 0, MAX_PASSES * 4, c->stream));
-    u64 *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
     for (size_t i = 0; i < todo.size(); ++i) {
         const int p = todo[i];
         SortArgs a; memset(&a, 0, sizeof a);
@@ -512,9 +531,29 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         std::swap(kin, kout); std::swap(vin, vout);
     }
     HIPCHK(c, hipGetLastError());
+    }
+    if (hybrid) {
+        // order the low bits inside every prefix bin (one more streaming pass instead of five scatter passes)
+        u32 *d_flag = sc.tickets + 60;                         // spare word of the ticket block
+        HIPCHK(c, hipMemsetAsync(d_flag, 0, 4, c->stream));
+        BinSortArgs b; b.in = kin; b.out = kout; b.n = n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flag;
+        hipLaunchKernelGGL(binsort_kernel, dim3((u32)((n + BS_TILE - 1) / BS_TILE)), dim3(BS_THREADS), 0, c->stream, b);
+        HIPCHK(c, hipGetLastError());
+        std::swap(kin, kout);
+        u32 *hf = (u32 *)((char *)c->pinned + c->pinned_bytes - 192);
+        HIPCHK(c, hipMemcpyAsync(hf, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*hf) {                                             // a long bin with several keys: finish with the full-width passes
+            u64 *other = (kin == keysA) ? keysB : keysA;
+            return sort_task_device<NW>(c, kin, other, nullptr, nullptr, n, K, sc, out_keys, out_vals, false);
+        }
+    }
     *out_keys = kin; *out_vals = vin;
     return HSK_OK;
 }
+
+static int alloc_sort_scratch(hsk_ctx *c, SortScratch &sc);
+static void free_sort_scratch(hsk_ctx *c, SortScratch &sc);
 
 // ---- eight tasks at a time, one per XCD (onesweep_multi_kernel) -----------------------------------------
 struct BatchTask { u64 n = 0; u64 *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr; u64 *out_k = nullptr, *out_v = nullptr; };
@@ -535,11 +574,12 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
     u64 *d_ghist, *d_gbase; u32 *d_tickets;
     DALLOC(c, d_ghist, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
     DALLOC(c, d_gbase, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
-    DALLOC(c, d_tickets, u32 *, (size_t)XCD_BATCH * MAX_PASSES * 4 + 256);
+    DALLOC(c, d_tickets, u32 *, (size_t)XCD_BATCH * MAX_PASSES * 4 + 256);       // + 8 flag words behind the tickets
     HIPCHK(c, hipMemsetAsync(d_ghist, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4 + 64, c->stream));
     PassDesc plan[MAX_PASSES];
-    const int npass = make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+    const bool hybrid = NW == 1 && !has_val && hybrid_enabled();
+    const int npass = hybrid ? make_hybrid_plan(plan) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
     u64 ntot = 0; bool wide = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
         bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
@@ -570,12 +610,14 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
     }
     int rc = HSK_OK;
     void *d_lookback = nullptr;
+    u64 ntiles[XCD_BATCH];
+    for (int i = 0; i < XCD_BATCH; ++i) ntiles[i] = bt[i].n < 2 ? 0 : (bt[i].n + TILE - 1) / TILE;
+    std::vector<u32> tk((size_t)XCD_BATCH * MAX_PASSES + 64, 0);
     if (!todo.empty()) {
         HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
         const size_t lbw = wide ? 8 : 4;
         size_t lb_off[XCD_BATCH + 1]; lb_off[0] = 0;
-        u64 ntiles[XCD_BATCH];
-        for (int i = 0; i < XCD_BATCH; ++i) { ntiles[i] = bt[i].n < 2 ? 0 : (bt[i].n + TILE - 1) / TILE; lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * lbw; }
+        for (int i = 0; i < XCD_BATCH; ++i) lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * lbw;
         const size_t per_pass = lb_off[XCD_BATCH];
         u64 max_tiles = 0; for (int i = 0; i < XCD_BATCH; ++i) max_tiles = std::max(max_tiles, ntiles[i]);
         const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
@@ -603,13 +645,35 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
         }
         HIPCHK(c, hipGetLastError());
         for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = kin[i]; bt[i].out_v = vin[i]; }
-        // every XCD must have drained its task: ticket counters are >= tile counts
-        std::vector<u32> tk((size_t)XCD_BATCH * MAX_PASSES);
-        HIPCHK(c, hipMemcpyAsync(tk.data(), d_tickets, tk.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    u32 *d_flags = d_tickets + (size_t)XCD_BATCH * MAX_PASSES;          // [8] mixed-giant flags (zeroed with the tickets)
+    if (hybrid) {
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            if (bt[i].n < 2) continue;
+            u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+            BinSortArgs b; b.in = bt[i].out_k; b.out = other; b.n = bt[i].n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flags + i;
+            hipLaunchKernelGGL(binsort_kernel, dim3((u32)((bt[i].n + BS_TILE - 1) / BS_TILE)), dim3(BS_THREADS), 0, c->stream, b);
+            bt[i].out_k = other;
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    if (!todo.empty() || hybrid) {
+        // every XCD must have drained its task (ticket counters >= tile counts); hybrid: which tasks need the long way
+        HIPCHK(c, hipMemcpyAsync(tk.data(), d_tickets, ((size_t)XCD_BATCH * MAX_PASSES + XCD_BATCH) * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
             for (size_t j = 0; j < todo.size(); ++j)
                 if (tk[(size_t)i * MAX_PASSES + j] < ntiles[i]) { rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (pass %zu: %u of %llu tiles)", i, j, tk[(size_t)i * MAX_PASSES + j], (unsigned long long)ntiles[i]); break; }
+        if (hybrid && rc == HSK_OK) {
+            for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i) {
+                if (!tk[(size_t)XCD_BATCH * MAX_PASSES + i]) continue;
+                SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+                u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+                rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+                bt[i].out_k = sk;
+                free_sort_scratch(c, sc1);
+            }
+        }
     }
     c->pool.release(d_lookback); c->pool.release(d_ghist); c->pool.release(d_gbase); c->pool.release(d_tickets);
     return rc;

@@ -304,4 +304,137 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_multi_kernel(MultiSortA
     onesweep_tile<NW, HAS_VAL, LB, true>(m.t[xcc]);       // leaves at once when the XCD's task has no tile left
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Hybrid finish for one-word keys: after LSD passes over the TOP bits only (hi_shift..63) the array is
+// ordered by that prefix; equal keys share a prefix "bin", bins are short (a few tens of records at the
+// task sizes used), so the remaining low bits are ordered INSIDE each bin in LDS instead of by 5 more
+// global passes (16 B of HBM traffic per key each).  Every workgroup handles the records at ITS tile
+// positions; a record finds its bin [bs, be) with bit scans over a head mask (both directions, the tile
+// is staged with a halo on both sides) and its place by counting smaller / equal-and-earlier records of
+// the bin -- or keeps its place when the bin holds one distinct key (the common case: duplicates of one
+// k-mer), which a second mask decides without touching the records.  Bins longer than the halo ("giant")
+// are passed through unchanged; if any of them holds two different keys a flag is raised and the host
+// finishes that task with the ordinary full-width passes.  Out of place: every output slot is written once.
+// ------------------------------------------------------------------------------------------------------
+constexpr int BS_THREADS = 256;
+constexpr int BS_PPT = 8;
+constexpr int BS_TILE = BS_THREADS * BS_PPT;   // 2048 records per workgroup
+constexpr int BS_HALO = 512;                   // bins up to this length are ordered locally
+constexpr int BS_NL = BS_TILE + 2 * BS_HALO;   // staged records
+constexpr int BS_WORDS = BS_NL / 64;
+
+struct BinSortArgs { const u64 *in; u64 *out; u64 n; int hi_shift; u32 *mixed_giant; };
+
+__global__ __launch_bounds__(BS_THREADS) void binsort_kernel(BinSortArgs a)
+{
+    __shared__ u64 s_k[BS_NL + 1];             // [0] = record before the staged range
+    __shared__ u64 s_head[BS_WORDS + 1];       // bit q: record q starts a bin
+    __shared__ u64 s_diff[BS_WORDS + 1];       // bit q: record q differs (all 64 bits) from record q-1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * BS_TILE;
+    const u64 lo = base >= (u64)BS_HALO ? base - BS_HALO : 0;
+    u64 hi = base + BS_TILE + BS_HALO; if (hi > a.n) hi = a.n;
+    const u32 nl = (u32)(hi - lo);
+    const u32 t0 = (u32)(base - lo);
+    const u32 t1 = (u32)(((base + BS_TILE) < a.n ? (base + BS_TILE) : a.n) - lo);
+    for (u32 i = tid; i < nl + 1; i += BS_THREADS) {
+        const long long g = (long long)lo + (long long)i - 1;
+        s_k[i] = g >= 0 ? a.in[g] : 0;
+    }
+    __syncthreads();
+    for (u32 q0 = wave * 64; q0 < (u32)BS_NL; q0 += BS_THREADS) {           // masks over the whole staged range
+        const u32 q = q0 + lane;
+        bool h = false, d = false;
+        if (q < nl) {
+            const u64 k = s_k[q + 1], kp = s_k[q];
+            const bool first = (lo + q == 0);
+            h = first || ((k >> a.hi_shift) != (kp >> a.hi_shift));
+            d = first || (k != kp);
+        }
+        const u64 mh = __ballot(h), md = __ballot(d);
+        if (lane == 0) { s_head[q0 >> 6] = mh; s_diff[q0 >> 6] = md; }
+    }
+    __syncthreads();
+    const bool at_end = (hi == a.n);
+    // fast path: no record of the staged range differs from its predecessor inside a bin -> every bin that
+    // touches this tile holds one key -> the tile is already in order
+    {
+        __shared__ u32 s_any;
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (tid < BS_WORDS && (s_diff[tid] & ~s_head[tid]) != 0) s_any = 1;
+        __syncthreads();
+        if (s_any == 0) {
+#pragma unroll
+            for (int j = 0; j < BS_PPT; ++j) {
+                const u32 q = t0 + j * BS_THREADS + tid;
+                if (q < t1) a.out[lo + q] = s_k[q + 1];
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BS_PPT; ++j) {
+        const u32 q = t0 + j * BS_THREADS + tid;
+        if (q >= t1) continue;
+        const u64 ke = s_k[q + 1];
+        // bin start: last head at or before q
+        int bs = -1;
+        {
+            int w = (int)(q >> 6);
+            u64 m = s_head[w] & (((q & 63) == 63) ? ~0ULL : ((2ULL << (q & 63)) - 1));
+            while (m == 0 && w > 0) m = s_head[--w];
+            if (m) bs = w * 64 + 63 - __builtin_clzll(m);
+        }
+        // bin end: next head after q (or the end of the array)
+        int be = -1;
+        {
+            u32 w = q >> 6;
+            u64 m = s_head[w] & (((q & 63) == 63) ? 0ULL : (~0ULL << ((q & 63) + 1)));
+            while (m == 0 && ++w < (u32)BS_WORDS) m = s_head[w];
+            if (m && (w * 64 + (u32)__builtin_ctzll(m)) < nl) be = (int)(w * 64 + (u32)__builtin_ctzll(m));
+            else if (at_end) be = (int)nl;
+        }
+        u64 dst = lo + q;
+        if (bs < 0 || be < 0 || (be - bs) > BS_HALO) {
+            // giant bin: passed through; two different keys inside it -> the host must finish this task the long way
+            const bool is_head = (s_head[q >> 6] >> (q & 63)) & 1;
+            const bool differs = (s_diff[q >> 6] >> (q & 63)) & 1;
+            if (differs && !is_head) atomicOr(a.mixed_giant, 1u);
+        } else {
+            // one distinct key in the bin? (no "differs" bit strictly inside (bs, be))
+            bool uniform = true;
+            {
+                const u32 a0 = (u32)bs + 1, a1 = (u32)be;              // bits [a0, a1)
+                if (a0 < a1) {
+                    u32 w0 = a0 >> 6, w1 = (a1 - 1) >> 6;
+                    for (u32 w = w0; w <= w1 && uniform; ++w) {
+                        u64 m = s_diff[w];
+                        if (w == w0) m &= ~0ULL << (a0 & 63);
+                        if (w == w1 && ((a1 & 63) != 0)) m &= (1ULL << (a1 & 63)) - 1;
+                        if (m) uniform = false;
+                    }
+                }
+            }
+            if (!uniform) {
+                u32 less = 0, eqb = 0;
+                for (int f = bs; f < be; f += 4) {                     // 4 independent LDS reads per step (latency bound otherwise)
+                    u64 kf[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kf[u] = s_k[(f + u < be ? f + u : bs) + 1];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = f + u < be;
+                        less += (in && kf[u] < ke) ? 1u : 0u;
+                        eqb += (in && kf[u] == ke && f + u < (int)q) ? 1u : 0u;
+                    }
+                }
+                dst = lo + (u64)bs + less + eqb;
+            }
+        }
+        a.out[dst] = ke;
+    }
+}
+
 } // namespace hsk
