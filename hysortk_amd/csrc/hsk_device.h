@@ -128,25 +128,33 @@ __device__ __forceinline__ u64 bits64_bytes_clamped(const u64 *p8, u64 bit, u64 
     return (hi << s) | (lo >> (64 - s));
 }
 
-// ---- x % d for a runtime-constant 32-bit d without a 64-bit division --------------------------
-// (GetMinimizerOwner, kmerops.cpp:1044: hash % tot_tasks).  Lemire fastmod for 32-bit operands,
-// applied to the two halves of the 64-bit hash.
-struct FastMod { u64 M; u32 d; u32 r32; /* 2^32 mod d */ };
+// ---- hash % ntasks without a 64-bit division -------------------------------------------------------
+// (GetMinimizerOwner, reference src/kmerops.cpp:1044: hash % tot_tasks; must be the exact remainder).
+// For d <= 1024 the 64-bit value is folded 16 bits at a time:  x = a*2^48 + b*2^32 + c*2^16 + e  =>
+// x mod d = (a*(2^48 mod d) + b*(2^32 mod d) + c*(2^16 mod d) + e) mod d, the sum stays below 2^28, so
+// three full-rate 24-bit multiply-adds and ONE Barrett step (floor(2^32/d)) replace three 64-bit fastmods.
+struct FastMod { u32 d; u32 c16, c32, c48; u32 inv; };
 inline FastMod make_fastmod(u32 d)
 {
-    FastMod f; f.d = d; f.M = d > 1 ? (~0ULL / d + 1) : 0; f.r32 = d > 1 ? (u32)((1ULL << 32) % d) : 0; return f;
+    FastMod f; f.d = d;
+    f.c16 = d > 1 ? (u32)((1ULL << 16) % d) : 0; f.c32 = d > 1 ? (u32)((1ULL << 32) % d) : 0; f.c48 = d > 1 ? (u32)((1ULL << 48) % d) : 0;
+    f.inv = d > 1 ? (u32)((1ULL << 32) / d) : 0;
+    return f;
 }
-__device__ __forceinline__ u32 fastmod32(u32 a, const FastMod &f)
-{
-    u64 low = f.M * a;
-    return (u32)__umul64hi(low, f.d);
-}
-__device__ __forceinline__ u32 fastmod64(u64 x, const FastMod &f)
+__host__ __device__ __forceinline__ u32 fastmod64(u64 x, const FastMod &f)
 {
     if (f.d <= 1) return 0;
-    u32 hi = fastmod32((u32)(x >> 32), f), lo = fastmod32((u32)x, f);
-    u32 t = hi * f.r32 + lo;                    // < d*d + d <= 2^30 + 2^15: d <= HSK_MAX_TASKS (32768)
-    return fastmod32(t, f);
+    const u32 a = (u32)(x >> 48), b = (u32)(x >> 32) & 0xFFFFu, c = (u32)(x >> 16) & 0xFFFFu, e = (u32)x & 0xFFFFu;
+    const u32 t = a * f.c48 + b * f.c32 + c * f.c16 + e;            // < 3 * 2^16 * 2^10 + 2^16 < 2^28
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 q = __umulhi(t, f.inv);
+#else
+    const u32 q = (u32)(((u64)t * f.inv) >> 32);
+#endif
+    u32 r = t - q * f.d;                                             // Barrett: q is the quotient or one less
+    if (r >= f.d) r -= f.d;
+    if (r >= f.d) r -= f.d;
+    return r;
 }
 
 // ---- wave / block scans ------------------------------------------------------------------------

@@ -75,6 +75,41 @@ __device__ __forceinline__ u64 find_read(const u64 *roff, u64 lo, u64 hi, u64 b)
     return lo;
 }
 
+// Supermer runs of a tile from the per-position task ids in s_dest (0xFFFF = no k-mer starts there).
+// Lane t looks at positions t, t+256, ...: boundary(p) = invalid(p) | p % 128 == 0 | dest[p] != dest[p-1]
+// goes into a bit mask with wave ballots; a run that starts at p ends at the next boundary, found with a bit
+// scan over that mask (at most two words: runs never cross a multiple of 128).  runs[j] = k-mers in the
+// supermer starting at position j*256 + t, 0 if none starts there.  No serial walk over LDS.
+__device__ __forceinline__ void supermer_runs(const u16 *s_dest, u64 *s_bnd, u32 (&runs)[PARSE_PPT])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool start[PARSE_PPT];
+#pragma unroll
+    for (int j = 0; j < PARSE_PPT; ++j) {
+        const u32 p = j * PARSE_THREADS + tid;
+        const u16 d = s_dest[p];
+        const u16 dp = p ? s_dest[p - 1] : (u16)0xFFFF;
+        const bool bnd = (d == 0xFFFF) || ((p & (SUPERMER_CUT - 1)) == 0) || (d != dp);
+        start[j] = bnd && d != 0xFFFF;
+        const u64 m = __ballot(bnd);
+        if (lane == 0) s_bnd[j * 4 + wave] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PARSE_PPT; ++j) {
+        runs[j] = 0;
+        if (!start[j]) continue;
+        const u32 p = j * PARSE_THREADS + tid;
+        const u32 lim = (p | (SUPERMER_CUT - 1)) + 1;
+        const u32 w = p >> 6;
+        u64 m = ((p & 63) == 63) ? 0ULL : (s_bnd[w] & (~0ULL << ((p & 63) + 1)));
+        u32 nb = lim;
+        if (m) nb = w * 64 + (u32)__builtin_ctzll(m);
+        else if ((w & 1) == 0) { const u64 m2 = s_bnd[w + 1]; if (m2) nb = (w + 1) * 64 + (u32)__builtin_ctzll(m2); }
+        runs[j] = nb - p;
+    }
+}
+
 template <int MODE, bool EXT>
 __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
 {
@@ -84,6 +119,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
     __shared__ u64 s_rng[4];                 // r0, r1 (first / last read overlapping the tile), window base, fast-path flag
     __shared__ u64 s_roff[PARSE_RWIN];       // roff[rb + i]: the read index window of this tile (one coalesced load)
     __shared__ u32 s_rlen[PARSE_RWIN];
+    __shared__ u64 s_bnd[PARSE_TILE / 64];    // bit p: a supermer boundary lies before position p (start of a run or a gap)
     __shared__ u32 s_scan[12];               // [0..8) block-scan scratch, [8] records in this tile (48 B keeps the dynamic base 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // 16 B per task: COUNT {supermers<<40|k-mers, bytes}; EMIT {slot cursor, u32 tile count, u32 tile prefix}
 
@@ -201,19 +237,23 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                 rstart = a.roff[r] * 4; rend = rstart + a.rlen[r];
                 nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
             }
+            // tile-relative 32-bit positions from here on (64-bit compares per position are slow)
+            const int HUGE = 1 << 30;
+            auto rel = [&](u64 x) -> int { return x >= gbase + (u64)HUGE ? HUGE : (x < gbase ? ((gbase - x) >= (u64)HUGE ? -HUGE : -(int)(gbase - x)) : (int)(x - gbase)); };
+            int rend_r = rel(rend), nxt_r = rel(nxt);
+            const int total_r = rel(total_pos);
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
-                const u64 g = g0 + i;
-                while (g >= nxt) {
+                const int g = p0 + i;
+                while (g >= nxt_r) {
                     ++r; rstart = nxt;
                     if (fast) { const u32 j = (u32)(r - rb); rend = rstart + s_rlen[j]; nxt = (r + 1 < a.nreads) ? s_roff[j + 1] * 4 : ~0ULL; }
                     else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
+                    rend_r = rel(rend); nxt_r = rel(nxt);
                 }
-                const bool valid = (g < total_pos) && (g + K <= rend);
-                if (!cached) {
-                    const u32 d = fastmod64(mn[i], a.fm);
-                    s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
-                }
+                const bool valid = (g < total_r) && (g + K <= rend_r);
+                const u32 d = fastmod64(mn[i], a.fm);
+                s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
             }
         }
         if (cached) {                                   // 8 task ids = one 16-byte load per lane
@@ -232,17 +272,13 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
                 if (g < total_pos) { u16 d = s_dest[p0 + i]; a.dump_dest[g] = d == 0xFFFF ? -1 : (int32_t)d; }
             }
         } else if (MODE == PARSE_COUNT) {
+            u32 runs[PARSE_PPT];
+            supermer_runs(s_dest, s_bnd, runs);
 #pragma unroll
-            for (int i = 0; i < PARSE_PPT; ++i) {
-                const int p = p0 + i;
-                const u16 d = s_dest[p];
-                if (d == 0xFFFF) continue;
-                const bool start = ((p & (SUPERMER_CUT - 1)) == 0) || (s_dest[p - 1] != d);   // p==0 -> first clause
-                if (!start) continue;
-                const int lim = (p | (SUPERMER_CUT - 1)) + 1;
-                int q = p + 1;
-                while (q < lim && s_dest[q] == d) ++q;
-                const u32 nk = (u32)(q - p);
+            for (int j = 0; j < PARSE_PPT; ++j) {
+                if (!runs[j]) continue;
+                const u32 d = s_dest[j * PARSE_THREADS + tid];
+                const u32 nk = runs[j];
                 const u32 nb = (nk + K - 1 + 3) >> 2;
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);   // supermers << 40 | k-mers
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)nb);
@@ -258,19 +294,18 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
             for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_tcnt[t] = 0;
             __syncthreads();
             u32 rec[PARSE_PPT], rnk[PARSE_PPT];
+            {
+                u32 runs[PARSE_PPT];
+                supermer_runs(s_dest, s_bnd, runs);
 #pragma unroll
-            for (int i = 0; i < PARSE_PPT; ++i) {
-                const int p = p0 + i;
-                const u16 d = s_dest[p];
-                rec[i] = 0xFFFFFFFFu;
-                if (d == 0xFFFF) continue;
-                const bool start = ((p & (SUPERMER_CUT - 1)) == 0) || (s_dest[p - 1] != d);
-                if (!start) continue;
-                const int lim = (p | (SUPERMER_CUT - 1)) + 1;
-                int q = p + 1;
-                while (q < lim && s_dest[q] == d) ++q;
-                rec[i] = (u32)p | ((u32)(q - p - 1) << 11) | ((u32)d << 18);
-                rnk[i] = atomicAdd(&s_tcnt[d], 1u);
+                for (int j = 0; j < PARSE_PPT; ++j) {
+                    rec[j] = 0xFFFFFFFFu;
+                    if (!runs[j]) continue;
+                    const u32 p = j * PARSE_THREADS + tid;
+                    const u32 d = s_dest[p];
+                    rec[j] = p | ((runs[j] - 1) << 11) | (d << 18);
+                    rnk[j] = atomicAdd(&s_tcnt[d], 1u);
+                }
             }
             __syncthreads();
             {   // exclusive prefix of the per-task counts: 4 consecutive tasks per lane
