@@ -333,7 +333,8 @@ static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
     a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos;
     if (st.tot_sup) {
-        hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
                                     st.sm_gpos, st.tot_sup, d_roff, nreads, rid_base, st.sm_pos, st.sm_rid);
     }

@@ -111,7 +111,7 @@ __device__ __forceinline__ void supermer_runs(const u16 *s_dest, u64 *s_bnd, u32
 }
 
 template <int MODE, bool EXT>
-__global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
+__global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
     __shared__ u64 s_hash[PARSE_HMAX];
@@ -343,6 +343,79 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_kernel(ParseArgs a)
             const u64 pk = s_cur[2 * t];
             o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
         }
+    }
+}
+
+// EMIT when the task ids were kept by COUNT (dest_cache): nothing is hashed and no base is read, so this is a
+// separate lean kernel (14 KB of LDS, few registers -> twice the residency of parse_kernel; the tile loop is a
+// chain of short barrier-separated phases and lives on latency hiding).  Same tile -> workgroup mapping and
+// the same per-(workgroup, task) cursors as parse_kernel<PARSE_EMIT>.
+__global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u16 s_dest[PARSE_TILE + 8];
+    __shared__ u32 s_srt[PARSE_TILE];
+    __shared__ u64 s_bnd[PARSE_TILE / 64];
+    __shared__ u32 s_scan[12];
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];      // [ntasks] slot cursors, then u32 tile counts, u32 tile prefixes
+    const int tid = threadIdx.x;
+    const int K = a.k;
+    u32 *s_tcnt = reinterpret_cast<u32 *>(s_cur + a.ntasks);
+    u32 *s_tpre = s_tcnt + a.ntasks;
+    for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] = a.blk_base[((u64)blockIdx.x * a.ntasks + t) * 2];
+    __syncthreads();
+    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    uint4 nextv = make_uint4(0, 0, 0, 0);
+    if (tile0 < a.ntiles) nextv = *reinterpret_cast<const uint4 *>(a.dest_cache + tile0 * PARSE_TILE + tid * PARSE_PPT);
+    for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
+        const u64 tile = tile0 + ti;
+        if (tile >= a.ntiles) break;
+        const u64 gbase = tile * PARSE_TILE;
+        *reinterpret_cast<uint4 *>(&s_dest[tid * PARSE_PPT]) = nextv;
+        if (ti + 1 < a.tiles_per_block && tile + 1 < a.ntiles)               // prefetch the next tile's task ids
+            nextv = *reinterpret_cast<const uint4 *>(a.dest_cache + (gbase + PARSE_TILE) + tid * PARSE_PPT);
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_tcnt[t] = 0;
+        __syncthreads();
+        u32 rec[PARSE_PPT], rnk[PARSE_PPT];
+        {
+            u32 runs[PARSE_PPT];
+            supermer_runs(s_dest, s_bnd, runs);
+#pragma unroll
+            for (int j = 0; j < PARSE_PPT; ++j) {
+                rec[j] = 0xFFFFFFFFu;
+                if (!runs[j]) continue;
+                const u32 p = j * PARSE_THREADS + tid;
+                const u32 d = s_dest[p];
+                rec[j] = p | ((runs[j] - 1) << 11) | (d << 18);
+                rnk[j] = atomicAdd(&s_tcnt[d], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            u32 c4[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; c4[j] = t < a.ntasks ? s_tcnt[t] : 0; sum += c4[j]; }
+            u32 tot;
+            u32 e = block_excl_scan_256<u32>(sum, s_scan, &tot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; if (t < a.ntasks) s_tpre[t] = e; e += c4[j]; }
+            if (tid == 0) s_scan[8] = tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PARSE_PPT; ++i)
+            if (rec[i] != 0xFFFFFFFFu) s_srt[s_tpre[rec[i] >> 18] + rnk[i]] = rec[i];
+        __syncthreads();
+        const u32 nrec = s_scan[8];
+        for (u32 i = tid; i < nrec; i += PARSE_THREADS) {
+            const u32 r = s_srt[i];
+            const u32 d = r >> 18;
+            const u64 slot = s_cur[d] + (i - s_tpre[d]);
+            a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);
+            a.sm_gpos[slot] = gbase + (u64)(r & 2047);
+        }
+        __syncthreads();
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
+        __syncthreads();
     }
 }
 
