@@ -199,7 +199,7 @@ def main():
                 "K": K, "M": M, "L": L, "U": U, "EXT": a.ext, "ntasks": info["ntasks"], "scale": a.scale,
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "onesweep_kernel (radix scatter pass)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": int(st["scatter_launches"]),
                          "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch,
                          "hist_GBs": (st["hist_bytes"] / max(st["hist_ms"], 1e-9) / 1e6) if st["hist_ms"] else None},
