@@ -35,7 +35,8 @@ class Result(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("scatter_launches", C.c_uint64), ("scatter_keys", C.c_uint64), ("scatter_bytes", C.c_uint64), ("scatter_ms", C.c_double),
-        ("hist_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("hist_ms", C.c_double), ("reserved", C.c_int64 * 8),
+        ("hist_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("hist_ms", C.c_double),
+        ("fused_tasks", C.c_int64), ("redone_tasks", C.c_int64), ("reserved", C.c_int64 * 6),
     ]
 
 

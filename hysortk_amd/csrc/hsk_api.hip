@@ -29,6 +29,7 @@
 #include "hsk_expand.h"
 #include "hsk_sort.h"
 #include "hsk_count.h"
+#include "hsk_finish.h"
 #include "hsk_synth.h"
 #include "hsk_plan.h"
 #include "hsk_comm.h"
@@ -545,6 +546,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         HIPCHK(c, hipMemcpyAsync(hf, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*hf) {                                             // a long bin with several keys: finish with the full-width passes
+            c->stats.redone_tasks++;
             u64 *other = (kin == keysA) ? keysB : keysA;
             return sort_task_device<NW>(c, kin, other, nullptr, nullptr, n, K, sc, out_keys, out_vals, false);
         }
@@ -567,7 +569,7 @@ static void launch_onesweep_multi(hsk_ctx *c, const MultiSortArgs &m, u32 grid)
 }
 
 template <int NW>
-static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
+static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follows)
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const bool has_val = bt[0].vA != nullptr;
@@ -648,7 +650,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
         for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = kin[i]; bt[i].out_v = vin[i]; }
     }
     u32 *d_flags = d_tickets + (size_t)XCD_BATCH * MAX_PASSES;          // [8] mixed-giant flags (zeroed with the tickets)
-    if (hybrid) {
+    if (hybrid && !finish_follows) {
         for (int i = 0; i < XCD_BATCH; ++i) {
             if (bt[i].n < 2) continue;
             u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
@@ -665,9 +667,10 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K)
         for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
             for (size_t j = 0; j < todo.size(); ++j)
                 if (tk[(size_t)i * MAX_PASSES + j] < ntiles[i]) { rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (pass %zu: %u of %llu tiles)", i, j, tk[(size_t)i * MAX_PASSES + j], (unsigned long long)ntiles[i]); break; }
-        if (hybrid && rc == HSK_OK) {
+        if (hybrid && !finish_follows && rc == HSK_OK) {
             for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i) {
                 if (!tk[(size_t)XCD_BATCH * MAX_PASSES + i]) continue;
+                c->stats.redone_tasks++;
                 SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
                 u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
                 rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
@@ -793,6 +796,82 @@ static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
     return (u32)std::min<u64>(std::max<u64>(t, 1), HSK_MAX_TASKS);
 }
 
+// Fused finish of a batch (hybrid sort, one-word keys, no payload): one finish_multi_kernel launch turns the
+// prefix-ordered keys of eight tasks into their (k-mer, count) lists.  Tasks the kernel could not finish (a
+// long bin with several keys, see hsk_finish.h) are redone with the full-width passes and the two-pass counter.
+static bool finish_enabled()
+{
+    static const bool on = !(getenv("HSK_FUSED_FINISH") && atoi(getenv("HSK_FUSED_FINISH")) == 0);
+    return on;
+}
+
+template <int NW>
+static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    static_assert(NW == 1, "fused finish handles one-word keys");
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 cap_t = (u32)FN_NL / L + 1;                  // a tile keeps at most (2048 + 512) / L runs
+    u64 ntiles[XCD_BATCH], cnt_off[XCD_BATCH + 1]; cnt_off[0] = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) { ntiles[i] = (bt[i].n + FN_TILE - 1) / FN_TILE; cnt_off[i + 1] = cnt_off[i] + ntiles[i] + 1; }
+    // control block: [8] flags (u32), then per task the tile counts (+1 word for the total)
+    const size_t ctl_bytes = 64;
+    char *d_ctl = (char *)c->pool.alloc(ctl_bytes + cnt_off[XCD_BATCH] * 8 + 64);
+    if (!d_ctl) return fail(c, HSK_ERR_OOM, "finish control block");
+    HIPCHK(c, hipMemsetAsync(d_ctl, 0, ctl_bytes, c->stream));
+    u32 *d_flags = (u32 *)d_ctl; u64 *d_cnt = (u64 *)(d_ctl + ctl_bytes);
+    // scratch: the idle ping-pong buffer of the task when the per-tile slots fit into it (L >= 3), else its own block
+    u64 *scratch[XCD_BATCH] = {nullptr}; bool own_scratch[XCD_BATCH] = {false};
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        if (bt[i].n == 0) continue;
+        u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        const u64 need = ntiles[i] * (u64)cap_t * 16;
+        if (need <= max_task * 8) scratch[i] = other;
+        else { scratch[i] = (u64 *)c->pool.alloc(need + 64); own_scratch[i] = true; if (!scratch[i]) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)need); }
+        FinishArgs a; memset(&a, 0, sizeof a);
+        a.keys = bt[i].out_k; a.n = bt[i].n; a.scratch = scratch[i]; a.cap_t = cap_t; a.tile_cnt = d_cnt + cnt_off[i]; a.flags = d_flags + i;
+        a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.hi_shift = HYBRID_SHIFT;
+        hipLaunchKernelGGL(finish_kernel, dim3((u32)ntiles[i]), dim3(FN_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_cnt + cnt_off[i], ntiles[i], d_cnt + cnt_off[i] + ntiles[i]);
+    }
+    HIPCHK(c, hipGetLastError());
+    struct { u32 flags[8]; u64 total[8]; } h; memset(&h, 0, sizeof h);
+    HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < XCD_BATCH; ++i) if (bt[i].n) HIPCHK(c, hipMemcpyAsync(&h.total[i], d_cnt + cnt_off[i] + ntiles[i], 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    static int occ = 0;
+    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, finish_compact_kernel, FN_THREADS, 0) == hipSuccess && nb > 0) ? nb : 4; }
+    int rc = HSK_OK;
+    for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i) {
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        if (h.flags[i]) {
+            // the long way for this task: full-width passes from the current order, then the two-pass counter
+            c->stats.redone_tasks++;
+            if (own_scratch[i]) { c->pool.release(scratch[i]); scratch[i] = nullptr; own_scratch[i] = false; }
+            SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+            u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+            rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+            free_sort_scratch(c, sc1);
+            if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
+            continue;
+        }
+        c->stats.fused_tasks++;
+        outs[i].n = h.total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16);
+            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * 16)); break; }
+            const u32 grid = (u32)std::min<u64>((ntiles[i] + 3) / 4, (u64)occ * 256);
+            hipLaunchKernelGGL(finish_compact_kernel, dim3(grid), dim3(FN_THREADS), 0, c->stream, scratch[i], cap_t, d_cnt + cnt_off[i], ntiles[i],
+                               outs[i].entries, d_histo, histo_len);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
+    for (int i = 0; i < XCD_BATCH; ++i) if (own_scratch[i]) c->pool.release(scratch[i]);
+    c->pool.release(d_ctl);
+    return rc;
+}
+
 // Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
 // result of this rank.  `segs[t]` lists where the supermers of task t live (x_len / x_src / x_pos / x_rid).
 template <int NW>
@@ -841,13 +920,22 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[i], vA[i]); if (rc) return rc;
         }
         pt.end(PH_EXTRACT);
+        const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K); if (rc) return rc; }
+        { int rc = sort_batch_device<NW>(c, bt, K, fused); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
-        for (int i = 0; i < XCD_BATCH; ++i) {
-            const u32 t = mine[pos + i];
-            int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+        if (fused) {
+            if constexpr (NW == 1) {
+                TaskOut fo[XCD_BATCH];
+                int rc = finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo); if (rc) return rc;
+                for (int i = 0; i < XCD_BATCH; ++i) touts[mine[pos + i]] = fo[i];
+            }
+        } else {
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                const u32 t = mine[pos + i];
+                int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+            }
         }
         pt.end(PH_COUNT);
         pos += XCD_BATCH;

@@ -109,7 +109,9 @@ typedef struct {
     uint64_t hist_launches;
     uint64_t hist_bytes;
     double   hist_ms;
-    int64_t  reserved[8];
+    int64_t  fused_tasks;         /* tasks finished by the fused finish kernel (hybrid sort) */
+    int64_t  redone_tasks;        /* tasks the hybrid path had to redo with the full-width passes */
+    int64_t  reserved[6];
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -313,3 +313,60 @@ def test_large_properties(H):
         res2 = c.count_device(dp, nb, do, dl, NR)
         c.synth_free(dp, do, dl)
     assert np.array_equal(res.kmers, res2.kmers) and np.array_equal(res.cnt, res2.cnt)
+
+
+# ---------------------------------------------------------------------------------------------------
+# hybrid sort + fused finish (8 tasks per launch): bins with one key, several keys, giant bins
+# ---------------------------------------------------------------------------------------------------
+def _adversarial_reads(rng, wild):
+    g = "".join(rng.choice(list("ACGT"), 30000))
+    reads = []
+    for _ in range(4000):                                   # ordinary coverage: most bins hold one k-mer, 20x
+        p = int(rng.integers(0, len(g) - 150))
+        reads.append(g[p:p + 150])
+    pre = "ACGTTGCAAGGCTTAACCGG"                            # 20 fixed bases: k-mers starting here share their top 32 bits
+    groups = ((60, 3), (700, 2), (40000, 1)) if wild else ((60, 3), (700, 2))
+    for nvar, copies in groups:                             # bins with tens / hundreds / thousands of different keys per task
+        for v in range(nvar):
+            tail = "".join(rng.choice(list("ACGT"), 40))
+            reads += [pre + tail] * copies
+        pre = pre[1:] + "T"
+    reads += ["A" * 400] * 30                               # one k-mer ~11000 times: giant single-key bin
+    reads += ["AC" * 150] * 20                              # two k-mers thousands of times each
+    reads += [("ACGTACGTAGCTAGCTAGCTAGGATCGATCGATTAGC" * 5)[:150]] * 3000   # short tandem repeat, high counts
+    return reads
+
+
+@pytest.mark.parametrize("L,U,wild", [(1, 65535, True), (2, 50, True), (15, 40, False), (1, 3000, False)])
+def test_fused_finish_adversarial(H, O, L, U, wild):
+    rng = np.random.default_rng(77)
+    seqs = _adversarial_reads(rng, wild)
+    dna = H.DnaBuffer.from_sequences(seqs)
+    packed, off, lens = dna.arrays()
+    for ntasks in (8, 16):
+        ores = O.count(packed, off, lens, k=31, m=17, L=L, U=U, ntasks=ntasks, fast=True)
+        with H.Context(K=31, M=17, L=L, U=U, ntasks=ntasks) as c:
+            res = c.count(dna)
+            st = c.stats()
+        # the fused kernel and its fallback (a long bin with several keys) must both be exercised over the cases
+        assert st["fused_tasks"] + st["redone_tasks"] == ntasks, st
+        assert (st["redone_tasks"] > 0) if wild else (st["fused_tasks"] == ntasks), st
+        assert np.array_equal(res.task_off, ores.task_off), (L, U, ntasks)
+        assert np.array_equal(res.kmers, ores.keys), (L, U, ntasks)
+        assert np.array_equal(res.cnt, ores.cnt), (L, U, ntasks)
+        assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+
+
+def test_fused_finish_equals_two_pass_path(H):
+    """Same input through HSK_FUSED_FINISH=0/1 and HSK_HYBRID=0 (subprocesses: the switches are read once)."""
+    import subprocess, sys, os, json
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "c = H.Context(K=31, M=17, L=2, U=60, ntasks=16)\n"
+            "dp, nb, do, dl = c.synth_reads(3000000, 150, 400000, 5)\n"
+            "r = c.count_device(dp, nb, do, dl, 400000)\n"
+            "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
+    outs = []
+    for env in ({"HSK_FUSED_FINISH": "1"}, {"HSK_FUSED_FINISH": "0"}, {"HSK_HYBRID": "0"}, {"HSK_XCD_BATCH": "0"}):
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
+    assert len({o[0] for o in outs}) == 1, outs
+    assert int(outs[0][1]) > 100000
