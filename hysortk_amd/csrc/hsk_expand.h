@@ -18,6 +18,7 @@ namespace hsk {
 constexpr int EXP_THREADS = 256;
 constexpr int EXP_SPT = 8;
 constexpr int EXP_TILE = EXP_THREADS * EXP_SPT;   // supermers per tile
+constexpr int EXP_CHUNK = 2048;                   // output slots produced per step inside a tile
 
 struct ExpSeg {
     u64 sup_off;     // first supermer slot (index into sm_len / sm_pos / sm_rid)
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
     __shared__ u32 s_boff[EXP_TILE + 1];
     __shared__ u32 s_koff[EXP_TILE + 1];
     __shared__ u32 s_scr[8];
+    __shared__ u64 s_mask[EXP_CHUNK / 64];
+    __shared__ u32 s_wpre[EXP_CHUNK / 64];
     const u64 tile = blockIdx.x;
     const int sg = seg_of_tile(segs, nseg, tile);
     const ExpSeg seg = segs[sg];
@@ -129,29 +132,57 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
     const u64 kbase = tile_off[2 * tile + 1];
     const u64 lastmask = ~0ULL << (64 * NW - 2 * k);      // 0 < 64*NW - 2k < 64 (k % 32 != 0)
 
-    for (u32 j = tid; j < totk; j += EXP_THREADS) {
-        // largest s with koff[s] <= j  (supermers have >= 1 k-mer, so koff is strictly increasing over [0, ns))
-        u32 lo = 0, hi = ns - 1;
-        while (lo < hi) {
-            u32 mid = (lo + hi + 1) >> 1;
-            if (s_koff[mid] <= j) lo = mid; else hi = mid - 1;
+    // The tile's k-mers are produced in chunks of 2048 consecutive output slots.  Which supermer a slot belongs to
+    // is NOT searched per k-mer: the supermers that start inside the chunk set one bit each in a 2048-bit mask, and
+    // slot j belongs to supermer  S0 + popcount(mask bits <= j) - 1  (S0 = supermers starting before the chunk: one
+    // search per chunk).  Lane t handles slots t, t+256, ...: consecutive lanes write consecutive records.
+    const int lane = tid & 63;
+    for (u32 c0 = 0; c0 < totk; c0 += EXP_CHUNK) {
+        const u32 c1 = (c0 + EXP_CHUNK < totk) ? c0 + EXP_CHUNK : totk;
+        // supermers starting in [c0, c1): a contiguous index range [sa, sb)
+        u32 sa, sb;
+        { u32 lo = 0, hi = ns; while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_koff[mid] < c0) lo = mid + 1; else hi = mid; } sa = lo; }
+        { u32 lo = sa, hi = ns; while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_koff[mid] < c1) lo = mid + 1; else hi = mid; } sb = lo; }
+        if (tid < EXP_CHUNK / 64) s_mask[tid] = 0;
+        __syncthreads();
+        for (u32 sidx = sa + tid; sidx < sb; sidx += EXP_THREADS) {
+            const u32 b = s_koff[sidx] - c0;
+            atomicOr((unsigned long long *)&s_mask[b >> 6], 1ULL << (b & 63));
         }
-        const u32 i = j - s_koff[lo];
-        const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[seg.sup_off + first + lo] + (u64)i))
-                                : (8 * (byte_abs + s_boff[lo]) + 2 * (u64)i);
-        Mer<NW> mer;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mer.w[w] = bits64_bytes_clamped(src8, bit + 64 * w, src_words);
-        mer.w[NW - 1] &= lastmask;
-        Mer<NW> c = canonical<NW>(mer, k);
-        const u64 o = kbase + j;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) keys_out[o * NW + w] = c.w[w];
-        if (EXT) {
-            const u64 sa = seg.sup_off + first + lo;
-            vals_out[o] = (u64)(sm_pos[sa] + i) | ((u64)(u32)sm_rid[sa] << 32);
+        __syncthreads();
+        if (tid < 64) {
+            const u32 v = tid < EXP_CHUNK / 64 ? (u32)__popcll(s_mask[tid]) : 0;
+            const u32 inc = wave_incl_scan<u32>(v);
+            if (tid < EXP_CHUNK / 64) s_wpre[tid] = inc - v;
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EXP_CHUNK / EXP_THREADS; ++r) {
+            const u32 j = c0 + r * EXP_THREADS + tid;
+            if (j >= c1) continue;
+            const u32 b = j - c0;
+            const u32 w = b >> 6;
+            const u64 below = ((b & 63) == 63) ? ~0ULL : ((2ULL << (b & 63)) - 1);
+            const u32 sidx = sa + s_wpre[w] + (u32)__popcll(s_mask[w] & below) - 1;   // sa > 0 when the chunk starts inside a supermer, so this never underflows
+            const u32 i = j - s_koff[sidx];
+            const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[seg.sup_off + first + sidx] + (u64)i))
+                                    : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i);
+            Mer<NW> mer;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) mer.w[w2] = bits64_bytes_clamped(src8, bit + 64 * w2, src_words);
+            mer.w[NW - 1] &= lastmask;
+            Mer<NW> cm = canonical<NW>(mer, k);
+            const u64 o = kbase + j;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) keys_out[o * NW + w2] = cm.w[w2];
+            if (EXT) {
+                const u64 sa_abs = seg.sup_off + first + sidx;
+                vals_out[o] = (u64)(sm_pos[sa_abs] + i) | ((u64)(u32)sm_rid[sa_abs] << 32);
+            }
+        }
+        __syncthreads();
     }
+    (void)lane;
 }
 
 // Multi-GPU only: materialise the re-aligned byte stream of reference-mode supermers for the
