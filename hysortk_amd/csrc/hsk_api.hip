@@ -483,7 +483,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
     if (n < 2) return HSK_OK;
     const bool has_val = valsA != nullptr;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
-    const bool hybrid = allow_hybrid && NW == 1 && !has_val && hybrid_enabled();
+    const bool hybrid = allow_hybrid && NW == 1 && hybrid_enabled();
     HistArgs h; memset(&h, 0, sizeof h);
     h.keys = keysA; h.n = n; h.npass = hybrid ? make_hybrid_plan(h.pass) : make_pass_plan(K, NW, c->cfg.radix_bits, h.pass); h.ghist = sc.ghist;
     HIPCHK(c, hipMemsetAsync(sc.ghist, 0, (size_t)MAX_PASSES * 256 * 8, c->stream));
@@ -538,17 +538,18 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         // order the low bits inside every prefix bin (one more streaming pass instead of five scatter passes)
         u32 *d_flag = sc.tickets + 60;                         // spare word of the ticket block
         HIPCHK(c, hipMemsetAsync(d_flag, 0, 4, c->stream));
-        BinSortArgs b; b.in = kin; b.out = kout; b.n = n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flag;
+        BinSortArgs b; b.in = kin; b.out = kout; b.vin = vin; b.vout = vout; b.n = n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flag;
         hipLaunchKernelGGL(binsort_kernel, dim3((u32)((n + BS_TILE - 1) / BS_TILE)), dim3(BS_THREADS), 0, c->stream, b);
         HIPCHK(c, hipGetLastError());
-        std::swap(kin, kout);
+        std::swap(kin, kout); std::swap(vin, vout);
         u32 *hf = (u32 *)((char *)c->pinned + c->pinned_bytes - 192);
         HIPCHK(c, hipMemcpyAsync(hf, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*hf) {                                             // a long bin with several keys: finish with the full-width passes
             c->stats.redone_tasks++;
             u64 *other = (kin == keysA) ? keysB : keysA;
-            return sort_task_device<NW>(c, kin, other, nullptr, nullptr, n, K, sc, out_keys, out_vals, false);
+            u64 *vother = has_val ? ((vin == valsA) ? valsB : valsA) : nullptr;
+            return sort_task_device<NW>(c, kin, other, vin, vother, n, K, sc, out_keys, out_vals, false);
         }
     }
     *out_keys = kin; *out_vals = vin;
@@ -581,7 +582,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     HIPCHK(c, hipMemsetAsync(d_ghist, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4 + 64, c->stream));
     PassDesc plan[MAX_PASSES];
-    const bool hybrid = NW == 1 && !has_val && hybrid_enabled();
+    const bool hybrid = NW == 1 && hybrid_enabled();
     const int npass = hybrid ? make_hybrid_plan(plan) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
     u64 ntot = 0; bool wide = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
@@ -654,9 +655,10 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
         for (int i = 0; i < XCD_BATCH; ++i) {
             if (bt[i].n < 2) continue;
             u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
-            BinSortArgs b; b.in = bt[i].out_k; b.out = other; b.n = bt[i].n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flags + i;
+            u64 *vother = has_val ? ((bt[i].out_v == bt[i].vA) ? bt[i].vB : bt[i].vA) : nullptr;
+            BinSortArgs b; b.in = bt[i].out_k; b.out = other; b.vin = bt[i].out_v; b.vout = vother; b.n = bt[i].n; b.hi_shift = HYBRID_SHIFT; b.mixed_giant = d_flags + i;
             hipLaunchKernelGGL(binsort_kernel, dim3((u32)((bt[i].n + BS_TILE - 1) / BS_TILE)), dim3(BS_THREADS), 0, c->stream, b);
-            bt[i].out_k = other;
+            bt[i].out_k = other; bt[i].out_v = vother;
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -673,8 +675,9 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
                 c->stats.redone_tasks++;
                 SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
                 u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
-                rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
-                bt[i].out_k = sk;
+                u64 *vcur = bt[i].out_v, *vother = has_val ? ((vcur == bt[i].vA) ? bt[i].vB : bt[i].vA) : nullptr;
+                rc = sort_task_device<NW>(c, cur, other, vcur, vother, bt[i].n, K, sc1, &sk, &sv, false);
+                bt[i].out_k = sk; bt[i].out_v = sv;
                 free_sort_scratch(c, sc1);
             }
         }

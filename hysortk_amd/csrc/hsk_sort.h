@@ -324,7 +324,7 @@ constexpr int BS_HALO = 512;                   // bins up to this length are ord
 constexpr int BS_NL = BS_TILE + 2 * BS_HALO;   // staged records
 constexpr int BS_WORDS = BS_NL / 64;
 
-struct BinSortArgs { const u64 *in; u64 *out; u64 n; int hi_shift; u32 *mixed_giant; };
+struct BinSortArgs { const u64 *in; u64 *out; const u64 *vin; u64 *vout; u64 n; int hi_shift; u32 *mixed_giant; };   // vin/vout: optional payload
 
 __global__ __launch_bounds__(BS_THREADS) void binsort_kernel(BinSortArgs a)
 {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(BS_THREADS) void binsort_kernel(BinSortArgs a)
 #pragma unroll
             for (int j = 0; j < BS_PPT; ++j) {
                 const u32 q = t0 + j * BS_THREADS + tid;
-                if (q < t1) a.out[lo + q] = s_k[q + 1];
+                if (q < t1) { a.out[lo + q] = s_k[q + 1]; if (a.vin) a.vout[lo + q] = a.vin[lo + q]; }
             }
             return;
         }
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(BS_THREADS) void binsort_kernel(BinSortArgs a)
             }
         }
         a.out[dst] = ke;
+        if (a.vin) a.vout[dst] = a.vin[lo + q];          // the payload follows its record (equal keys keep their order: eqb)
     }
 }
 
