@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdint.h>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -141,31 +142,38 @@ struct ExchangePlan {
     uint64_t recv_tot_sup = 0, recv_tot_bytes = 0;
 };
 
+// group_of / g: restrict the plan to the tasks t with (*group_of)[t] == g (the exchange proceeds in groups of
+// tasks so that the transfer of group g+1 overlaps the sort of group g); group_of == nullptr plans everything.
+// A rank's tasks are stored grouped by owner in ascending id, and groups are consecutive runs of an owner's
+// tasks, so a (peer, group) share is still one contiguous range of the send arrays.
 inline void plan_exchange(int nranks, int rank, uint32_t ntasks, const std::vector<int32_t> &owner, const std::vector<uint32_t> &order,
                           const std::vector<uint64_t> &M /* [nranks][ntasks][3] */, const std::vector<uint64_t> &task_base /* mine [ntasks][3] */,
-                          ExchangePlan &pl, std::vector<TaskSegs> &segs)
+                          ExchangePlan &pl, std::vector<TaskSegs> &segs, const std::vector<int32_t> *group_of = nullptr, int g = -1)
 {
+    auto in_group = [&](uint32_t t) { return group_of == nullptr || (*group_of)[t] == g; };
     pl.send_sup.assign(nranks, 0); pl.send_bytes.assign(nranks, 0); pl.send_sup_off.assign(nranks, 0); pl.send_byte_off.assign(nranks, 0);
     pl.recv_sup.assign(nranks, 0); pl.recv_bytes.assign(nranks, 0); pl.recv_sup_off.assign(nranks, 0); pl.recv_byte_off.assign(nranks, 0);
     const uint64_t *mine = &M[(size_t)rank * ntasks * 3];
     std::vector<char> seen(nranks, 0);
     for (uint32_t i = 0; i < ntasks; ++i) {                 // storage order: grouped by owner
         const uint32_t t = order[i]; const int q = owner[t];
+        if (!in_group(t)) continue;
         if (!seen[q]) { seen[q] = 1; pl.send_sup_off[q] = task_base[3 * t]; pl.send_byte_off[q] = task_base[3 * t + 1]; }
         pl.send_sup[q] += mine[3 * t]; pl.send_bytes[q] += mine[3 * t + 1];
     }
     uint64_t so = 0, bo = 0;
     for (int p = 0; p < nranks; ++p) {
         pl.recv_sup_off[p] = so; pl.recv_byte_off[p] = bo;
-        for (uint32_t t = 0; t < ntasks; ++t) if (owner[t] == rank) { pl.recv_sup[p] += M[((size_t)p * ntasks + t) * 3]; pl.recv_bytes[p] += M[((size_t)p * ntasks + t) * 3 + 1]; }
+        for (uint32_t t = 0; t < ntasks; ++t) if (owner[t] == rank && in_group(t)) { pl.recv_sup[p] += M[((size_t)p * ntasks + t) * 3]; pl.recv_bytes[p] += M[((size_t)p * ntasks + t) * 3 + 1]; }
         so += pl.recv_sup[p]; bo += pl.recv_bytes[p];
     }
     pl.recv_tot_sup = so; pl.recv_tot_bytes = bo;
-    segs.assign(ntasks, TaskSegs());
+    if (group_of == nullptr) segs.assign(ntasks, TaskSegs());
     std::vector<uint64_t> cs(nranks), cb(nranks);
     for (int p = 0; p < nranks; ++p) { cs[p] = pl.recv_sup_off[p]; cb[p] = pl.recv_byte_off[p]; }
     for (uint32_t t = 0; t < ntasks; ++t) {
-        if (owner[t] != rank) continue;
+        if (owner[t] != rank || !in_group(t)) continue;
+        segs[t] = TaskSegs();
         uint64_t koff = 0;
         for (int p = 0; p < nranks; ++p) {
             const uint64_t *m = &M[((size_t)p * ntasks + t) * 3];
@@ -176,25 +184,20 @@ inline void plan_exchange(int nranks, int rank, uint32_t ntasks, const std::vect
     }
 }
 
-template <typename Pool>
-inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int /*K*/, uint32_t ntasks, const std::vector<int32_t> &owner,
-                              const std::vector<uint32_t> &order, const std::vector<uint64_t> &task_tot, const std::vector<uint64_t> &task_base,
-                              const uint8_t *sm_len, const uint8_t *sm_bytes, const uint32_t *sm_pos, const int32_t *sm_rid,
-                              ExchangeBuffers &xb, std::vector<TaskSegs> &segs)
+// group index of every task inside its owner's ascending task list (groups of `group_size` tasks)
+inline void assign_task_groups(int nranks, uint32_t ntasks, const std::vector<int32_t> &owner, int group_size, std::vector<int32_t> &group_of, int &ngroups)
+{
+    std::vector<int> seen(nranks, 0);
+    group_of.assign(ntasks, 0); ngroups = 0;
+    for (uint32_t t = 0; t < ntasks; ++t) { const int q = owner[t]; group_of[t] = seen[q] / group_size; ++seen[q]; ngroups = std::max(ngroups, group_of[t] + 1); }
+}
+
+// the grouped send/recv of one plan on stream s (self share: device copy).  Does not synchronise.
+inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &pl, const uint8_t *sm_len, const uint8_t *sm_bytes,
+                         const uint32_t *sm_pos, const int32_t *sm_rid, ExchangeBuffers &xb)
 {
     const int nr = cm.nranks, me = cm.rank;
-    // 1. size matrix: every rank contributes its row, the sum is the full matrix
-    std::vector<uint64_t> M((size_t)nr * ntasks * 3, 0);
-    for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)me * ntasks * 3 + i] = task_tot[i];
-    int rc = cm.allreduce_sum_u64(M.data(), M.size(), s, pool);
-    if (rc) return rc;
-    ExchangePlan pl;
-    plan_exchange(nr, me, ntasks, owner, order, M, task_base, pl, segs);
-    xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);
-    xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64); xb.nbytes = pl.recv_tot_bytes;
-    if (ext) { xb.pos = (uint32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); xb.rid = (int32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); }
-    if (!xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid))) { cm.last_error = "oom"; return -1; }
-    // 2. payload: one grouped send/recv per peer and array (self: device copy)
+    int rc;
     if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return rc;
     for (int q = 0; q < nr; ++q) {
         if (q == me) continue;
@@ -224,6 +227,29 @@ inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int
             if (hipMemcpyAsync(xb.rid + pl.recv_sup_off[me], sm_rid + pl.send_sup_off[me], pl.send_sup[me] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
         }
     }
+    return 0;
+}
+
+template <typename Pool>
+inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int /*K*/, uint32_t ntasks, const std::vector<int32_t> &owner,
+                              const std::vector<uint32_t> &order, const std::vector<uint64_t> &task_tot, const std::vector<uint64_t> &task_base,
+                              const uint8_t *sm_len, const uint8_t *sm_bytes, const uint32_t *sm_pos, const int32_t *sm_rid,
+                              ExchangeBuffers &xb, std::vector<TaskSegs> &segs)
+{
+    const int nr = cm.nranks, me = cm.rank;
+    // 1. size matrix: every rank contributes its row, the sum is the full matrix
+    std::vector<uint64_t> M((size_t)nr * ntasks * 3, 0);
+    for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)me * ntasks * 3 + i] = task_tot[i];
+    int rc = cm.allreduce_sum_u64(M.data(), M.size(), s, pool);
+    if (rc) return rc;
+    ExchangePlan pl;
+    plan_exchange(nr, me, ntasks, owner, order, M, task_base, pl, segs);
+    xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);
+    xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64); xb.nbytes = pl.recv_tot_bytes;
+    if (ext) { xb.pos = (uint32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); xb.rid = (int32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); }
+    if (!xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid))) { cm.last_error = "oom"; return -1; }
+    // 2. payload: one grouped send/recv per peer and array (self: device copy)
+    if ((rc = post_exchange(cm, s, ext, pl, sm_len, sm_bytes, sm_pos, sm_rid, xb))) return rc;
     if (hipStreamSynchronize(s) != hipSuccess) return -2;
     return 0;
 }
