@@ -875,12 +875,120 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exchange / sort overlap (multi-GPU).  The owned tasks of every rank are cut into groups of
+// XCD_BATCH consecutive tasks; group g+1 travels on `comm_stream` (RCCL send/recv, or device copies
+// between the virtual ranks of the loopback driver) while group g is expanded, sorted and counted on
+// the main stream.  The reference overlaps the same way with BATCH-sized MPI_Ialltoallv rounds
+// (src/kmerops.cpp:130-196, exchange_supermer's stage loop); here the unit is a task group so that a
+// sort batch never waits for bytes it does not need.  HSK_OVERLAP=0 selects one exchange up front.
+// ------------------------------------------------------------------------------------------------
+struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; };
+
+struct GroupFeeder {
+    hsk_ctx *c = nullptr;
+    int nranks = 1, rank = 0, ngroups = 0;
+    bool ext = false;
+    std::vector<int32_t> group_of;                     // task -> group inside its owner's task list
+    std::vector<ExchangePlan> pl;                      // [group] this rank's plan
+    std::vector<ExchangeBuffers> xb;                   // [group] receive arrays, alive from post to release
+    std::vector<hipEvent_t> arrived;                   // [group] recorded on comm_stream after the transfer
+    int posted = 0, released = 0;
+    // transport: RCCL (store of this rank) or loopback (stores and plans of all virtual ranks)
+    const SupermerStore *st = nullptr;
+    const std::vector<SupermerStore> *st_all = nullptr;
+    const std::vector<std::vector<ExchangePlan>> *pl_all = nullptr;     // [rank][group]
+    u64 bytes_moved = 0;
+
+    int plan(hsk_ctx *c_, int nranks_, int rank_, u32 ntasks, const std::vector<int32_t> &owner, const std::vector<u32> &order,
+             const std::vector<u64> &M, const std::vector<u64> &task_base, std::vector<TaskSegs> &segs)
+    {
+        c = c_; nranks = nranks_; rank = rank_; ext = c->cfg.extension != 0;
+        assign_task_groups(nranks, ntasks, owner, XCD_BATCH, group_of, ngroups);
+        pl.resize(ngroups); xb.resize(ngroups); arrived.assign(ngroups, nullptr);
+        segs.assign(ntasks, TaskSegs());
+        for (int g = 0; g < ngroups; ++g) plan_exchange(nranks, rank, ntasks, owner, order, M, task_base, pl[g], segs, &group_of, g);
+        return HSK_OK;
+    }
+    int post(int g)
+    {
+        ExchangeBuffers &b = xb[g]; const ExchangePlan &p = pl[g];
+        b.len = (u8 *)c->pool.alloc(p.recv_tot_sup + 64); b.bytes = (u8 *)c->pool.alloc(p.recv_tot_bytes + 64); b.nbytes = p.recv_tot_bytes;
+        if (ext) { b.pos = (u32 *)c->pool.alloc(p.recv_tot_sup * 4 + 64); b.rid = (int32_t *)c->pool.alloc(p.recv_tot_sup * 4 + 64); }
+        if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid))) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
+        // the pool hands out blocks whose previous user may still be running on the main stream: order the
+        // transfer after everything launched there so far (that is the work of group g-2 and earlier)
+        hipEvent_t fence = ev_get(c);
+        HIPCHK(c, hipEventRecord(fence, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, fence, 0));
+        ev_put(c, fence);
+        hipStream_t s = c->comm_stream;
+        if (st_all) {
+            for (int src = 0; src < nranks; ++src) {
+                const ExchangePlan &sp = (*pl_all)[src][g]; const SupermerStore &ss = (*st_all)[src];
+                const u64 n = sp.send_sup[rank], nb = sp.send_bytes[rank];
+                if (n != p.recv_sup[src] || nb != p.recv_bytes[src]) return fail(c, HSK_ERR_INTERNAL, "exchange plan mismatch %d->%d (group %d)", src, rank, g);
+                if (!n) continue;
+                HIPCHK(c, hipMemcpyAsync(b.len + p.recv_sup_off[src], ss.sm_len + sp.send_sup_off[rank], n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(b.bytes + p.recv_byte_off[src], ss.sm_bytes + sp.send_byte_off[rank], nb, hipMemcpyDeviceToDevice, s));
+                if (ext) {
+                    HIPCHK(c, hipMemcpyAsync(b.pos + p.recv_sup_off[src], ss.sm_pos + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
+                    HIPCHK(c, hipMemcpyAsync(b.rid + p.recv_sup_off[src], ss.sm_rid + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
+                }
+            }
+        } else {
+            int rc = post_exchange(c->comm, s, ext, p, st->sm_len, st->sm_bytes, st->sm_pos, st->sm_rid, b);
+            if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange (group %d) failed: %d (%s)", g, rc, c->comm.last_error.c_str());
+        }
+        bytes_moved += p.recv_tot_bytes + p.recv_tot_sup * (ext ? 9 : 1);
+        arrived[g] = ev_get(c);
+        HIPCHK(c, hipEventRecord(arrived[g], s));
+        return HSK_OK;
+    }
+    // the main stream is about to read group g: make sure g and g+1 are on their way, wait for g
+    int need(int g)
+    {
+        const int upto = std::min(g + 1, ngroups - 1);
+        while (posted <= upto) { int rc = post(posted); if (rc) return rc; ++posted; }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, arrived[g], 0));
+        return HSK_OK;
+    }
+    // the main stream has launched its last reader of every group below g
+    void release_below(int g)
+    {
+        for (; released < g && released < posted; ++released) {
+            xb[released].release(c->pool);         // next user is ordered after the readers by post()'s fence (or is on the main stream)
+            if (arrived[released]) { ev_put(c, arrived[released]); arrived[released] = nullptr; }
+        }
+    }
+    // every rank must take part in every group even when it owns no task of it
+    int finish()
+    {
+        while (posted < ngroups) { int rc = post(posted); if (rc) return rc; ++posted; }
+        HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+        release_below(ngroups);
+        return HSK_OK;
+    }
+    TaskInput input(u32 t) const
+    {
+        const ExchangeBuffers &b = xb[group_of[t]];
+        TaskInput in; in.len = b.len; in.src = source_from_bytes(b.bytes, b.nbytes); in.pos = b.pos; in.rid = b.rid;
+        return in;
+    }
+};
+
+static bool overlap_enabled()
+{
+    static const bool on = !(getenv("HSK_OVERLAP") && atoi(getenv("HSK_OVERLAP")) == 0);
+    return on;
+}
+
 // Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
 // result of this rank.  `segs[t]` lists where the supermers of task t live (x_len / x_src / x_pos / x_rid).
 template <int NW>
 static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owner, int rank, std::vector<TaskSegs> &segs,
                         const u8 *x_len, const BaseSource &x_src, const u32 *x_pos, const int32_t *x_rid,
-                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open)
+                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open, GroupFeeder *feeder = nullptr)
 {
     const bool ext = c->cfg.extension != 0;
     const int K = c->cfg.kmer_size;
@@ -913,16 +1021,24 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
     { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
+    TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
     size_t pos = 0;
     while (batch && pos + XCD_BATCH <= mine.size()) {
         BatchTask bt[XCD_BATCH];
+        if (feeder) {                                   // exposed (not overlapped) part of the exchange
+            pt.begin(PH_EXCH);
+            for (int i = 0; i < XCD_BATCH; ++i) { int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
+            pt.end(PH_EXCH);
+        }
         pt.begin(PH_EXTRACT);
         for (int i = 0; i < XCD_BATCH; ++i) {
             const u32 t = mine[pos + i];
             bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
-            int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[i], vA[i]); if (rc) return rc;
+            const TaskInput in = feeder ? feeder->input(t) : dflt;
+            int rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[i], vA[i]); if (rc) return rc;
         }
         pt.end(PH_EXTRACT);
+        if (feeder) feeder->release_below(pos + XCD_BATCH < mine.size() ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
         pt.begin(PH_SORT);
         { int rc = sort_batch_device<NW>(c, bt, K, fused); if (rc) return rc; }
@@ -946,9 +1062,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     for (; pos < mine.size(); ++pos) {
         const u32 t = mine[pos];
         const u64 n = segs[t].nkmers;
+        int rc;
+        if (feeder) { pt.begin(PH_EXCH); rc = feeder->need(feeder->group_of[t]); pt.end(PH_EXCH); if (rc) return rc; }
         pt.begin(PH_EXTRACT);
-        int rc = expand_task<NW>(c, segs[t], x_len, x_src, x_pos, x_rid, kA[0], vA[0]); if (rc) return rc;
+        const TaskInput in = feeder ? feeder->input(t) : dflt;
+        rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[0], vA[0]); if (rc) return rc;
         pt.end(PH_EXTRACT);
+        if (feeder) feeder->release_below(pos + 1 < mine.size() ? feeder->group_of[mine[pos + 1]] : feeder->ngroups);
         pt.begin(PH_SORT);
         u64 *sk, *sv;
         rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
@@ -958,6 +1078,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.end(PH_COUNT);
     }
     for (u32 t : mine) { n_total += touts[t].n; pay_total += touts[t].npay; }
+    if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     {
         int rc = check_device_error(c); if (rc) return rc;
     }
@@ -1068,15 +1189,26 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     const u8 *x_len = st.sm_len; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
     BaseSource x_src = source_from_packed(d_packed, packed_bytes, st.sm_gpos);
     ExchangeBuffers xb;
+    GroupFeeder feeder; bool fed = false;
     pt.begin(PH_EXCH);
     if (nranks > 1) {
         int rc = pack_store_bytes(c, st, x_src); if (rc) return rc;
-        rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
+        if (overlap_enabled()) {
+            // size matrix: every rank contributes its row, the sum is the full matrix
+            std::vector<u64> M((size_t)nranks * ntasks * 3, 0);
+            for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)rank * ntasks * 3 + i] = st.task_tot[i];
+            rc = c->comm.allreduce_sum_u64(M.data(), M.size(), c->stream, c->pool);
+            if (rc) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", rc, c->comm.last_error.c_str());
+            rc = feeder.plan(c, nranks, rank, ntasks, owner, order, M, st.task_base, segs); if (rc) return rc;
+            feeder.st = &st; fed = true;
+        } else {
+            rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
                                     st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
-        if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
-        x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
-        x_src = source_from_bytes(xb.bytes, xb.nbytes);
-        free_store(c, st);
+            if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
+            x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
+            x_src = source_from_bytes(xb.bytes, xb.nbytes);
+            free_store(c, st);
+        }
     } else {
         for (u32 t = 0; t < ntasks; ++t) {
             if (st.task_tot[3 * t] == 0) continue;
@@ -1085,8 +1217,8 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         }
     }
     pt.end(PH_EXCH);
-    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true);
-    if (nranks > 1) xb.release(c->pool); else free_store(c, st);
+    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr);
+    if (nranks > 1 && !fed) xb.release(c->pool); else free_store(c, st);
     return rc;
 }
 
@@ -1128,7 +1260,25 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) return rc;
         for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
     }
-    // 3. the exchange: same plan as hsk_comm.h, copies instead of send/recv
+    // 3. the exchange: same plans as the RCCL path (hsk_comm.h), device copies instead of send/recv
+    if (overlap_enabled()) {
+        // grouped exchange overlapped with the sort, exactly as run_pipeline drives it
+        std::vector<GroupFeeder> fd(R);
+        std::vector<std::vector<ExchangePlan>> pl_all(R);
+        std::vector<std::vector<TaskSegs>> segs(R);
+        for (int d = 0; d < R; ++d) { int rc = fd[d].plan(c, R, d, ntasks, owner, order, M, st[d].task_base, segs[d]); if (rc) return rc; pl_all[d] = fd[d].pl; }
+        int rc_all = HSK_OK;
+        for (int r = 0; r < R && rc_all == HSK_OK; ++r) {
+            fd[r].st_all = &st; fd[r].pl_all = &pl_all;
+            memset(&outs[r], 0, sizeof(hsk_result));
+            ResultPriv *rp = new ResultPriv();
+            outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
+            PhaseTimer pt(c);
+            rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r]);
+        }
+        for (int r = 0; r < R; ++r) free_store(c, st[r]);
+        return rc_all;
+    }
     std::vector<ExchangePlan> pl(R);
     std::vector<std::vector<TaskSegs>> segs(R);
     std::vector<ExchangeBuffers> xb(R);

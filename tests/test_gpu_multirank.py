@@ -67,3 +67,49 @@ def test_loopback_vs_oracle_with_owner_table(variant, R):
                 pos, rid = kl.payload(i)
                 a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
                 assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist()))
+
+
+@pytest.mark.parametrize("variant,R,ntasks", [("k31", 2, 40), ("k31ext", 3, 60), ("k51", 2, 34)])
+def test_loopback_grouped_exchange(variant, R, ntasks):
+    """Several task groups per rank: the exchange of group g+1 overlaps the sort of group g (GroupFeeder);
+    per-rank lists must still equal the oracle restricted to the rank's tasks."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    from oracle import hsk_oracle as O
+    cfg = util.VARIANTS[variant]
+    seqs = synth.reads(150000, 150, 12000, 23)
+    parts = _split(H, seqs, R)
+    with H.Context(K=cfg["k"], M=cfg["m"], L=2, U=50, EXT=cfg["ext"], ntasks=ntasks) as c:
+        res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])
+    assert np.bincount(owner, minlength=R).max() > 8                  # more than one group on some rank
+    packed, off, lens = O.pack_reads(seqs)
+    for r in range(R):
+        ores = O.count(packed, off, lens, k=cfg["k"], m=cfg["m"], L=2, U=50, ext=cfg["ext"], ntasks=ntasks, task_owner=owner, my_rank=r)
+        kl = res[r]
+        assert np.array_equal(kl.kmers, ores.keys), r
+        assert np.array_equal(kl.cnt, ores.cnt), r
+        assert np.array_equal(kl.task_off, ores.task_off), r
+        if cfg["ext"]:
+            for i in range(0, len(kl), 97):
+                pos, rid = kl.payload(i)
+                a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+                assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist()))
+
+
+def test_overlap_switch_gives_identical_lists():
+    """HSK_OVERLAP=0 (one exchange up front) and the grouped, overlapped exchange produce the same bytes."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np, hashlib; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "from hysortk_amd import synth\n"
+            "seqs = synth.reads(200000, 150, 9000, 3)\n"
+            "parts = [seqs[:len(seqs)//2], seqs[len(seqs)//2:]]\n"
+            "c = H.Context(K=31, M=17, L=1, U=80, ntasks=48)\n"
+            "res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])\n"
+            "h = hashlib.sha256(owner.tobytes())\n"
+            "for kl in res: h.update(kl.kmers.tobytes() + kl.cnt.tobytes() + kl.task_off.tobytes() + kl.histo.tobytes())\n"
+            "print(h.hexdigest(), sum(len(k) for k in res))\n") % util.ROOT
+    outs = []
+    for env in ({"HSK_OVERLAP": "1"}, {"HSK_OVERLAP": "0"}):
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
+    assert outs[0] == outs[1], outs
+    assert int(outs[0][1]) > 10000
