@@ -1,0 +1,210 @@
+// hsk_agg.h -- "two passes, then aggregate": the last stage of filter_kmer for one-word keys without payload.
+//
+// Replaces the tail of sort_task + count_sorted_kmers (reference src/kmerops.cpp:1382-1445) for NW == 1,
+// EXTENSION == 0.  The reference sorts every k-mer instance of a task completely (RADULS, 8 byte passes) and
+// then scans the sorted array for runs.  Sequencing data repeats every k-mer about `coverage` times, so most of
+// that sorting moves copies of the same key around.  Here only the top 16 key bits are sorted globally (two
+// onesweep passes, hsk_sort.h): that cuts a 2^28-key task into 65536 prefix bins of ~4096 records, and such a
+// bin holds only ~4096 / coverage DISTINCT keys.  One workgroup per bin then
+//   1. streams the bin's records once from HBM and counts them in an LDS hash table (open addressing; the common
+//      case "key already present" is one LDS read + one LDS atomic add),
+//   2. sorts the few distinct (key, count) pairs in LDS (rank by counting up to 256 keys, bitonic beyond),
+//   3. applies the [L, U] filter and writes the kept entries, in ascending key order, to the bin's own slot range
+//      of a scratch buffer (no inter-workgroup dependency), with their number in bin_cnt[].
+// count_scan_kernel (hsk_count.h) turns bin_cnt into offsets and agg_compact_kernel moves the entries to their
+// final place, building the count histogram (print_kmer_histogram, reference src/hysortk.cpp:98-136) on the way.
+// Bins are ascending in the key prefix and entries ascending inside a bin, so the list is exactly the sorted,
+// filtered list the reference produces.
+//
+// A bin with more distinct keys than the table holds raises AG_FLAG_OVERFLOW for its task: the host retries the
+// task with the large table and, if that overflows too, takes the long way (full-width passes + count_kernel).
+#pragma once
+#include "hsk_device.h"
+
+namespace hsk {
+
+constexpr int AG_THREADS = 256;
+constexpr int AG_PREFIX_BITS = 16;
+constexpr int AG_SHIFT = 64 - AG_PREFIX_BITS;
+constexpr u32 AG_BINS = 1u << AG_PREFIX_BITS;
+constexpr int AG_MAX_PROBE = 48;
+constexpr u64 AG_EMPTY = ~0ULL;                   // never a canonical k-mer word (the all-T k-mer's twin, all-A, is smaller)
+constexpr int AG_LDS_HIST = 256;
+constexpr int AG_BATCH = 8;
+
+enum { AG_FLAG_OVERFLOW = 1 };
+
+struct AggTask {
+    const u64 *keys; u64 n;        // sorted on the top AG_PREFIX_BITS bits
+    u64 *bounds;                   // [AG_BINS + 1] first record of every prefix bin (bin_bounds_kernel)
+    u64 *scratch; u32 slot_shift;  // bin b writes entry e {key, count} to scratch[((bounds[b] >> slot_shift) + e) * 2 ..]
+    u32 active;
+    u64 *bin_cnt;                  // [AG_BINS (+1 for the scan total)] kept entries of each bin
+    u32 *flags;                    // out: AG_FLAG_*
+};
+struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; };
+
+// bounds[b] = index of the first key whose top bits are >= b (b = 0 .. AG_BINS); one thread per bound
+__global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
+{
+    const AggTask &t = a.t[blockIdx.y];
+    const u32 b = blockIdx.x * AG_THREADS + threadIdx.x;
+    if (!t.active || b > AG_BINS) return;
+    u64 lo = 0, hi = t.n;                               // first index in [0, n] with (key >> AG_SHIFT) >= b
+    if (b == AG_BINS) lo = t.n;
+    else while (lo < hi) {
+        const u64 mid = lo + ((hi - lo) >> 1);
+        if ((u32)(t.keys[mid] >> AG_SHIFT) < b) lo = mid + 1; else hi = mid;
+    }
+    t.bounds[b] = lo;
+}
+
+template <int LOG2CAP>
+__device__ __forceinline__ u32 agg_slot(u64 k)
+{
+    const u32 x = (u32)(k >> 32) ^ (u32)k;
+    return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
+}
+
+template <int LOG2CAP>
+__global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
+{
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    __shared__ u64 s_key[CAP];      // hash table, later the rank-sorted keys
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u64 s_ck[CAP];       // distinct keys, compacted
+    __shared__ u32 s_cc[CAP];
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_ovf;
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    const u32 b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_key[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    // ---- 1. count the records of the bin in the table ------------------------------------------------------
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * 4) {
+        u64 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k[u] == AG_EMPTY) continue;
+            u32 h = agg_slot<LOG2CAP>(k[u]);
+            bool done = false;
+            for (int p = 0; p < AG_MAX_PROBE; ++p) {
+                u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
+                if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_cnt[h], 1u); done = true; break; }
+                h = (h + 1) & (CAP - 1);
+            }
+            if (!done) s_ovf = 1;
+        }
+    }
+    __syncthreads();
+    if (s_ovf) {
+        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        return;
+    }
+
+    // ---- 2. compact the occupied slots, sort the distinct keys -----------------------------------------------
+    u32 occ = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) occ += s_key[tid * PER + j] != AG_EMPTY;
+    u32 D;
+    u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u64 k = s_key[tid * PER + j];
+        if (k != AG_EMPTY) { s_ck[o] = k; s_cc[o] = s_cnt[tid * PER + j]; ++o; }
+    }
+    __syncthreads();
+    const u64 *sk; const u32 *sc;
+    if (D <= (u32)AG_THREADS) {
+        // rank by counting: keys are distinct, so ranks are a permutation; s_ck[j] is a broadcast read
+        if ((u32)tid < D) {
+            const u64 k = s_ck[tid]; const u32 c = s_cc[tid];
+            u32 r = 0;
+            for (u32 j = 0; j < D; ++j) r += s_ck[j] < k;
+            s_key[r] = k; s_cnt[r] = c;
+        }
+        __syncthreads();
+        sk = s_key; sc = s_cnt;
+    } else {
+        u32 P = 512; while (P < D) P <<= 1;
+        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_ck[i] = AG_EMPTY; s_cc[i] = 0; }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < P; i += AG_THREADS) {
+                    const u32 q = i ^ j;
+                    if (q > i) {
+                        const u64 x = s_ck[i], y = s_ck[q];
+                        const bool up = (i & kk) == 0;
+                        if ((x > y) == up) { const u32 cx = s_cc[i], cy = s_cc[q]; s_ck[i] = y; s_ck[q] = x; s_cc[i] = cy; s_cc[q] = cx; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        sk = s_ck; sc = s_cc;
+    }
+
+    // ---- 3. filter, entries in key order to the bin's slots --------------------------------------------------
+    u32 kept = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) { const u32 c = sc[i]; kept += (c >= a.lower && c <= a.upper); }
+    }
+    u32 tot;
+    u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);
+    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 2;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) {
+            const u32 c = sc[i];
+            if (c >= a.lower && c <= a.upper) { dst[0] = sk[i]; dst[1] = (u64)c; dst += 2; }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+}
+
+// Moves the kept entries from the per-bin slots to their final place (bin_off = exclusive scan of bin_cnt,
+// bin_off[AG_BINS] = total) and builds the count histogram.  One wave per bin, persistent workgroups.
+__global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(const u64 *scratch, const u64 *bounds, u32 slot_shift, const u64 *bin_off,
+                                                                  u64 *entries, u64 *histo, u32 histo_len)
+{
+    __shared__ u32 s_hist[AG_LDS_HIST];
+    for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) s_hist[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (u32 b = blockIdx.x * 4 + wave; b < AG_BINS; b += gridDim.x * 4) {
+        const u64 o = bin_off[b];
+        const u32 cnt = (u32)(bin_off[b + 1] - o);
+        const u64 *src = scratch + (bounds[b] >> slot_shift) * 2;
+        for (u32 i = lane; i < cnt * 2; i += 64) {
+            const u64 v = src[i];
+            entries[o * 2 + i] = v;
+            if (i & 1) {
+                if (v < (u64)AG_LDS_HIST) atomicAdd(&s_hist[(u32)v], 1u);
+                else if (v < histo_len) atomicAdd((unsigned long long *)&histo[v], 1ULL);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) {
+        const u32 c = s_hist[i];
+        if (c && (u32)i < histo_len) atomicAdd((unsigned long long *)&histo[i], (unsigned long long)c);
+    }
+}
+
+} // namespace hsk

@@ -30,6 +30,7 @@
 #include "hsk_sort.h"
 #include "hsk_count.h"
 #include "hsk_finish.h"
+#include "hsk_agg.h"
 #include "hsk_synth.h"
 #include "hsk_plan.h"
 #include "hsk_comm.h"
@@ -246,6 +247,7 @@ static void drain_profile_events(hsk_ctx *c)
         float f = 0;
         if (hipEventElapsedTime(&f, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { c->stats.scatter_launches++; c->stats.scatter_keys += p.keys; c->stats.scatter_bytes += p.bytes; c->stats.scatter_ms += f; }
+            else if (p.kind == 2) { c->stats.agg_launches++; c->stats.agg_bytes += p.bytes; c->stats.agg_ms += f; }
             else { c->stats.hist_launches++; c->stats.hist_bytes += p.bytes; c->stats.hist_ms += f; }
         }
         ev_put(c, p.a); ev_put(c, p.b);
@@ -448,10 +450,11 @@ static int make_pass_plan(int K, int nw, int rb, PassDesc *out)
 // copies of ONE k-mer and passes through untouched; 24 bits left 40 % of the records in multi-key bins whose
 // in-LDS ordering (serial, LDS-latency bound) cost more than the fourth pass.
 constexpr int HYBRID_SHIFT = 32;
-static int make_hybrid_plan(PassDesc *out)
+static int make_hybrid_plan(PassDesc *out, int prefix_bits = 64 - HYBRID_SHIFT)
 {
-    out[0] = PassDesc{0, 32, 8}; out[1] = PassDesc{0, 40, 8}; out[2] = PassDesc{0, 48, 8}; out[3] = PassDesc{0, 56, 8};
-    return 4;
+    const int np = prefix_bits / 8;                     // LSD passes over the top prefix_bits bits
+    for (int i = 0; i < np; ++i) out[i] = PassDesc{0, 64 - prefix_bits + 8 * i, 8};
+    return np;
 }
 static bool hybrid_enabled()
 {
@@ -570,7 +573,7 @@ static void launch_onesweep_multi(hsk_ctx *c, const MultiSortArgs &m, u32 grid)
 }
 
 template <int NW>
-static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follows)
+static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follows, int prefix_bits = 64 - HYBRID_SHIFT)
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const bool has_val = bt[0].vA != nullptr;
@@ -583,7 +586,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4 + 64, c->stream));
     PassDesc plan[MAX_PASSES];
     const bool hybrid = NW == 1 && hybrid_enabled();
-    const int npass = hybrid ? make_hybrid_plan(plan) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+    const int npass = hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
     u64 ntot = 0; bool wide = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
         bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
@@ -875,6 +878,106 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
     return rc;
 }
 
+// ---- two passes + aggregation (hsk_agg.h): the batch's keys are sorted on their top 16 bits ---------------
+static bool agg_enabled()
+{
+    static const bool on = !(getenv("HSK_AGG") && atoi(getenv("HSK_AGG")) == 0);
+    return on;
+}
+
+template <int NW>
+static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    static_assert(NW == 1, "the aggregating finish handles one-word keys");
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 slot_shift = L >= 2 ? 1 : 0;              // a bin of n records keeps at most n / L entries of 16 bytes
+    const size_t per = (size_t)AG_BINS + 8;
+    u64 *d_bounds, *d_cnt; u32 *d_flags;
+    DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_flags, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+    AggArgs a; memset(&a, 0, sizeof a);
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq;
+    bool own_scratch[AG_BATCH] = {false};
+    u64 ntot = 0;
+    for (int i = 0; i < AG_BATCH; ++i) {
+        AggTask &t = a.t[i];
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
+        t.slot_shift = slot_shift; t.active = 1; ntot += bt[i].n;
+        if (slot_shift) t.scratch = other;               // the idle ping-pong buffer: n / 2 entries
+        else {
+            t.scratch = (u64 *)c->pool.alloc(bt[i].n * 16 + 64); own_scratch[i] = true;
+            if (!t.scratch) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)(bt[i].n * 16));
+        }
+    }
+    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
+    auto run = [&](int log2cap) -> int {
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
+        if (log2cap == 10) hipLaunchKernelGGL((agg_finish_kernel<10>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_finish_kernel<11>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+        for (int i = 0; i < AG_BATCH; ++i)
+            if (a.t[i].active) hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, a.t[i].bin_cnt, (u64)AG_BINS, a.t[i].bin_cnt + AG_BINS);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + AG_BINS, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HSK_OK;
+    };
+    memset(&h, 0, sizeof h);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(AG_BINS / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    int rc = run(10); if (rc) return rc;
+    bool retry = false, done[AG_BATCH];
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
+    if (retry) {
+        // second chance with the large table for the tasks that overflowed
+        AggArgs keep = a;
+        for (int i = 0; i < AG_BATCH; ++i) a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0;
+        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+        memset(&h, 0, sizeof h);
+        rc = run(11); if (rc) return rc;
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
+        a = keep;
+    }
+    static int occ = 0;
+    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, agg_compact_kernel, AG_THREADS, 0) == hipSuccess && nb > 0) ? nb : 4; }
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0) continue;
+        if (!done[i]) {
+            // the long way for this task: full-width passes from the current order, then the two-pass counter
+            c->stats.redone_tasks++;
+            if (own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
+            SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+            u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+            rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+            free_sort_scratch(c, sc1);
+            if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
+            continue;
+        }
+        c->stats.fused_tasks++;
+        outs[i].n = total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16);
+            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * 16)); break; }
+            const u32 grid = (u32)std::min<u64>(AG_BINS / 4, (u64)occ * 256);
+            hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(AG_THREADS), 0, c->stream, a.t[i].scratch, a.t[i].bounds, slot_shift, a.t[i].bin_cnt,
+                               outs[i].entries, d_histo, histo_len);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
+    for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) c->pool.release(a.t[i].scratch);
+    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
+    (void)max_task;
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Exchange / sort overlap (multi-GPU).  The owned tasks of every rank are cut into groups of
 // XCD_BATCH consecutive tasks; group g+1 travels on `comm_stream` (RCCL send/recv, or device copies
@@ -1040,14 +1143,17 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.end(PH_EXTRACT);
         if (feeder) feeder->release_below(pos + XCD_BATCH < mine.size() ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
+        const bool agg = fused && agg_enabled();
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K, fused); if (rc) return rc; }
+        { int rc = sort_batch_device<NW>(c, bt, K, fused, agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         if (fused) {
             if constexpr (NW == 1) {
                 TaskOut fo[XCD_BATCH];
-                int rc = finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo); if (rc) return rc;
+                int rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo)
+                             : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
+                if (rc) return rc;
                 for (int i = 0; i < XCD_BATCH; ++i) touts[mine[pos + i]] = fo[i];
             }
         } else {

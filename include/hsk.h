@@ -109,9 +109,12 @@ typedef struct {
     uint64_t hist_launches;
     uint64_t hist_bytes;
     double   hist_ms;
-    int64_t  fused_tasks;         /* tasks finished by the fused finish kernel (hybrid sort) */
+    int64_t  fused_tasks;         /* tasks finished by a fused finish kernel (aggregating or tile finish) */
     int64_t  redone_tasks;        /* tasks the hybrid path had to redo with the full-width passes */
-    int64_t  reserved[6];
+    uint64_t agg_launches;        /* aggregating finish kernel (hsk_agg.h): launches, record bytes read, duration */
+    uint64_t agg_bytes;
+    double   agg_ms;
+    int64_t  reserved[3];
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

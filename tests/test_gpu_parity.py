@@ -358,7 +358,8 @@ def test_fused_finish_adversarial(H, O, L, U, wild):
 
 
 def test_fused_finish_equals_two_pass_path(H):
-    """Same input through HSK_FUSED_FINISH=0/1 and HSK_HYBRID=0 (subprocesses: the switches are read once)."""
+    """Same input through the aggregating finish (default), HSK_AGG=0 (tile finish), HSK_FUSED_FINISH=0, HSK_HYBRID=0 and
+    the single-task path (subprocesses: the switches are read once)."""
     import subprocess, sys, os, json
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
             "c = H.Context(K=31, M=17, L=2, U=60, ntasks=16)\n"
@@ -366,7 +367,7 @@ def test_fused_finish_equals_two_pass_path(H):
             "r = c.count_device(dp, nb, do, dl, 400000)\n"
             "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
     outs = []
-    for env in ({"HSK_FUSED_FINISH": "1"}, {"HSK_FUSED_FINISH": "0"}, {"HSK_HYBRID": "0"}, {"HSK_XCD_BATCH": "0"}):
+    for env in ({"HSK_FUSED_FINISH": "1"}, {"HSK_AGG": "0"}, {"HSK_FUSED_FINISH": "0"}, {"HSK_HYBRID": "0"}, {"HSK_XCD_BATCH": "0"}):
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
