@@ -37,7 +37,8 @@ class Stats(C.Structure):
         ("scatter_launches", C.c_uint64), ("scatter_keys", C.c_uint64), ("scatter_bytes", C.c_uint64), ("scatter_ms", C.c_double),
         ("hist_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("hist_ms", C.c_double),
         ("fused_tasks", C.c_int64), ("redone_tasks", C.c_int64),
-        ("agg_launches", C.c_uint64), ("agg_bytes", C.c_uint64), ("agg_ms", C.c_double), ("reserved", C.c_int64 * 3),
+        ("agg_launches", C.c_uint64), ("agg_bytes", C.c_uint64), ("agg_ms", C.c_double),
+        ("agg_retried_tasks", C.c_int64), ("reserved", C.c_int64 * 2),
     ]
 
 

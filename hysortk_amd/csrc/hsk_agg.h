@@ -90,12 +90,14 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     __syncthreads();
 
     // ---- 1. count the records of the bin in the table ------------------------------------------------------
-    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * 4) {
-        u64 k[4];
+    // 16 loads per lane are issued before the first insert: a typical bin (4096 records) costs one memory latency
+    constexpr int AG_UNROLL = 16;
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * AG_UNROLL) {
+        u64 k[AG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+        for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AG_UNROLL; ++u) {
             if (k[u] == AG_EMPTY) continue;
             u32 h = agg_slot<LOG2CAP>(k[u]);
             bool done = false;
@@ -178,12 +180,43 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     if (tid == 0) t.bin_cnt[b] = tot;
 }
 
+// exclusive scan of bin_cnt[AG_BINS] of every active task (total behind the last bin); one workgroup per task
+__global__ __launch_bounds__(AG_THREADS) void agg_scan_kernel(AggArgs a)
+{
+    __shared__ u64 s_scr[8];
+    __shared__ u64 s_carry;
+    const AggTask &t = a.t[blockIdx.x];
+    if (!t.active) return;
+    constexpr int IPT = 8;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b = 0; b < AG_BINS; b += AG_THREADS * IPT) {
+        const u32 t0 = b + threadIdx.x * IPT;
+        u64 v[IPT], sum = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) { v[i] = t.bin_cnt[t0 + i]; sum += v[i]; }
+        u64 tot;
+        u64 ex = block_excl_scan_256<u64>(sum, s_scr, &tot) + s_carry;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) { t.bin_cnt[t0 + i] = ex; ex += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) t.bin_cnt[AG_BINS] = s_carry;
+}
+
 // Moves the kept entries from the per-bin slots to their final place (bin_off = exclusive scan of bin_cnt,
 // bin_off[AG_BINS] = total) and builds the count histogram.  One wave per bin, persistent workgroups.
-__global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(const u64 *scratch, const u64 *bounds, u32 slot_shift, const u64 *bin_off,
-                                                                  u64 *entries, u64 *histo, u32 histo_len)
+struct AggCompactArgs { const u64 *scratch[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH]; u64 *entries[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; };
+__global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(AggCompactArgs ca)
 {
     __shared__ u32 s_hist[AG_LDS_HIST];
+    u64 *entries = ca.entries[blockIdx.y];
+    if (!entries) return;                               // task not handled here (empty, or redone the long way)
+    const u64 *scratch = ca.scratch[blockIdx.y], *bounds = ca.bounds[blockIdx.y], *bin_off = ca.bin_off[blockIdx.y];
+    const u32 slot_shift = ca.slot_shift, histo_len = ca.histo_len;
+    u64 *histo = ca.histo;
     for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) s_hist[i] = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -921,8 +921,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         if (log2cap == 10) hipLaunchKernelGGL((agg_finish_kernel<10>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg_finish_kernel<11>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-        for (int i = 0; i < AG_BATCH; ++i)
-            if (a.t[i].active) hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, a.t[i].bin_cnt, (u64)AG_BINS, a.t[i].bin_cnt + AG_BINS);
+        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
         for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + AG_BINS, 8, hipMemcpyDeviceToHost, c->stream));
@@ -938,37 +937,38 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     if (retry) {
         // second chance with the large table for the tasks that overflowed
         AggArgs keep = a;
-        for (int i = 0; i < AG_BATCH; ++i) a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0;
+        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
         HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
         memset(&h, 0, sizeof h);
         rc = run(11); if (rc) return rc;
         for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
         a = keep;
     }
-    static int occ = 0;
-    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, agg_compact_kernel, AG_THREADS, 0) == hipSuccess && nb > 0) ? nb : 4; }
+    AggCompactArgs ca; memset(&ca, 0, sizeof ca);
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len;
+    bool any = false;
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
-        if (bt[i].n == 0) continue;
-        if (!done[i]) {
-            // the long way for this task: full-width passes from the current order, then the two-pass counter
-            c->stats.redone_tasks++;
-            if (own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
-            SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
-            u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
-            rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
-            free_sort_scratch(c, sc1);
-            if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
-            continue;
-        }
+        if (bt[i].n == 0 || !done[i]) continue;
         c->stats.fused_tasks++;
         outs[i].n = total[i];
         if (outs[i].n) {
             outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16);
             if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * 16)); break; }
-            const u32 grid = (u32)std::min<u64>(AG_BINS / 4, (u64)occ * 256);
-            hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(AG_THREADS), 0, c->stream, a.t[i].scratch, a.t[i].bounds, slot_shift, a.t[i].bin_cnt,
-                               outs[i].entries, d_histo, histo_len);
+            ca.scratch[i] = a.t[i].scratch; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt; ca.entries[i] = outs[i].entries;
+            any = true;
         }
+    }
+    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || done[i]) continue;
+        // the long way for this task: full-width passes from the current order, then the two-pass counter
+        c->stats.redone_tasks++;
+        if (own_scratch[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
+        SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+        u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+        rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+        free_sort_scratch(c, sc1);
+        if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch

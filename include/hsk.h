@@ -114,7 +114,8 @@ typedef struct {
     uint64_t agg_launches;        /* aggregating finish kernel (hsk_agg.h): launches, record bytes read, duration */
     uint64_t agg_bytes;
     double   agg_ms;
-    int64_t  reserved[3];
+    int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
+    int64_t  reserved[2];
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

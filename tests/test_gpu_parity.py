@@ -357,6 +357,34 @@ def test_fused_finish_adversarial(H, O, L, U, wild):
         assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
 
 
+@pytest.mark.parametrize("L,U", [(1, 65535), (2, 50)])
+def test_aggregating_finish_table_ladder(H, O, L, U):
+    """Prefix bins with ~200 / ~500 / ~1000 distinct keys per task: rank-by-counting, bitonic, and the retry with the
+    large hash table (hsk_agg.h) must all give the oracle's list."""
+    rng = np.random.default_rng(91)
+    g = "".join(rng.choice(list("ACGT"), 20000))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 3000)]
+    for pre, nvar in (("AACCGGTTACGTACGGTCAA", 3200), ("ACTGACTGGTCAGTCAACGT", 16000)):
+        for v in range(nvar):
+            reads.append(pre + "".join(rng.choice(list("ACGT"), 40)))
+        reads += reads[-50:]                                   # some of them twice
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    retried = 0
+    for ntasks in (8, 16):
+        ores = O.count(packed, off, lens, k=31, m=17, L=L, U=U, ntasks=ntasks, fast=True)
+        with H.Context(K=31, M=17, L=L, U=U, ntasks=ntasks) as c:
+            res = c.count(dna)
+            st = c.stats()
+        assert st["fused_tasks"] + st["redone_tasks"] == ntasks, st
+        retried += st["agg_retried_tasks"]
+        assert np.array_equal(res.task_off, ores.task_off), (L, U, ntasks)
+        assert np.array_equal(res.kmers, ores.keys), (L, U, ntasks)
+        assert np.array_equal(res.cnt, ores.cnt), (L, U, ntasks)
+        assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+    assert retried > 0
+
+
 def test_fused_finish_equals_two_pass_path(H):
     """Same input through the aggregating finish (default), HSK_AGG=0 (tile finish), HSK_FUSED_FINISH=0, HSK_HYBRID=0 and
     the single-task path (subprocesses: the switches are read once)."""
