@@ -31,6 +31,8 @@ constexpr int AG_MAX_PROBE = 48;
 constexpr u64 AG_EMPTY = ~0ULL;                   // never a canonical k-mer word (the all-T k-mer's twin, all-A, is smaller)
 constexpr int AG_LDS_HIST = 256;
 constexpr int AG_BATCH = 8;
+constexpr int AG_LOG2CAP_SMALL = 10;             // hash table slots: first try / retry
+constexpr int AG_LOG2CAP_LARGE = 12;
 
 enum { AG_FLAG_OVERFLOW = 1 };
 
@@ -71,10 +73,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 {
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
-    __shared__ u64 s_key[CAP];      // hash table, later the rank-sorted keys
+    __shared__ u64 s_key[CAP];      // hash table, then the distinct keys compacted, then sorted
     __shared__ u32 s_cnt[CAP];
-    __shared__ u64 s_ck[CAP];       // distinct keys, compacted
-    __shared__ u32 s_cc[CAP];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
@@ -116,48 +116,46 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         return;
     }
 
-    // ---- 2. compact the occupied slots, sort the distinct keys -----------------------------------------------
+    // ---- 2. compact the occupied slots (in place: every lane holds its PER slots in registers across the
+    //         barrier), sort the distinct keys ---------------------------------------------------------------
+    u64 mk[PER]; u32 mc[PER];
     u32 occ = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) occ += s_key[tid * PER + j] != AG_EMPTY;
+    for (int j = 0; j < PER; ++j) { mk[j] = s_key[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
     u32 D;
-    u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+    u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);      // (two barriers inside: all slots are read before any is rewritten)
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const u64 k = s_key[tid * PER + j];
-        if (k != AG_EMPTY) { s_ck[o] = k; s_cc[o] = s_cnt[tid * PER + j]; ++o; }
-    }
+    for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
     __syncthreads();
-    const u64 *sk; const u32 *sc;
     if (D <= (u32)AG_THREADS) {
-        // rank by counting: keys are distinct, so ranks are a permutation; s_ck[j] is a broadcast read
+        // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
+        u64 k = 0; u32 c = 0, r = 0;
         if ((u32)tid < D) {
-            const u64 k = s_ck[tid]; const u32 c = s_cc[tid];
-            u32 r = 0;
-            for (u32 j = 0; j < D; ++j) r += s_ck[j] < k;
-            s_key[r] = k; s_cnt[r] = c;
+            k = s_key[tid]; c = s_cnt[tid];
+            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
         }
         __syncthreads();
-        sk = s_key; sc = s_cnt;
+        if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; }
+        __syncthreads();
     } else {
         u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_ck[i] = AG_EMPTY; s_cc[i] = 0; }
+        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; }
         __syncthreads();
         for (u32 kk = 2; kk <= P; kk <<= 1) {
             for (u32 j = kk >> 1; j > 0; j >>= 1) {
                 for (u32 i = tid; i < P; i += AG_THREADS) {
                     const u32 q = i ^ j;
                     if (q > i) {
-                        const u64 x = s_ck[i], y = s_ck[q];
+                        const u64 x = s_key[i], y = s_key[q];
                         const bool up = (i & kk) == 0;
-                        if ((x > y) == up) { const u32 cx = s_cc[i], cy = s_cc[q]; s_ck[i] = y; s_ck[q] = x; s_cc[i] = cy; s_cc[q] = cx; }
+                        if ((x > y) == up) { const u32 cx = s_cnt[i], cy = s_cnt[q]; s_key[i] = y; s_key[q] = x; s_cnt[i] = cy; s_cnt[q] = cx; }
                     }
                 }
                 __syncthreads();
             }
         }
-        sk = s_ck; sc = s_cc;
     }
+    const u64 *sk = s_key; const u32 *sc = s_cnt;
 
     // ---- 3. filter, entries in key order to the bin's slots --------------------------------------------------
     u32 kept = 0;

@@ -918,8 +918,8 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto run = [&](int log2cap) -> int {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
-        if (log2cap == 10) hipLaunchKernelGGL((agg_finish_kernel<10>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_finish_kernel<11>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
@@ -930,7 +930,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     };
     memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_kernel, dim3(AG_BINS / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    int rc = run(10); if (rc) return rc;
+    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
     bool retry = false, done[AG_BATCH];
     u64 total[AG_BATCH];
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
@@ -940,7 +940,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
         HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
         memset(&h, 0, sizeof h);
-        rc = run(11); if (rc) return rc;
+        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
         for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
         a = keep;
     }

@@ -16,7 +16,7 @@
 namespace hsk {
 
 constexpr int EXP_THREADS = 256;
-constexpr int EXP_SPT = 8;
+constexpr int EXP_SPT = 4;
 constexpr int EXP_TILE = EXP_THREADS * EXP_SPT;   // supermers per tile
 constexpr int EXP_CHUNK = 2048;                   // output slots produced per step inside a tile
 
@@ -90,6 +90,29 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_scan_kernel(const ExpSeg *
 // byte offsets come from the prefix sums) or, for supermers that never left this GPU, the rank's
 // packed reads themselves (sm_gpos[s] = position of the supermer's first base; `src8` = packed reads
 // rounded down to 8 bytes, `src_bit0` = bit offset of the first read base inside src8).
+// NW + 1 words of the base stream starting at bit `bit` (bits past the buffer read as zero)
+template <int NW>
+__device__ __forceinline__ void load_window(const u64 *p8, u64 bit, u64 nwords, u64 (&w)[NW + 1])
+{
+    const u64 i = bit >> 6; const u32 s = (u32)(bit & 63);
+    u64 a[NW + 2];
+#pragma unroll
+    for (int x = 0; x < NW + 2; ++x) a[x] = (i + x < nwords) ? __builtin_bswap64(p8[i + x]) : 0;
+#pragma unroll
+    for (int x = 0; x < NW + 1; ++x) w[x] = s ? ((a[x] << s) | (a[x + 1] >> (64 - s))) : a[x];
+}
+
+// The k-mers of a tile are produced by WORK ITEMS: a supermer of n k-mers is cut into ceil(n / 8) items of up to
+// 8 consecutive k-mers.  A lane takes one item: it pulls a window of the base stream once (all loads of a lane are
+// issued together, nothing waits inside the roll) and then ROLLS: the forward k-mer is the window shifted by one
+// base per step, its twin is shifted the other way with the complement of the entering base on top
+// (the reference recomputes Kmer::GetTwin per k-mer, include/kmer.hpp:266-296).  The 256 items of one step cover a
+// contiguous range of at most 2048 output records; they pass through an LDS buffer so that the global stores are
+// coalesced (consecutive lanes, consecutive records).
+constexpr int EXP_RUN = 8;                            // k-mers per work item
+constexpr int EXP_OUT = EXP_THREADS * EXP_RUN;        // records per step at most
+constexpr int EXP_OUT_LDS = EXP_OUT + EXP_OUT / 8;    // one pad record per 8 (items start 8 records apart: spreads the banks)
+
 template <int NW, bool EXT>
 __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *src8, u64 src_bit0, u64 src_words,
                                                               const u64 *sm_gpos, const u32 *sm_pos, const int32_t *sm_rid, const u64 *tile_off,
@@ -97,9 +120,10 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
 {
     __shared__ u32 s_boff[EXP_TILE + 1];
     __shared__ u32 s_koff[EXP_TILE + 1];
+    __shared__ u32 s_ioff[EXP_TILE + 1];
     __shared__ u32 s_scr[8];
-    __shared__ u64 s_mask[EXP_CHUNK / 64];
-    __shared__ u32 s_wpre[EXP_CHUNK / 64];
+    __shared__ u32 s_rng[2];
+    __shared__ u64 s_out[EXP_OUT_LDS];
     const u64 tile = blockIdx.x;
     const int sg = seg_of_tile(segs, nseg, tile);
     const ExpSeg seg = segs[sg];
@@ -108,81 +132,100 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
     const int tid = threadIdx.x;
 
     // blocked arrangement: thread t owns supermers [t*SPT, t*SPT+SPT) of the tile
-    u32 nb[EXP_SPT], nk[EXP_SPT], sb = 0, sk = 0;
+    u32 nb[EXP_SPT], nk[EXP_SPT], sb = 0, sk = 0, si = 0;
 #pragma unroll
     for (int i = 0; i < EXP_SPT; ++i) {
         u32 s = tid * EXP_SPT + i;
         u32 len = (s < ns) ? sm_len[seg.sup_off + first + s] : 0;
         nb[i] = (s < ns) ? ((len + 3) >> 2) : 0;
         nk[i] = (s < ns) ? (len - k + 1) : 0;
-        sb += nb[i]; sk += nk[i];
+        sb += nb[i]; sk += nk[i]; si += (nk[i] + EXP_RUN - 1) / EXP_RUN;
     }
-    u32 totb, totk;
+    u32 totb, totk, toti;
     u32 eb = block_excl_scan_256<u32>(sb, s_scr, &totb);
     u32 ek = block_excl_scan_256<u32>(sk, s_scr, &totk);
+    u32 ei = block_excl_scan_256<u32>(si, s_scr, &toti);
 #pragma unroll
     for (int i = 0; i < EXP_SPT; ++i) {
-        s_boff[tid * EXP_SPT + i] = eb; s_koff[tid * EXP_SPT + i] = ek;
-        eb += nb[i]; ek += nk[i];
+        s_boff[tid * EXP_SPT + i] = eb; s_koff[tid * EXP_SPT + i] = ek; s_ioff[tid * EXP_SPT + i] = ei;
+        eb += nb[i]; ek += nk[i]; ei += (nk[i] + EXP_RUN - 1) / EXP_RUN;
     }
-    if (tid == EXP_THREADS - 1) { s_boff[EXP_TILE] = eb; s_koff[EXP_TILE] = ek; }
+    if (tid == EXP_THREADS - 1) { s_boff[EXP_TILE] = eb; s_koff[EXP_TILE] = ek; s_ioff[EXP_TILE] = ei; }
     __syncthreads();
 
     const u64 byte_abs = tile_off[2 * tile];
     const u64 kbase = tile_off[2 * tile + 1];
-    const u64 lastmask = ~0ULL << (64 * NW - 2 * k);      // 0 < 64*NW - 2k < 64 (k % 32 != 0)
+    const int low = 64 * NW - 2 * k;                      // unused low bits of the last word; 0 < low < 64 (k % 32 != 0)
+    const u64 lastmask = ~0ULL << low;
 
-    // The tile's k-mers are produced in chunks of 2048 consecutive output slots.  Which supermer a slot belongs to
-    // is NOT searched per k-mer: the supermers that start inside the chunk set one bit each in a 2048-bit mask, and
-    // slot j belongs to supermer  S0 + popcount(mask bits <= j) - 1  (S0 = supermers starting before the chunk: one
-    // search per chunk).  Lane t handles slots t, t+256, ...: consecutive lanes write consecutive records.
-    const int lane = tid & 63;
-    for (u32 c0 = 0; c0 < totk; c0 += EXP_CHUNK) {
-        const u32 c1 = (c0 + EXP_CHUNK < totk) ? c0 + EXP_CHUNK : totk;
-        // supermers starting in [c0, c1): a contiguous index range [sa, sb)
-        u32 sa, sb;
-        { u32 lo = 0, hi = ns; while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_koff[mid] < c0) lo = mid + 1; else hi = mid; } sa = lo; }
-        { u32 lo = sa, hi = ns; while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_koff[mid] < c1) lo = mid + 1; else hi = mid; } sb = lo; }
-        if (tid < EXP_CHUNK / 64) s_mask[tid] = 0;
-        __syncthreads();
-        for (u32 sidx = sa + tid; sidx < sb; sidx += EXP_THREADS) {
-            const u32 b = s_koff[sidx] - c0;
-            atomicOr((unsigned long long *)&s_mask[b >> 6], 1ULL << (b & 63));
+    for (u32 it0 = 0; it0 < toti; it0 += EXP_THREADS) {
+        const u32 item = it0 + tid;
+        const bool valid = item < toti;
+        u32 cnt = 0, out0 = 0;
+        u64 keys[EXP_RUN][NW];
+        u64 vals[EXT ? EXP_RUN : 1];
+        if (valid) {
+            u32 lo = 0, hi = ns;                           // last supermer whose first item is <= item (every supermer has >= 1 item)
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_ioff[mid] <= item) lo = mid; else hi = mid; }
+            const u32 sidx = lo;
+            const u32 i0 = (item - s_ioff[sidx]) * EXP_RUN;
+            const u32 k0 = s_koff[sidx];
+            const u32 nks = s_koff[sidx + 1] - k0;
+            cnt = nks - i0 < (u32)EXP_RUN ? nks - i0 : (u32)EXP_RUN;
+            out0 = k0 + i0;
+            const u64 sabs = seg.sup_off + first + sidx;
+            const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[sabs] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+            u64 win[NW + 1];
+            load_window<NW>(src8, bit, src_words, win);
+            u64 vbase = 0;
+            if (EXT) vbase = (u64)(sm_pos[sabs] + i0) | ((u64)(u32)sm_rid[sabs] << 32);
+            Mer<NW> fw, rc;
+#pragma unroll
+            for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
+            fw.w[NW - 1] &= lastmask;
+            rc = twin<NW>(fw, k);
+#pragma unroll
+            for (int r = 0; r < EXP_RUN; ++r) {
+                if (r > 0) {
+                    // one base further: window left by 2 bits; twin right by 2 bits, complement of the entering base on top
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) win[x] = (win[x] << 2) | (win[x + 1] >> 62);
+                    win[NW] <<= 2;
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
+                    fw.w[NW - 1] &= lastmask;
+                    const u64 nbase = (fw.w[NW - 1] >> low) & 3;
+#pragma unroll
+                    for (int x = NW - 1; x > 0; --x) rc.w[x] = (rc.w[x] >> 2) | (rc.w[x - 1] << 62);
+                    rc.w[0] = (rc.w[0] >> 2) | ((3 - nbase) << 62);
+                    rc.w[NW - 1] &= lastmask;
+                }
+                const bool use_rc = mer_less<NW>(rc, fw);
+#pragma unroll
+                for (int x = 0; x < NW; ++x) keys[r][x] = use_rc ? rc.w[x] : fw.w[x];
+                if (EXT) vals[r] = vbase + (u64)r;         // pos + r (the low word never carries: pos < read length)
+            }
         }
+        if (tid == 0) s_rng[0] = out0;
+        if (valid && (tid == EXP_THREADS - 1 || item + 1 == toti)) s_rng[1] = out0 + cnt;
         __syncthreads();
-        if (tid < 64) {
-            const u32 v = tid < EXP_CHUNK / 64 ? (u32)__popcll(s_mask[tid]) : 0;
-            const u32 inc = wave_incl_scan<u32>(v);
-            if (tid < EXP_CHUNK / 64) s_wpre[tid] = inc - v;
-        }
-        __syncthreads();
+        const u32 o0 = s_rng[0], nout = s_rng[1] - o0;
+        const u32 q0 = out0 - o0;                          // first record of this lane's item inside the step's range
+        // one key word (or the payload) at a time through the LDS buffer
 #pragma unroll
-        for (int r = 0; r < EXP_CHUNK / EXP_THREADS; ++r) {
-            const u32 j = c0 + r * EXP_THREADS + tid;
-            if (j >= c1) continue;
-            const u32 b = j - c0;
-            const u32 w = b >> 6;
-            const u64 below = ((b & 63) == 63) ? ~0ULL : ((2ULL << (b & 63)) - 1);
-            const u32 sidx = sa + s_wpre[w] + (u32)__popcll(s_mask[w] & below) - 1;   // sa > 0 when the chunk starts inside a supermer, so this never underflows
-            const u32 i = j - s_koff[sidx];
-            const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[seg.sup_off + first + sidx] + (u64)i))
-                                    : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i);
-            Mer<NW> mer;
+        for (int x = 0; x < NW + (EXT ? 1 : 0); ++x) {
+            if (x > 0) __syncthreads();
 #pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) mer.w[w2] = bits64_bytes_clamped(src8, bit + 64 * w2, src_words);
-            mer.w[NW - 1] &= lastmask;
-            Mer<NW> cm = canonical<NW>(mer, k);
-            const u64 o = kbase + j;
-#pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) keys_out[o * NW + w2] = cm.w[w2];
-            if (EXT) {
-                const u64 sa_abs = seg.sup_off + first + sidx;
-                vals_out[o] = (u64)(sm_pos[sa_abs] + i) | ((u64)(u32)sm_rid[sa_abs] << 32);
+            for (int r = 0; r < EXP_RUN; ++r)
+                if ((u32)r < cnt) { const u32 q = q0 + r; s_out[q + (q >> 3)] = (x < NW) ? keys[r][x < NW ? x : 0] : vals[EXT ? r : 0]; }
+            __syncthreads();
+            for (u32 q = tid; q < nout; q += EXP_THREADS) {
+                const u64 v = s_out[q + (q >> 3)];
+                if (x < NW) keys_out[(kbase + o0 + q) * NW + x] = v; else vals_out[kbase + o0 + q] = v;
             }
         }
         __syncthreads();
     }
-    (void)lane;
 }
 
 // Multi-GPU only: materialise the re-aligned byte stream of reference-mode supermers for the

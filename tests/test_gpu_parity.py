@@ -325,7 +325,7 @@ def _adversarial_reads(rng, wild):
         p = int(rng.integers(0, len(g) - 150))
         reads.append(g[p:p + 150])
     pre = "ACGTTGCAAGGCTTAACCGG"                            # 20 fixed bases: k-mers starting here share their top 32 bits
-    groups = ((60, 3), (700, 2), (40000, 1)) if wild else ((60, 3), (700, 2))
+    groups = ((60, 3), (700, 2), (160000, 1)) if wild else ((60, 3), (700, 2))
     for nvar, copies in groups:                             # bins with tens / hundreds / thousands of different keys per task
         for v in range(nvar):
             tail = "".join(rng.choice(list("ACGT"), 40))
