@@ -298,55 +298,134 @@ static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_byte
     return a;
 }
 
-// COUNT + scan + EMIT.  `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
-static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
-                       int64_t rid_base, u32 ntasks, const std::vector<u32> &order, SupermerStore &st)
+// The parse in two steps, so that a caller that needs the task sizes before it can fix the storage order
+// (multi-GPU: sizes -> all-reduce -> dispatcher -> owner-grouped order) hashes the reads only once:
+//   parse_count: minimizers + supermer boundaries of every tile; per-(workgroup, task) counts; task totals
+//   parse_place: exclusive scan of the counts in the storage order `order`, supermers to their slots
+// Fast path = scan_kernel + place_kernel (compact supermer records kept in between); the general path
+// (M > 25, or a tile with more supermers than the record capacity) = parse_kernel<COUNT> + emit_kernel.
+struct ParseJob {
+    ParseArgs a; u32 nblocks = 0, ntasks = 0; bool fast = false, empty = true;
+    const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
+    u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
+    std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
+};
+
+static void parse_release(hsk_ctx *c, ParseJob &j)
+{
+    c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
+    j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
+}
+
+static bool parse_fast_enabled()
+{
+    static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
+    return on;
+}
+static u32 parse_rec_cap()
+{
+    static const u32 cap = getenv("HSK_PARSE_REC_CAP") ? (u32)std::min(std::max(atoi(getenv("HSK_PARSE_REC_CAP")), 1), (int)PLACE_MAX_REC) : SCAN_REC_CAP;
+    return cap;
+}
+
+static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                       int64_t rid_base, u32 ntasks, ParseJob &j)
+{
+    j = ParseJob();
+    j.ntasks = ntasks; j.d_roff = d_roff; j.nreads = nreads; j.rid_base = rid_base;
+    j.task_tot.assign((size_t)ntasks * 3, 0);
+    if (nreads == 0 || packed_bytes == 0) return HSK_OK;            // nothing to parse on this rank
+    j.empty = false;
+    j.a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
+    ParseArgs &a = j.a;
+    DALLOC(c, j.d_blk_cnt, u64 *, (size_t)j.nblocks * ntasks * 3 * 8);
+    a.blk_cnt = j.d_blk_cnt;
+    u64 *d_task_tot; DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8 + 64);
+    j.fast = parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
+    u32 *h_ovf = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
+    *h_ovf = 0;
+    if (j.fast) {
+        a.rec_cap = parse_rec_cap();
+        a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
+        DALLOC(c, j.d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+        DALLOC(c, j.d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+        DALLOC(c, j.d_overflow, u32 *, 256);
+        HIPCHK(c, hipMemsetAsync(j.d_overflow, 0, 4, c->stream));
+        a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec; a.overflow = j.d_overflow;
+        hipLaunchKernelGGL(scan_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
+        HIPCHK(c, hipMemcpyAsync(h_ovf, j.d_overflow, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*h_ovf) {                                                // a tile with more supermers than the record capacity
+            j.fast = false; c->stats.parse_fallbacks++;
+            c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); j.d_tile_rec = j.d_tile_nrec = nullptr;
+            a.tile_rec = a.tile_nrec = nullptr;
+        }
+    }
+    if (!j.fast) {
+        // task id per base position, kept from COUNT to EMIT (2 B x 4 x packed_bytes); optional: without it EMIT re-hashes
+        j.d_dest_cache = (u16 *)c->pool.alloc((size_t)a.ntiles * PARSE_TILE * 2);
+        a.dest_cache = j.d_dest_cache;
+        hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
+        HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(d_task_tot);
+    return HSK_OK;
+}
+
+// `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
+static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st)
 {
     const bool ext = c->cfg.extension != 0;
-    if (nreads == 0 || packed_bytes == 0) {              // nothing to parse on this rank
-        st = SupermerStore();
-        st.ntasks = ntasks; st.order = order;
-        st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0);
-        return HSK_OK;
-    }
-    u32 nblocks = 0;
-    ParseArgs a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &nblocks);
-    st.ntasks = ntasks; st.nblocks = nblocks; st.order = order;
-    u64 *d_blk_cnt, *d_blk_base, *d_task_tot, *d_task_base; u32 *d_order;
-    DALLOC(c, d_blk_cnt, u64 *, (size_t)nblocks * ntasks * 3 * 8);
-    DALLOC(c, d_blk_base, u64 *, (size_t)nblocks * ntasks * 2 * 8);
+    const u32 ntasks = j.ntasks;
+    st = SupermerStore();
+    st.ntasks = ntasks; st.nblocks = j.nblocks; st.order = order;
+    st.task_tot = j.task_tot;
+    st.task_base.assign((size_t)ntasks * 3, 0);
+    { u64 s = 0, b = 0, k = 0;
+      for (u32 i = 0; i < ntasks; ++i) { const u32 t = order[i]; st.task_base[3 * t] = s; st.task_base[3 * t + 1] = b; st.task_base[3 * t + 2] = k;
+                                          s += st.task_tot[3 * t]; b += st.task_tot[3 * t + 1]; k += st.task_tot[3 * t + 2]; }
+      st.tot_sup = s; st.tot_bytes = b; st.tot_kmers = k; }
+    if (j.empty) return HSK_OK;
+    ParseArgs &a = j.a;
+    u64 *d_blk_base, *d_task_tot, *d_task_base; u32 *d_order;
+    DALLOC(c, d_blk_base, u64 *, (size_t)j.nblocks * ntasks * 2 * 8);
     DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8);
     DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
     DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
     HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
-    a.blk_cnt = d_blk_cnt;
-    // task id per base position, kept from COUNT to EMIT (2 B x 4 x packed_bytes); optional: without it EMIT re-hashes
-    u16 *d_dest_cache = (u16 *)c->pool.alloc((size_t)a.ntiles * PARSE_TILE * 2);
-    a.dest_cache = d_dest_cache;
-    hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
-    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, d_blk_cnt, nblocks, ntasks, d_order, d_task_tot, d_task_base, d_blk_base);
-    st.task_tot.resize((size_t)ntasks * 3); st.task_base.resize((size_t)ntasks * 3);
-    HIPCHK(c, hipMemcpyAsync(st.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.task_base.data(), d_task_base, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    st.tot_sup = st.tot_bytes = st.tot_kmers = 0;
-    for (u32 t = 0; t < ntasks; ++t) { st.tot_sup += st.task_tot[3 * t]; st.tot_bytes += st.task_tot[3 * t + 1]; st.tot_kmers += st.task_tot[3 * t + 2]; }
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_task_tot, d_task_base, d_blk_base);
     DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
     DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);          // reference mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
     a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos;
     if (st.tot_sup) {
-        if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
-        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        if (j.fast) hipLaunchKernelGGL(place_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, c->stream, a);
+        else if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                                    st.sm_gpos, st.tot_sup, d_roff, nreads, rid_base, st.sm_pos, st.sm_rid);
+                                    st.sm_gpos, st.tot_sup, j.d_roff, j.nreads, j.rid_base, st.sm_pos, st.sm_rid);
     }
     HIPCHK(c, hipGetLastError());
     // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
     // every later user of these blocks is enqueued on the same stream)
-    c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order);
-    c->pool.release(d_dest_cache);
+    c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order);
     return HSK_OK;
+}
+
+// count + place with a known storage order
+static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                       int64_t rid_base, u32 ntasks, const std::vector<u32> &order, SupermerStore &st)
+{
+    ParseJob j;
+    int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, j);
+    if (rc == HSK_OK) rc = parse_place(c, j, order, st);
+    parse_release(c, j);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,22 +1347,22 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     SupermerStore st;
     pt.begin(PH_PARSE);
     {
+        // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
+        // before the storage order (tasks grouped by owner rank) is known, then parse_place lays the supermers out
+        ParseJob job;
+        int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, job);
+        if (rc) { parse_release(c, job); return rc; }
         if (nranks > 1) {
-            // dispatch needs global task sizes first: COUNT once with identity order, exchange sizes,
-            // decide owners, then run the full parse with tasks grouped by owner.
-            SupermerStore probe;
-            int rc = parse_phase(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, order, probe);
-            if (rc) return rc;
-            free_store(c, probe);
             std::vector<u64> bytes(ntasks);
-            for (u32 t = 0; t < ntasks; ++t) bytes[t] = probe.task_tot[3 * t + 1] + probe.task_tot[3 * t] * (ext ? 9 : 1);
+            for (u32 t = 0; t < ntasks; ++t) bytes[t] = job.task_tot[3 * t + 1] + job.task_tot[3 * t] * (ext ? 9 : 1);
             rc = c->comm.allreduce_sum_u64(bytes.data(), ntasks, c->stream, c->pool);
-            if (rc) return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc);
+            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc); }
             rc = plan_dispatch(bytes.data(), (int)ntasks, nranks, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data());
-            if (rc) return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
+            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }
             std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
         }
-        int rc = parse_phase(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, order, st);
+        rc = parse_place(c, job, order, st);
+        parse_release(c, job);
         if (rc) return rc;
     }
     pt.end(PH_PARSE);
@@ -1345,25 +1424,30 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<int64_t> rid_base(R, 0);
     for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
-    // 1. probe task sizes on every rank, sum, dispatch
+    // 1. hash every rank's reads once (parse_count), sum the task sizes, dispatch
     std::vector<u64> bytes(ntasks, 0);
+    std::vector<ParseJob> jobs(R);
+    auto release_jobs = [&]() { for (auto &j : jobs) parse_release(c, j); };
     for (int r = 0; r < R; ++r) {
-        SupermerStore probe;
-        int rc = parse_phase(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, order, probe); if (rc) return rc;
-        free_store(c, probe);
-        for (u32 t = 0; t < ntasks; ++t) bytes[t] += probe.task_tot[3 * t + 1] + probe.task_tot[3 * t] * (ext ? 9 : 1);
+        int rc = parse_count(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, jobs[r]);
+        if (rc) { release_jobs(); return rc; }
+        for (u32 t = 0; t < ntasks; ++t) bytes[t] += jobs[r].task_tot[3 * t + 1] + jobs[r].task_tot[3 * t] * (ext ? 9 : 1);
     }
     std::vector<int32_t> owner(ntasks, 0);
-    if (plan_dispatch(bytes.data(), (int)ntasks, R, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data()))
+    if (plan_dispatch(bytes.data(), (int)ntasks, R, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data())) {
+        release_jobs();
         return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
+    }
     if (owner_out) memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks);
     std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
-    // 2. owner-grouped parse + byte materialisation on every rank
+    // 2. owner-grouped placement + byte materialisation on every rank
     std::vector<SupermerStore> st(R);
     std::vector<u64> M((size_t)R * ntasks * 3, 0);
     for (int r = 0; r < R; ++r) {
-        int rc = parse_phase(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, order, st[r]); if (rc) return rc;
-        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) return rc;
+        int rc = parse_place(c, jobs[r], order, st[r]);
+        parse_release(c, jobs[r]);
+        if (rc) { release_jobs(); return rc; }
+        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) { release_jobs(); return rc; }
         for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
     }
     // 3. the exchange: same plans as the RCCL path (hsk_comm.h), device copies instead of send/recv

@@ -61,6 +61,13 @@ struct ParseArgs {
     // optional: task id per base position (0xFFFF = no k-mer starts there), written by COUNT and read
     // by EMIT so that the minimizer hashes are computed once; 16-byte aligned, 2 B per position
     u16 *dest_cache;
+    // fast path (scan_kernel / place_kernel): the supermers of a tile as compact records, kept from the
+    // scan to the placement so that nothing is hashed or re-derived twice
+    u32 *tile_rec;             // [ntiles][rec_cap]: position in tile | (k-mers - 1) << 11 | task << 18, in position order
+    u32 *tile_nrec;            // [ntiles] supermers that start in the tile (may exceed rec_cap: see overflow)
+    u32 rec_cap;
+    u32 place_group;           // tiles placed together by one place_kernel step (rec_cap * place_group <= PLACE_MAX_REC)
+    u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
 };
 
 enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
@@ -419,6 +426,303 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
     }
 }
 
+// ======================================================================================================
+// Fast path: scan_kernel (minimizers, supermer records, per-(workgroup, task) counts) + place_kernel.
+//
+// Same contract as parse_kernel<COUNT> + emit_kernel, rebuilt around the instruction count (the parse is
+// VALU-bound: ~10^10 positions x MurmurHash3; integer multiplies are full rate on gfx950, so every other
+// instruction per position matters as much as the six 64-bit multiplies):
+//   * a lane owns 8 CONSECUTIVE positions: one 64-bit window of the base stream gives all 8 m-mers by
+//     constant shifts, the reverse strand is rolled (one base per step) instead of reversed per position;
+//   * the lane keeps its 8 hashes in registers and reads only the W-1 neighbours' hashes from LDS;
+//   * supermers are cut where the window MINIMUM changes (not where min % ntasks changes): no modulo per
+//     position; a supermer is never longer than before, the k-mers of a task are the same multiset
+//     (supermer boundaries are an internal format, see the header of this file);
+//   * supermer starts are compacted first, then one lane per SUPERMER does the modulo, the run length
+//     (bit scan over the boundary mask) and the per-task counters;
+//   * the tile's supermers leave as 4-byte records in position order (tile_rec); place_kernel reads them
+//     back (~1 KB per tile instead of the 4 KB task-id cache), counting-sorts a group of tiles by task in
+//     LDS and writes {length, position} to the per-task slots.
+// Requires 2*M + 14 <= 64 (M <= 25) so that the 8 m-mers of a lane fit one 64-bit window.
+// ======================================================================================================
+constexpr int SCAN_MAX_M = 25;
+constexpr u32 SCAN_REC_CAP = 512;                     // default records kept per tile (expected ~270 at K=31, M=17)
+constexpr u32 PLACE_MAX_REC = 2048;                   // records of one placement step (rec_cap * place_group)
+
+__global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
+{
+    __shared__ u32 s_words[PARSE_WORDS];
+    __shared__ __attribute__((aligned(16))) u64 s_hash[PARSE_HMAX];     // hashes of the tile; later the minima of the supermer starts
+    __shared__ u64 s_last[PARSE_THREADS];                                // window minimum of every lane's last position
+    __shared__ __attribute__((aligned(8))) u8 s_v8[PARSE_THREADS];       // valid mask of every lane's 8 positions
+    __shared__ __attribute__((aligned(8))) u8 s_bnd8[PARSE_THREADS + 16]; // boundary mask: bit p = a supermer cannot continue across p
+    __shared__ u16 s_plist[PARSE_TILE];                                  // positions of the supermer starts, ascending
+    __shared__ u64 s_rng[4];
+    __shared__ u64 s_roff[PARSE_RWIN];
+    __shared__ u32 s_rlen[PARSE_RWIN];
+    __shared__ u32 s_scan[12];
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];          // [task] {supermers << 40 | k-mers, bytes}
+
+    const int tid = threadIdx.x;
+    const int K = a.k, M = a.m, W = K - M + 1;
+    const u64 mmask = ~0ULL << (64 - 2 * M);
+    for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
+    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    if (tid == 0) s_rng[1] = (tile0 < a.ntiles) ? find_read(a.roff, 0, a.nreads - 1, (tile0 * PARSE_TILE) >> 2) : 0;
+    __syncthreads();
+    const u64 RINF = ~0ULL >> 2;
+    const int p0 = tid * PARSE_PPT;
+
+    for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
+        const u64 tile = tile0 + ti;
+        if (tile >= a.ntiles) break;
+        const u64 gbase = tile * PARSE_TILE;
+        const u64 bbase = gbase >> 2;
+
+        // ---- 1. stage bytes (big-endian words), read index window (as parse_kernel) -----------------------
+        {
+            const u32 *src = reinterpret_cast<const u32 *>(a.packed + bbase);
+            const u64 left = a.packed_bytes - bbase;
+            for (int i = tid; i < PARSE_WORDS; i += PARSE_THREADS) {
+                u32 wv = 0;
+                if ((u64)i * 4 + 4 <= left) wv = __builtin_bswap32(src[i]);
+                else if ((u64)i * 4 < left) {
+                    for (u64 b = (u64)i * 4; b < left; ++b) wv |= (u32)a.packed[bbase + b] << (24 - 8 * (b & 3));
+                }
+                s_words[i] = wv;
+            }
+        }
+        if (tid < PARSE_RWIN) {
+            const u64 rb = s_rng[1];
+            u64 blast = bbase + PARSE_TILE / 4 - 1;
+            if (blast >= a.packed_bytes) blast = a.packed_bytes - 1;
+            const u64 idx = rb + tid;
+            const u64 off = (idx <= a.nreads) ? a.roff[idx] : RINF;
+            s_roff[tid] = off;
+            s_rlen[tid] = (idx < a.nreads) ? a.rlen[idx] : 0;
+            const u32 c0 = (u32)__popcll(__ballot(idx < a.nreads && off <= bbase));
+            const u32 c1 = (u32)__popcll(__ballot(idx < a.nreads && off <= blast));
+            if (tid == 0) {
+                u64 r0 = rb + c0 - 1, r1 = rb + c1 - 1;
+                const bool fast = c1 < PARSE_RWIN;
+                if (!fast) {
+                    r0 = find_read(a.roff, rb, a.nreads - 1, bbase);
+                    r1 = find_read(a.roff, r0, a.nreads - 1, blast);
+                }
+                s_rng[0] = r0; s_rng[1] = r1; s_rng[2] = rb; s_rng[3] = fast ? 1 : 0;
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. canonical m-mer hashes of this lane's 8 positions (rolled), kept in registers -------------
+        u64 h[PARSE_PPT];
+        {
+            const u64 w0 = bits64_be32(s_words, 16u * (u32)tid);       // 32 bases from position p0
+            const u64 cw = ~w0;
+            u64 rc = twin1(w0 & mmask, M);
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const u64 fw = (w0 << (2 * i)) & mmask;
+                if (i > 0) rc = ((rc >> 2) | ((cw << (2 * (i - 1 + M))) & (3ULL << 62))) & mmask;   // base p0+i-1+M enters the reverse strand
+                h[i] = murmur64_8(rc < fw ? rc : fw);
+            }
+            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(&s_hash[p0]);
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; i += 2) dst[i >> 1] = make_ulonglong2(h[i], h[i + 1]);
+            // the W-1 positions behind the tile (windows of the last k-mers): high lanes first
+            for (int e = PARSE_THREADS - 1 - tid; e < W - 1; e += PARSE_THREADS) {
+                const int p = PARSE_TILE + e;
+                const u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
+                const u64 tw = twin1(fw, M);
+                s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+            }
+        }
+        __syncthreads();
+
+        // ---- 3. window minima (shared middle), validity --------------------------------------------------
+        u64 mn[PARSE_PPT];
+        if (W >= PARSE_PPT) {
+            u64 c = h[PARSE_PPT - 1];
+            for (int j = PARSE_PPT; j <= W - 1; ++j) { const u64 v = s_hash[p0 + j]; c = v < c ? v : c; }
+            mn[PARSE_PPT - 1] = c;
+            u64 suf = ~0ULL;
+#pragma unroll
+            for (int i = PARSE_PPT - 2; i >= 0; --i) { suf = h[i] < suf ? h[i] : suf; mn[i] = suf < c ? suf : c; }
+            u64 run = ~0ULL;
+#pragma unroll
+            for (int i = 1; i < PARSE_PPT; ++i) { const u64 v = s_hash[p0 + W + i - 1]; run = v < run ? v : run; mn[i] = run < mn[i] ? run : mn[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                u64 c = ~0ULL;
+                for (int j = 0; j < W; ++j) { const u64 v = s_hash[p0 + i + j]; c = v < c ? v : c; }
+                mn[i] = c;
+            }
+        }
+        u32 vmask = 0;
+        {
+            const u64 g0 = gbase + p0;
+            const u64 rlo = s_rng[0], rhi = s_rng[1], rb = s_rng[2];
+            const bool fast = s_rng[3] != 0;
+            u64 r, rstart, rend, nxt;
+            if (fast) {
+                u32 lo = (u32)(rlo - rb), hi = (u32)(rhi - rb);
+                const u64 b0 = g0 >> 2;
+                while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_roff[mid] <= b0) lo = mid; else hi = mid - 1; }
+                r = rb + lo; rstart = s_roff[lo] * 4; rend = rstart + s_rlen[lo];
+                nxt = (r + 1 < a.nreads) ? s_roff[lo + 1] * 4 : ~0ULL;
+            } else {
+                r = find_read(a.roff, rlo, rhi, g0 >> 2);
+                rstart = a.roff[r] * 4; rend = rstart + a.rlen[r];
+                nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL;
+            }
+            if (nxt >= g0 + PARSE_PPT) {
+                // one read under all 8 positions: k-mers start at g0 .. rend - K
+                const long long cnt = (long long)rend - (long long)K - (long long)g0 + 1;
+                vmask = cnt <= 0 ? 0u : (cnt >= PARSE_PPT ? 0xFFu : ((1u << (u32)cnt) - 1u));
+            } else {
+#pragma unroll
+                for (int i = 0; i < PARSE_PPT; ++i) {
+                    const u64 g = g0 + i;
+                    while (g >= nxt) {
+                        ++r; rstart = nxt;
+                        if (fast) { const u32 j = (u32)(r - rb); rend = rstart + s_rlen[j]; nxt = (r + 1 < a.nreads) ? s_roff[j + 1] * 4 : ~0ULL; }
+                        else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
+                    }
+                    if (g + (u64)K <= rend) vmask |= 1u << i;
+                }
+            }
+        }
+        s_last[tid] = mn[PARSE_PPT - 1];
+        s_v8[tid] = (u8)vmask;
+        __syncthreads();
+
+        // ---- 4. boundaries, supermer starts, compaction ---------------------------------------------------
+        u32 start8 = 0;
+        {
+            u64 pm = tid ? s_last[tid - 1] : 0;
+            bool pv = tid ? ((s_v8[tid - 1] >> 7) & 1) != 0 : false;
+            u32 bnd8 = 0;
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const bool v = (vmask >> i) & 1;
+                const bool cut = (i == 0) && ((tid & (SUPERMER_CUT / PARSE_PPT - 1)) == 0);
+                const bool bnd = !v || cut || !pv || (mn[i] != pm);
+                bnd8 |= (bnd ? 1u : 0u) << i;
+                start8 |= ((v && bnd) ? 1u : 0u) << i;
+                pm = mn[i]; pv = v;
+            }
+            s_bnd8[tid] = (u8)bnd8;
+        }
+        u32 nrec;
+        u32 off = block_excl_scan_256<u32>((u32)__popc(start8), s_scan, &nrec);   // (barriers inside: s_hash is free from here on)
+#pragma unroll
+        for (int i = 0; i < PARSE_PPT; ++i)
+            if ((start8 >> i) & 1) { s_hash[off] = mn[i]; s_plist[off] = (u16)(p0 + i); ++off; }
+        __syncthreads();
+
+        // ---- 5. one lane per supermer: task, run length, counters, record ----------------------------------
+        {
+            const u64 *bw = reinterpret_cast<const u64 *>(s_bnd8);
+            u32 *trec = a.tile_rec + tile * (u64)a.rec_cap;
+            for (u32 r = tid; r < nrec; r += PARSE_THREADS) {
+                const u32 p = s_plist[r];
+                const u32 d = fastmod64(s_hash[r], a.fm);
+                const u32 w = p >> 6;
+                const u64 m = ((p & 63) == 63) ? 0ULL : (bw[w] & (~0ULL << ((p & 63) + 1)));
+                u32 nb = (p | (SUPERMER_CUT - 1)) + 1;
+                if (m) nb = w * 64 + (u32)__builtin_ctzll(m);
+                else if ((w & 1) == 0) { const u64 m2 = bw[w + 1]; if (m2) nb = (w + 1) * 64 + (u32)__builtin_ctzll(m2); }
+                const u32 nk = nb - p;
+                atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);
+                atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((nk + K - 1 + 3) >> 2));
+                if (r < a.rec_cap) trec[r] = p | ((nk - 1) << 11) | (d << 18);
+            }
+            if (tid == 0) {
+                a.tile_nrec[tile] = nrec;
+                if (nrec > a.rec_cap) atomicOr(a.overflow, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
+        u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
+        const u64 pk = s_cur[2 * t];
+        o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
+    }
+}
+
+// Placement: the records of `place_group` consecutive tiles of this workgroup are loaded (coalesced), counting-sorted
+// by task in LDS and written to the per-(workgroup, task) slot ranges that parse_scan_kernel laid out.  Several
+// tiles per step make the runs per task longer (~27 records of 8 + 1 bytes at 40 tasks) than one tile would.
+// dynamic LDS: u64 cur[ntasks], u32 tcnt[ntasks], u32 tpre[ntasks], u32 srt[PLACE_MAX_REC]
+__global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
+{
+    constexpr int RPT = PLACE_MAX_REC / PARSE_THREADS;                 // records per thread and step at most
+    __shared__ u32 s_scan[12];
+    __shared__ u32 s_go[20];                                            // record offsets of the tiles of the step (+ total)
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];
+    const int tid = threadIdx.x;
+    const int K = a.k;
+    u32 *s_tcnt = reinterpret_cast<u32 *>(s_cur + a.ntasks);
+    u32 *s_tpre = s_tcnt + a.ntasks;
+    u32 *s_srt = s_tpre + a.ntasks;
+    for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] = a.blk_base[((u64)blockIdx.x * a.ntasks + t) * 2];
+    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    const u32 G = a.place_group;
+    for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
+        const u64 tfirst = tile0 + t0;
+        if (tfirst >= a.ntiles) break;
+        u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
+        if (tfirst + ng > a.ntiles) ng = (u32)(a.ntiles - tfirst);
+        __syncthreads();                                                // previous step done with s_go / s_tcnt / s_srt
+        if (tid == 0) {
+            u32 run = 0;
+            for (u32 j = 0; j < ng; ++j) { s_go[j] = run; u32 n = a.tile_nrec[tfirst + j]; run += n < a.rec_cap ? n : a.rec_cap; }
+            for (u32 j = ng; j <= 16; ++j) s_go[j] = run;
+        }
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_tcnt[t] = 0;
+        __syncthreads();
+        const u32 total = s_go[16];
+        u32 rec[RPT], rnk[RPT];
+#pragma unroll
+        for (int x = 0; x < RPT; ++x) {
+            const u32 i = x * PARSE_THREADS + tid;
+            rec[x] = 0xFFFFFFFFu;
+            if (i < total) {
+                u32 j = 0;
+                while (j + 1 < ng && s_go[j + 1] <= i) ++j;
+                const u32 r = a.tile_rec[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])];
+                rec[x] = r | (j << 28);
+                rnk[x] = atomicAdd(&s_tcnt[(r >> 18) & 1023u], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            u32 c4[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; c4[j] = t < a.ntasks ? s_tcnt[t] : 0; sum += c4[j]; }
+            u32 e = block_excl_scan_256<u32>(sum, s_scan, nullptr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; if (t < a.ntasks) s_tpre[t] = e; e += c4[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < RPT; ++x)
+            if (rec[x] != 0xFFFFFFFFu) s_srt[s_tpre[(rec[x] >> 18) & 1023u] + rnk[x]] = rec[x];
+        __syncthreads();
+        for (u32 i = tid; i < total; i += PARSE_THREADS) {
+            const u32 r = s_srt[i];
+            const u32 d = (r >> 18) & 1023u;
+            const u64 slot = s_cur[d] + (i - s_tpre[d]);
+            a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);
+            a.sm_gpos[slot] = (tfirst + (r >> 28)) * PARSE_TILE + (u64)(r & 2047);
+        }
+        __syncthreads();
+        for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
+    }
+}
+
 // EXTENSION: (PosInRead, ReadId) of every supermer from its base position (one index search per supermer;
 // the reference carries them in length_t, include/kmer.hpp:350-360)
 __global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *roff, u64 nreads, int64_t rid_base, u32 *sm_pos, int32_t *sm_rid)
@@ -430,6 +734,19 @@ __global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *rof
         sm_pos[s] = (u32)(g - roff[r] * 4);
         sm_rid[s] = (int32_t)(rid_base + (int64_t)r);
     }
+}
+
+// task_tot[t][3] = column sums of the COUNT matrix (supermers, bytes, k-mers of task t on this rank)
+__global__ void task_totals_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, u64 *task_tot)
+{
+    const u32 t = threadIdx.x;
+    if (t >= ntasks) return;
+    u64 s = 0, b = 0, k = 0;
+    for (u32 blk = 0; blk < nblocks; ++blk) {
+        const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
+        s += c[0]; b += c[1]; k += c[2];
+    }
+    task_tot[3 * t] = s; task_tot[3 * t + 1] = b; task_tot[3 * t + 2] = k;
 }
 
 // Exclusive scan of the COUNT matrix: per task totals, task bases (tasks laid out in `order`),

@@ -115,7 +115,8 @@ typedef struct {
     uint64_t agg_bytes;
     double   agg_ms;
     int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
-    int64_t  reserved[2];
+    int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
+    int64_t  reserved[1];
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
