@@ -448,11 +448,16 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
 constexpr int SCAN_MAX_M = 25;
 constexpr u32 SCAN_REC_CAP = 512;                     // default records kept per tile (expected ~270 at K=31, M=17)
 constexpr u32 PLACE_MAX_REC = 2048;                   // records of one placement step (rec_cap * place_group)
+// LDS layout of the tile's hashes: position p = 8*t + i lives at [i][t] (row stride SCAN_HSTRIDE), so that the 64
+// lanes of a wave, which all touch the same i of consecutive t, hit consecutive 8-byte words (a lane-major layout
+// puts them 64 bytes apart: 8-way bank conflicts on every access)
+constexpr int SCAN_HSTRIDE = PARSE_THREADS + 16;      // 256 lanes + 12 lanes' worth of positions behind the tile
+__device__ __forceinline__ int scan_hidx(int p) { return (p & 7) * SCAN_HSTRIDE + (p >> 3); }
 
 __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
-    __shared__ __attribute__((aligned(16))) u64 s_hash[PARSE_HMAX];     // hashes of the tile; later the minima of the supermer starts
+    __shared__ __attribute__((aligned(16))) u64 s_hash[8 * SCAN_HSTRIDE]; // hashes of the tile ([i][t] layout); later the minima of the supermer starts
     __shared__ u64 s_last[PARSE_THREADS];                                // window minimum of every lane's last position
     __shared__ __attribute__((aligned(8))) u8 s_v8[PARSE_THREADS];       // valid mask of every lane's 8 positions
     __shared__ __attribute__((aligned(8))) u8 s_bnd8[PARSE_THREADS + 16]; // boundary mask: bit p = a supermer cannot continue across p
@@ -526,15 +531,14 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 if (i > 0) rc = ((rc >> 2) | ((cw << (2 * (i - 1 + M))) & (3ULL << 62))) & mmask;   // base p0+i-1+M enters the reverse strand
                 h[i] = murmur64_8(rc < fw ? rc : fw);
             }
-            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(&s_hash[p0]);
 #pragma unroll
-            for (int i = 0; i < PARSE_PPT; i += 2) dst[i >> 1] = make_ulonglong2(h[i], h[i + 1]);
+            for (int i = 0; i < PARSE_PPT; ++i) s_hash[i * SCAN_HSTRIDE + tid] = h[i];
             // the W-1 positions behind the tile (windows of the last k-mers): high lanes first
             for (int e = PARSE_THREADS - 1 - tid; e < W - 1; e += PARSE_THREADS) {
                 const int p = PARSE_TILE + e;
                 const u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
                 const u64 tw = twin1(fw, M);
-                s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+                s_hash[scan_hidx(p)] = murmur64_8(tw < fw ? tw : fw);
             }
         }
         __syncthreads();
@@ -543,19 +547,19 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         u64 mn[PARSE_PPT];
         if (W >= PARSE_PPT) {
             u64 c = h[PARSE_PPT - 1];
-            for (int j = PARSE_PPT; j <= W - 1; ++j) { const u64 v = s_hash[p0 + j]; c = v < c ? v : c; }
+            for (int j = PARSE_PPT; j <= W - 1; ++j) { const u64 v = s_hash[scan_hidx(p0 + j)]; c = v < c ? v : c; }
             mn[PARSE_PPT - 1] = c;
             u64 suf = ~0ULL;
 #pragma unroll
             for (int i = PARSE_PPT - 2; i >= 0; --i) { suf = h[i] < suf ? h[i] : suf; mn[i] = suf < c ? suf : c; }
             u64 run = ~0ULL;
 #pragma unroll
-            for (int i = 1; i < PARSE_PPT; ++i) { const u64 v = s_hash[p0 + W + i - 1]; run = v < run ? v : run; mn[i] = run < mn[i] ? run : mn[i]; }
+            for (int i = 1; i < PARSE_PPT; ++i) { const u64 v = s_hash[scan_hidx(p0 + W + i - 1)]; run = v < run ? v : run; mn[i] = run < mn[i] ? run : mn[i]; }
         } else {
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 u64 c = ~0ULL;
-                for (int j = 0; j < W; ++j) { const u64 v = s_hash[p0 + i + j]; c = v < c ? v : c; }
+                for (int j = 0; j < W; ++j) { const u64 v = s_hash[scan_hidx(p0 + i + j)]; c = v < c ? v : c; }
                 mn[i] = c;
             }
         }
