@@ -457,36 +457,91 @@ static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
 
 struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr; };
 
-static int expand_prepare(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, ExpandScratch &x)
+// tile sums + scans of n <= EXP_PREP_BATCH tasks with two launches
+static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, const u8 *const *sm_len, ExpandScratch *x)
 {
-    const int nseg = (int)ts.segs.size();
-    DALLOC(c, x.d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
-    DALLOC(c, x.d_tile_sum, u64 *, ts.ntiles * 16);
-    DALLOC(c, x.d_tile_off, u64 *, ts.ntiles * 16);
-    HIPCHK(c, hipMemcpyAsync(x.d_segs, ts.segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len, c->cfg.kmer_size, x.d_tile_sum);
-    hipLaunchKernelGGL(expand_scan_kernel, dim3(nseg), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, ts.ntiles, x.d_tile_sum, x.d_tile_off);
+    ExpandPrepArgs pa; memset(&pa, 0, sizeof pa);
+    pa.k = c->cfg.kmer_size;
+    u64 max_tiles = 0; int max_seg = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nseg = (int)ts[i]->segs.size();
+        DALLOC(c, x[i].d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
+        DALLOC(c, x[i].d_tile_sum, u64 *, ts[i]->ntiles * 16);
+        DALLOC(c, x[i].d_tile_off, u64 *, ts[i]->ntiles * 16);
+        HIPCHK(c, hipMemcpyAsync(x[i].d_segs, ts[i]->segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
+        pa.segs[i] = x[i].d_segs; pa.nseg[i] = nseg; pa.sm_len[i] = sm_len[i]; pa.ntiles[i] = ts[i]->ntiles;
+        pa.tile_sum[i] = x[i].d_tile_sum; pa.tile_off[i] = x[i].d_tile_off;
+        max_tiles = std::max(max_tiles, ts[i]->ntiles); max_seg = std::max(max_seg, nseg);
+    }
+    if (max_tiles == 0) return HSK_OK;
+    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)max_tiles, n), dim3(EXP_THREADS), 0, c->stream, pa);
+    hipLaunchKernelGGL(expand_scan_kernel, dim3(max_seg, n), dim3(EXP_THREADS), 0, c->stream, pa);
     return HSK_OK;
 }
+static int expand_prepare(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, ExpandScratch &x)
+{
+    const TaskSegs *tp = &ts;
+    return expand_prepare_batch(c, 1, &tp, &sm_len, &x);
+}
 static void expand_release(hsk_ctx *c, ExpandScratch &x) { c->pool.release(x.d_segs); c->pool.release(x.d_tile_sum); c->pool.release(x.d_tile_off); x = ExpandScratch(); }
+
+// One launch for up to EXP_BATCH tasks (hsk_expand.h).  ghist[i] (optional) receives the digit histograms of
+// the `npass` radix passes in `plan` for task i.
+struct ExpandJob { const TaskSegs *ts; const u8 *sm_len; BaseSource src; const u32 *sm_pos; const int32_t *sm_rid; u64 *keys, *vals, *ghist; };
+
+template <int NW>
+static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass = 0, const PassDesc *plan = nullptr)
+{
+    const bool ext = c->cfg.extension != 0;
+    ExpandArgs a; memset(&a, 0, sizeof a);
+    ExpandScratch x[EXP_BATCH];
+    int nt = 0; u64 max_tiles = 0;
+    {
+        const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH]; int m = 0;
+        for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles) { tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; ++m; }
+        // (ts.segs is host memory owned by the caller and stays alive until the next sync)
+        int rc = expand_prepare_batch(c, m, tsp, lens, x); if (rc) return rc;
+    }
+    for (int i = 0; i < njobs; ++i) {
+        const ExpandJob &j = jobs[i];
+        if (j.ts->ntiles == 0) continue;
+        ExpandTask &t = a.t[nt];
+        t.segs = x[nt].d_segs; t.nseg = (int)j.ts->segs.size(); t.sm_len = j.sm_len;
+        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos; t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid;
+        t.tile_off = x[nt].d_tile_off; t.ntiles = j.ts->ntiles; t.keys_out = j.keys; t.vals_out = j.vals; t.ghist = npass ? j.ghist : nullptr;
+        max_tiles = std::max(max_tiles, t.ntiles);
+        ++nt;
+    }
+    if (nt == 0) return HSK_OK;
+    a.ntask = nt; a.k = c->cfg.kmer_size; a.npass = npass;
+    if (npass) memcpy(a.pass, plan, sizeof(PassDesc) * npass);
+    const size_t dyn = (size_t)std::max(npass, 1) * 256 * 4;
+    // persistent workgroups: exactly what is resident at once (a second wave would start when the first is done)
+    static int occ_c[2] = {0, 0};
+    int &occ = occ_c[ext ? 1 : 0];
+    if (!occ) {
+        int nb = 0;
+        hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_kernel<NW, true>, EXP_THREADS, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_kernel<NW, false>, EXP_THREADS, dyn);
+        occ = (e == hipSuccess && nb > 0) ? nb : 4;
+    }
+    u32 rw = (u32)std::max(1, occ * 256 / (8 * nt));
+    rw = (u32)std::min<u64>(rw, (max_tiles + 7) / 8);
+    a.row_workers = std::max<u32>(rw, 1);
+    const u32 grid = 8u * (u32)nt * a.row_workers;
+    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);
+    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    for (int i = 0; i < nt; ++i) expand_release(c, x[i]);
+    return HSK_OK;
+}
 
 template <int NW>
 static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const BaseSource &src, const u32 *sm_pos, const int32_t *sm_rid,
                        u64 *d_keys, u64 *d_vals)
 {
-    if (ts.ntiles == 0) return HSK_OK;
-    const bool ext = c->cfg.extension != 0;
-    const int nseg = (int)ts.segs.size();
-    ExpandScratch x;
-    int rc = expand_prepare(c, ts, sm_len, x); if (rc) return rc;
-    // (ts.segs is host memory owned by the caller and stays alive until the next sync)
-    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len,
-                                src.src8, src.bit0, src.nwords, src.gpos, sm_pos, sm_rid, x.d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
-    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3((u32)ts.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, nseg, sm_len,
-                            src.src8, src.bit0, src.nwords, src.gpos, sm_pos, sm_rid, x.d_tile_off, c->cfg.kmer_size, d_keys, d_vals);
-    HIPCHK(c, hipGetLastError());
-    expand_release(c, x);
-    return HSK_OK;
+    ExpandJob j; j.ts = &ts; j.sm_len = sm_len; j.src = src; j.sm_pos = sm_pos; j.sm_rid = sm_rid; j.keys = d_keys; j.vals = d_vals; j.ghist = nullptr;
+    return expand_batch<NW>(c, &j, 1);
 }
 
 // multi-GPU: bytes of all supermers of the store, in storage order (what the exchange sends)
@@ -651,26 +706,38 @@ static void launch_onesweep_multi(hsk_ctx *c, const MultiSortArgs &m, u32 grid)
     hipLaunchKernelGGL((onesweep_multi_kernel<NW, HAS_VAL, LB>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, m);
 }
 
+// the digit plan of a batch sort (shared with expand_batch, which counts the digits while it writes the keys)
 template <int NW>
-static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follows, int prefix_bits = 64 - HYBRID_SHIFT)
+static int batch_pass_plan(hsk_ctx *c, int K, bool finish_follows, int prefix_bits, PassDesc *plan)
+{
+    const bool hybrid = NW == 1 && hybrid_enabled();
+    return hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+}
+
+// d_ghist_pre: [XCD_BATCH][MAX_PASSES][256] digit histograms already counted by expand_batch (null: hist_kernel runs here)
+template <int NW>
+static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follows, int prefix_bits = 64 - HYBRID_SHIFT, u64 *d_ghist_pre = nullptr)
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const bool has_val = bt[0].vA != nullptr;
     constexpr int TILE = SortTile<NW>::TILE;
     u64 *d_ghist, *d_gbase; u32 *d_tickets;
-    DALLOC(c, d_ghist, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    if (d_ghist_pre) d_ghist = d_ghist_pre;
+    else {
+        DALLOC(c, d_ghist, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+        HIPCHK(c, hipMemsetAsync(d_ghist, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
+    }
     DALLOC(c, d_gbase, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
     DALLOC(c, d_tickets, u32 *, (size_t)XCD_BATCH * MAX_PASSES * 4 + 256);       // + 8 flag words behind the tickets
-    HIPCHK(c, hipMemsetAsync(d_ghist, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4 + 64, c->stream));
     PassDesc plan[MAX_PASSES];
     const bool hybrid = NW == 1 && hybrid_enabled();
-    const int npass = hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+    const int npass = batch_pass_plan<NW>(c, K, finish_follows, prefix_bits, plan);
     u64 ntot = 0; bool wide = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
         bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
         ntot += bt[i].n; if (bt[i].n >= (1ULL << 30)) wide = true;
-        if (bt[i].n == 0) continue;
+        if (bt[i].n == 0 || d_ghist_pre) continue;
         HistArgs h; memset(&h, 0, sizeof h);
         h.keys = bt[i].kA; h.n = bt[i].n; h.npass = npass; memcpy(h.pass, plan, sizeof(PassDesc) * npass);
         h.ghist = d_ghist + (size_t)i * MAX_PASSES * 256;
@@ -764,7 +831,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
             }
         }
     }
-    c->pool.release(d_lookback); c->pool.release(d_ghist); c->pool.release(d_gbase); c->pool.release(d_tickets);
+    c->pool.release(d_lookback); if (!d_ghist_pre) c->pool.release(d_ghist); c->pool.release(d_gbase); c->pool.release(d_tickets);
     return rc;
 }
 
@@ -1198,6 +1265,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
+    u64 *d_ghist_batch = nullptr;
+    if (batch) DALLOC(c, d_ghist_batch, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
     std::vector<TaskOut> touts(ntasks);
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
@@ -1212,19 +1281,29 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             for (int i = 0; i < XCD_BATCH; ++i) { int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
             pt.end(PH_EXCH);
         }
+        const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
+        const bool agg = fused && agg_enabled();
+        const int prefix_bits = agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        // one launch expands the eight tasks and counts the digits of the passes that follow
+        PassDesc plan[MAX_PASSES];
+        const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
         pt.begin(PH_EXTRACT);
-        for (int i = 0; i < XCD_BATCH; ++i) {
-            const u32 t = mine[pos + i];
-            bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
-            const TaskInput in = feeder ? feeder->input(t) : dflt;
-            int rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[i], vA[i]); if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(d_ghist_batch, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
+        {
+            ExpandJob jobs[XCD_BATCH];
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                const u32 t = mine[pos + i];
+                bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
+                const TaskInput in = feeder ? feeder->input(t) : dflt;
+                jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
+                jobs[i].keys = kA[i]; jobs[i].vals = vA[i]; jobs[i].ghist = d_ghist_batch + (size_t)i * MAX_PASSES * 256;
+            }
+            int rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan); if (rc) return rc;
         }
         pt.end(PH_EXTRACT);
         if (feeder) feeder->release_below(pos + XCD_BATCH < mine.size() ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
-        const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
-        const bool agg = fused && agg_enabled();
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K, fused, agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT); if (rc) return rc; }
+        { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_batch); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         if (fused) {
@@ -1269,6 +1348,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     }
     for (int i = 0; i < nsets; ++i) { c->pool.release(kA[i]); c->pool.release(kB[i]); c->pool.release(vA[i]); c->pool.release(vB[i]); }
     free_sort_scratch(c, sc);
+    c->pool.release(d_ghist_batch);
 
     // ---- result ----------------------------------------------------------------------------------------
     pt.begin(PH_D2H);

@@ -189,6 +189,18 @@ __device__ __forceinline__ T block_excl_scan_256(T v, T *scratch, T *total)
     return base + inc - v;
 }
 
+// ---- radix digit plan (hsk_sort.h; hsk_expand.h builds the digit histograms while it writes the keys) ----
+constexpr int MAX_PASSES = 24;
+struct PassDesc { int word; int shift; int bits; };
+
+// k[word] without dynamic register indexing (which would spill the key array to scratch)
+template <int NW> __device__ __forceinline__ u64 pick_word(const u64 *k, int word)
+{
+    if (NW == 1) return k[0];
+    if (NW == 2) return word == 0 ? k[0] : k[1];
+    return word == 0 ? k[0] : (word == 1 ? k[1] : k[NW - 1]);
+}
+
 // splitmix64 -- the synthetic-read generator's PRNG (also in hysortk_amd/synth.py)
 __host__ __device__ __forceinline__ u64 splitmix64(u64 x)
 {

@@ -8,7 +8,7 @@
 // consecutive lanes are consecutive records (coalesced).
 //
 // A task's supermers arrive as `nseg` segments (one per source rank; one on a single GPU).  Three
-// launches: tile sums (bytes, k-mers per 2048 supermers) -> per-segment exclusive scan -> expand.
+// launches: tile sums (bytes, k-mers per EXP_TILE supermers) -> per-segment exclusive scan -> expand.
 #pragma once
 #include <vector>
 #include "hsk_device.h"
@@ -16,9 +16,8 @@
 namespace hsk {
 
 constexpr int EXP_THREADS = 256;
-constexpr int EXP_SPT = 4;
+constexpr int EXP_SPT = 2;
 constexpr int EXP_TILE = EXP_THREADS * EXP_SPT;   // supermers per tile
-constexpr int EXP_CHUNK = 2048;                   // output slots produced per step inside a tile
 
 struct ExpSeg {
     u64 sup_off;     // first supermer slot (index into sm_len / sm_pos / sm_rid)
@@ -38,18 +37,28 @@ __device__ __forceinline__ int seg_of_tile(const ExpSeg *segs, int nseg, u64 til
     return s;
 }
 
+// Tile sums and their scan for up to EXP_PREP_BATCH tasks per launch (blockIdx.y = task)
+constexpr int EXP_PREP_BATCH = 8;
+struct ExpandPrepArgs {
+    const ExpSeg *segs[EXP_PREP_BATCH]; int nseg[EXP_PREP_BATCH]; const u8 *sm_len[EXP_PREP_BATCH];
+    u64 ntiles[EXP_PREP_BATCH]; u64 *tile_sum[EXP_PREP_BATCH]; u64 *tile_off[EXP_PREP_BATCH]; int k;
+};
+
 // tile_sum[tile] = {bytes, kmers}
-__global__ __launch_bounds__(EXP_THREADS) void expand_tilesum_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, int k, u64 *tile_sum)
+__global__ __launch_bounds__(EXP_THREADS) void expand_tilesum_kernel(ExpandPrepArgs a)
 {
     __shared__ u64 s_red[2 * 4];
+    const int ti = blockIdx.y;
     const u64 tile = blockIdx.x;
-    const int sg = seg_of_tile(segs, nseg, tile);
+    if (tile >= a.ntiles[ti]) return;
+    const ExpSeg *segs = a.segs[ti]; const u8 *sm_len = a.sm_len[ti];
+    const int sg = seg_of_tile(segs, a.nseg[ti], tile);
     const ExpSeg seg = segs[sg];
     const u64 first = (tile - seg.tile_start) * EXP_TILE;
     u64 nb = 0, nk = 0;
     for (int i = 0; i < EXP_SPT; ++i) {
         u64 s = first + (u64)i * EXP_THREADS + threadIdx.x;
-        if (s < seg.n_sup) { u32 len = sm_len[seg.sup_off + s]; nb += (len + 3) >> 2; nk += len - k + 1; }
+        if (s < seg.n_sup) { u32 len = sm_len[seg.sup_off + s]; nb += (len + 3) >> 2; nk += len - a.k + 1; }
     }
     for (int o = 32; o > 0; o >>= 1) { nb += __shfl_down(nb, o, WAVE); nk += __shfl_down(nk, o, WAVE); }
     if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = nb; s_red[2 * (threadIdx.x >> 6) + 1] = nk; }
@@ -57,29 +66,44 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_tilesum_kernel(const ExpSe
     if (threadIdx.x == 0) {
         u64 b = 0, kk = 0;
         for (int w = 0; w < 4; ++w) { b += s_red[2 * w]; kk += s_red[2 * w + 1]; }
-        tile_sum[2 * tile] = b; tile_sum[2 * tile + 1] = kk;
+        a.tile_sum[ti][2 * tile] = b; a.tile_sum[ti][2 * tile + 1] = kk;
     }
 }
 
-// one block per segment: tile_off[tile] = {absolute byte offset, k-mer offset relative to task}
-__global__ __launch_bounds__(EXP_THREADS) void expand_scan_kernel(const ExpSeg *segs, int nseg, u64 ntiles_total, const u64 *tile_sum, u64 *tile_off)
+// one block per (segment, task): tile_off[tile] = {absolute byte offset, k-mer offset relative to task};
+// 8 consecutive tiles per thread and step
+__global__ __launch_bounds__(EXP_THREADS) void expand_scan_kernel(ExpandPrepArgs a)
 {
+    constexpr int IPT = 8;
     __shared__ u64 s_scr[8];
     __shared__ u64 s_carry[2];
-    const int sg = blockIdx.x;
-    const ExpSeg seg = segs[sg];
+    const int ti = blockIdx.y, sg = blockIdx.x;
+    if (sg >= a.nseg[ti]) return;
+    const ExpSeg seg = a.segs[ti][sg];
+    const u64 *tile_sum = a.tile_sum[ti]; u64 *tile_off = a.tile_off[ti];
     const u64 t0 = seg.tile_start;
-    const u64 t1 = (sg + 1 < nseg) ? segs[sg + 1].tile_start : ntiles_total;
+    const u64 t1 = (sg + 1 < a.nseg[ti]) ? a.segs[ti][sg + 1].tile_start : a.ntiles[ti];
     if (threadIdx.x == 0) { s_carry[0] = seg.byte_off; s_carry[1] = seg.kmer_off; }
     __syncthreads();
-    for (u64 base = t0; base < t1; base += EXP_THREADS) {
-        const u64 t = base + threadIdx.x;
-        u64 b = 0, kk = 0;
-        if (t < t1) { b = tile_sum[2 * t]; kk = tile_sum[2 * t + 1]; }
+    for (u64 base = t0; base < t1; base += (u64)EXP_THREADS * IPT) {
+        const u64 tf = base + (u64)threadIdx.x * IPT;
+        u64 b[IPT], kk[IPT], sb = 0, sk = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const u64 t = tf + i;
+            b[i] = 0; kk[i] = 0;
+            if (t < t1) { b[i] = tile_sum[2 * t]; kk[i] = tile_sum[2 * t + 1]; }
+            sb += b[i]; sk += kk[i];
+        }
         u64 tb, tk;
-        u64 eb = block_excl_scan_256<u64>(b, s_scr, &tb);
-        u64 ek = block_excl_scan_256<u64>(kk, s_scr, &tk);
-        if (t < t1) { tile_off[2 * t] = s_carry[0] + eb; tile_off[2 * t + 1] = s_carry[1] + ek; }
+        u64 eb = block_excl_scan_256<u64>(sb, s_scr, &tb) + s_carry[0];
+        u64 ek = block_excl_scan_256<u64>(sk, s_scr, &tk) + s_carry[1];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const u64 t = tf + i;
+            if (t < t1) { tile_off[2 * t] = eb; tile_off[2 * t + 1] = ek; }
+            eb += b[i]; ek += kk[i];
+        }
         __syncthreads();
         if (threadIdx.x == 0) { s_carry[0] += tb; s_carry[1] += tk; }
         __syncthreads();
@@ -103,87 +127,136 @@ __device__ __forceinline__ void load_window(const u64 *p8, u64 bit, u64 nwords, 
 }
 
 // The k-mers of a tile are produced by WORK ITEMS: a supermer of n k-mers is cut into ceil(n / 8) items of up to
-// 8 consecutive k-mers.  A lane takes one item: it pulls a window of the base stream once (all loads of a lane are
-// issued together, nothing waits inside the roll) and then ROLLS: the forward k-mer is the window shifted by one
-// base per step, its twin is shifted the other way with the complement of the entering base on top
-// (the reference recomputes Kmer::GetTwin per k-mer, include/kmer.hpp:266-296).  The 256 items of one step cover a
-// contiguous range of at most 2048 output records; they pass through an LDS buffer so that the global stores are
-// coalesced (consecutive lanes, consecutive records).
+// 8 consecutive k-mers.  A lane takes one item (item -> supermer through a map the tile prologue writes to LDS):
+// it pulls a window of the base stream once (all loads of a lane are issued together) and then ROLLS: the forward
+// k-mer is the window shifted by one base per step, its twin is shifted the other way with the complement of the
+// entering base on top (the reference recomputes Kmer::GetTwin per k-mer, include/kmer.hpp:266-296).
+//
+// Output order inside a task is free (the sort follows), so nothing is staged: the 64 items of a wave own one
+// contiguous range of the task's key array (items are consecutive), and the wave fills it ROUND-MAJOR: in round r
+// the lanes that still have an r-th k-mer store to consecutive slots (rank = popcount of the ballot below the
+// lane).  Every store instruction of a wave writes one contiguous run of up to 512 bytes; no LDS, no barrier.
+//
+// One launch expands up to EXP_BATCH tasks (the batch the sort takes next).  Workgroups are persistent and the
+// blockIdx -> (task, tile) map is XCD-aware: the dispatcher deals workgroups round-robin over the 8 XCDs, XCD x
+// takes the tile rows x, x+8, ... of ALL tasks of the batch.  Tile row i of every task covers about the same
+// stretch of the packed reads (a task's supermers are in read order), so a 128-byte line of reads that holds
+// bases of several tasks is fetched from HBM once per batch and hit in that XCD's L2 by the other tasks
+// (one launch per task fetched nearly the whole read set once per TASK: 87 GB for 64 GB of keys written).
+//
+// While the keys are in registers the digit histograms of the radix passes that follow are counted
+// (LDS-privatised, merged with global atomics once per workgroup): the sort needs no histogram pass of its own.
 constexpr int EXP_RUN = 8;                            // k-mers per work item
-constexpr int EXP_OUT = EXP_THREADS * EXP_RUN;        // records per step at most
-constexpr int EXP_OUT_LDS = EXP_OUT + EXP_OUT / 8;    // one pad record per 8 (items start 8 records apart: spreads the banks)
+constexpr int EXP_MAX_ITEMS = EXP_TILE * 16;          // a supermer has at most 128 k-mers (SUPERMER_CUT)
+constexpr int EXP_BATCH = 8;
+
+struct ExpandTask {
+    const ExpSeg *segs; int nseg; u32 pad_;
+    const u8 *sm_len; const u64 *src8; u64 src_bit0, src_words;
+    const u64 *sm_gpos; const u32 *sm_pos; const int32_t *sm_rid;
+    const u64 *tile_off; u64 ntiles;
+    u64 *keys_out, *vals_out;
+    u64 *ghist;                    // [npass][256] digit histograms of this task (null: none)
+};
+struct ExpandArgs { ExpandTask t[EXP_BATCH]; int ntask, k; u32 row_workers; int npass; PassDesc pass[MAX_PASSES]; };
 
 template <int NW, bool EXT>
-__global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *src8, u64 src_bit0, u64 src_words,
-                                                              const u64 *sm_gpos, const u32 *sm_pos, const int32_t *sm_rid, const u64 *tile_off,
-                                                              int k, u64 *keys_out, u64 *vals_out)
+__global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
 {
     __shared__ u32 s_boff[EXP_TILE + 1];
     __shared__ u32 s_koff[EXP_TILE + 1];
     __shared__ u32 s_ioff[EXP_TILE + 1];
+    __shared__ u16 s_isup[EXP_MAX_ITEMS];
+    __shared__ u64 s_gpos[EXP_TILE];                                  // first base of every supermer of the tile (reference mode)
     __shared__ u32 s_scr[8];
-    __shared__ u32 s_rng[2];
-    __shared__ u64 s_out[EXP_OUT_LDS];
-    const u64 tile = blockIdx.x;
-    const int sg = seg_of_tile(segs, nseg, tile);
-    const ExpSeg seg = segs[sg];
-    const u64 first = (tile - seg.tile_start) * EXP_TILE;
-    const u32 ns = (u32)((seg.n_sup - first) < (u64)EXP_TILE ? (seg.n_sup - first) : (u64)EXP_TILE);
+    extern __shared__ __attribute__((aligned(16))) u32 s_hist[];       // [npass][256]
     const int tid = threadIdx.x;
-
-    // blocked arrangement: thread t owns supermers [t*SPT, t*SPT+SPT) of the tile
-    u32 nb[EXP_SPT], nk[EXP_SPT], sb = 0, sk = 0, si = 0;
-#pragma unroll
-    for (int i = 0; i < EXP_SPT; ++i) {
-        u32 s = tid * EXP_SPT + i;
-        u32 len = (s < ns) ? sm_len[seg.sup_off + first + s] : 0;
-        nb[i] = (s < ns) ? ((len + 3) >> 2) : 0;
-        nk[i] = (s < ns) ? (len - k + 1) : 0;
-        sb += nb[i]; sk += nk[i]; si += (nk[i] + EXP_RUN - 1) / EXP_RUN;
-    }
-    u32 totb, totk, toti;
-    u32 eb = block_excl_scan_256<u32>(sb, s_scr, &totb);
-    u32 ek = block_excl_scan_256<u32>(sk, s_scr, &totk);
-    u32 ei = block_excl_scan_256<u32>(si, s_scr, &toti);
-#pragma unroll
-    for (int i = 0; i < EXP_SPT; ++i) {
-        s_boff[tid * EXP_SPT + i] = eb; s_koff[tid * EXP_SPT + i] = ek; s_ioff[tid * EXP_SPT + i] = ei;
-        eb += nb[i]; ek += nk[i]; ei += (nk[i] + EXP_RUN - 1) / EXP_RUN;
-    }
-    if (tid == EXP_THREADS - 1) { s_boff[EXP_TILE] = eb; s_koff[EXP_TILE] = ek; s_ioff[EXP_TILE] = ei; }
-    __syncthreads();
-
-    const u64 byte_abs = tile_off[2 * tile];
-    const u64 kbase = tile_off[2 * tile + 1];
+    const u32 xcd = blockIdx.x & 7u, wk = blockIdx.x >> 3;
+    const u32 ti = wk % (u32)a.ntask, row0 = wk / (u32)a.ntask;
+    const ExpandTask &t = a.t[ti];
+    const int k = a.k;
+    const bool do_hist = t.ghist != nullptr && a.npass > 0;
+    if (do_hist) for (int i = tid; i < a.npass * 256; i += EXP_THREADS) s_hist[i] = 0;
     const int low = 64 * NW - 2 * k;                      // unused low bits of the last word; 0 < low < 64 (k % 32 != 0)
     const u64 lastmask = ~0ULL << low;
+    __syncthreads();
 
-    for (u32 it0 = 0; it0 < toti; it0 += EXP_THREADS) {
-        const u32 item = it0 + tid;
-        const bool valid = item < toti;
-        u32 cnt = 0, out0 = 0;
-        u64 keys[EXP_RUN][NW];
-        u64 vals[EXT ? EXP_RUN : 1];
-        if (valid) {
-            u32 lo = 0, hi = ns;                           // last supermer whose first item is <= item (every supermer has >= 1 item)
-            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_ioff[mid] <= item) lo = mid; else hi = mid; }
-            const u32 sidx = lo;
-            const u32 i0 = (item - s_ioff[sidx]) * EXP_RUN;
-            const u32 k0 = s_koff[sidx];
-            const u32 nks = s_koff[sidx + 1] - k0;
-            cnt = nks - i0 < (u32)EXP_RUN ? nks - i0 : (u32)EXP_RUN;
-            out0 = k0 + i0;
-            const u64 sabs = seg.sup_off + first + sidx;
-            const u64 bit = sm_gpos ? (src_bit0 + 2 * (sm_gpos[sabs] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+    for (u64 tile = xcd + 8ULL * row0; tile < t.ntiles; tile += 8ULL * a.row_workers) {
+        const int sg = seg_of_tile(t.segs, t.nseg, tile);
+        const ExpSeg seg = t.segs[sg];
+        const u64 first = (tile - seg.tile_start) * EXP_TILE;
+        const u32 ns = (u32)((seg.n_sup - first) < (u64)EXP_TILE ? (seg.n_sup - first) : (u64)EXP_TILE);
+
+        // ---- prologue: blocked arrangement, thread t owns supermers [t*SPT, t*SPT+SPT) of the tile -------------
+        u32 nb[EXP_SPT], nk[EXP_SPT], sb = 0, sk = 0, si = 0;
+#pragma unroll
+        for (int i = 0; i < EXP_SPT; ++i) {
+            const u32 s = tid * EXP_SPT + i;
+            const u32 len = (s < ns) ? t.sm_len[seg.sup_off + first + s] : 0;
+            nb[i] = (s < ns) ? ((len + 3) >> 2) : 0;
+            nk[i] = (s < ns) ? (len - k + 1) : 0;
+            sb += nb[i]; sk += nk[i]; si += (nk[i] + EXP_RUN - 1) / EXP_RUN;
+        }
+        u32 totb, totk, toti;
+        u32 eb = block_excl_scan_256<u32>(sb, s_scr, &totb);
+        u32 ek = block_excl_scan_256<u32>(sk, s_scr, &totk);
+        u32 ei = block_excl_scan_256<u32>(si, s_scr, &toti);
+#pragma unroll
+        for (int i = 0; i < EXP_SPT; ++i) {
+            const u32 s = tid * EXP_SPT + i;
+            const u32 ni = (nk[i] + EXP_RUN - 1) / EXP_RUN;
+            s_boff[s] = eb; s_koff[s] = ek; s_ioff[s] = ei;
+            if (t.sm_gpos && s < ns) s_gpos[s] = t.sm_gpos[seg.sup_off + first + s];
+            for (u32 j = 0; j < ni; ++j) s_isup[ei + j] = (u16)s;        // item -> supermer
+            eb += nb[i]; ek += nk[i]; ei += ni;
+        }
+        if (tid == EXP_THREADS - 1) { s_boff[EXP_TILE] = eb; s_koff[EXP_TILE] = ek; s_ioff[EXP_TILE] = ei; }
+        __syncthreads();
+
+        const u64 byte_abs = t.tile_off[2 * tile];
+        const u64 kbase = t.tile_off[2 * tile + 1];
+
+        // The window of step s+1 is requested before step s is computed (two dependent memory latencies per step
+        // -- item -> position -> bases -- would otherwise sit in front of every 8 rounds of arithmetic).
+        u32 n_cnt = 0, n_out0 = 0, n_sh = 0; u64 n_vbase = 0; u64 n_raw[NW + 2];
+        auto fetch = [&](u32 item) {
+            n_cnt = 0; n_out0 = 0; n_sh = 0; n_vbase = 0;
+#pragma unroll
+            for (int x = 0; x < NW + 2; ++x) n_raw[x] = 0;
+            if (item < toti) {
+                const u32 sidx = s_isup[item];
+                const u32 i0 = (item - s_ioff[sidx]) * EXP_RUN;
+                const u32 k0 = s_koff[sidx];
+                const u32 nks = s_koff[sidx + 1] - k0;
+                n_cnt = nks - i0 < (u32)EXP_RUN ? nks - i0 : (u32)EXP_RUN;
+                n_out0 = k0 + i0;
+                const u64 bit = t.sm_gpos ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+                const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
+#pragma unroll
+                for (int x = 0; x < NW + 2; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+                if (EXT) { const u64 sabs = seg.sup_off + first + sidx; n_vbase = (u64)(t.sm_pos[sabs] + i0) | ((u64)(u32)t.sm_rid[sabs] << 32); }
+            }
+        };
+        fetch(tid);
+        for (u32 it0 = 0; it0 < toti; it0 += EXP_THREADS) {
+            const u32 cnt = n_cnt, out0 = n_out0; const u64 vbase = n_vbase;
             u64 win[NW + 1];
-            load_window<NW>(src8, bit, src_words, win);
-            u64 vbase = 0;
-            if (EXT) vbase = (u64)(sm_pos[sabs] + i0) | ((u64)(u32)sm_rid[sabs] << 32);
+            {
+                u64 aw[NW + 2];
+#pragma unroll
+                for (int x = 0; x < NW + 2; ++x) aw[x] = __builtin_bswap64(n_raw[x]);
+#pragma unroll
+                for (int x = 0; x < NW + 1; ++x) win[x] = n_sh ? ((aw[x] << n_sh) | (aw[x + 1] >> (64 - n_sh))) : aw[x];
+            }
+            if (it0 + EXP_THREADS < toti) fetch(it0 + EXP_THREADS + tid);
             Mer<NW> fw, rc;
 #pragma unroll
             for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
             fw.w[NW - 1] &= lastmask;
             rc = twin<NW>(fw, k);
+            // the wave's items are consecutive: their k-mers fill [wbase, wbase + sum of cnt) of the tile's range
+            const u32 wbase = (u32)__shfl((int)out0, 0, WAVE);
+            u32 run = 0;
 #pragma unroll
             for (int r = 0; r < EXP_RUN; ++r) {
                 if (r > 0) {
@@ -200,31 +273,41 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(const ExpSeg *segs,
                     rc.w[0] = (rc.w[0] >> 2) | ((3 - nbase) << 62);
                     rc.w[NW - 1] &= lastmask;
                 }
-                const bool use_rc = mer_less<NW>(rc, fw);
+                const bool act = (u32)r < cnt;
+                const u64 m = __ballot(act);
+                if (m == 0) break;                                    // uniform: no lane of the wave has an r-th k-mer
+                if (act) {
+                    const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+                    const u64 o = kbase + wbase + run + below;
+                    const bool use_rc = mer_less<NW>(rc, fw);
+                    u64 key[NW];
 #pragma unroll
-                for (int x = 0; x < NW; ++x) keys[r][x] = use_rc ? rc.w[x] : fw.w[x];
-                if (EXT) vals[r] = vbase + (u64)r;         // pos + r (the low word never carries: pos < read length)
+                    for (int x = 0; x < NW; ++x) key[x] = use_rc ? rc.w[x] : fw.w[x];
+                    if (NW == 2) *reinterpret_cast<ulonglong2 *>(t.keys_out + o * 2) = make_ulonglong2(key[0], key[NW - 1]);
+                    else {
+#pragma unroll
+                        for (int x = 0; x < NW; ++x) t.keys_out[o * NW + x] = key[x];
+                    }
+                    if (EXT) t.vals_out[o] = vbase + (u64)r;          // pos + r (the low word never carries: pos < read length)
+                    if (do_hist) {
+                        for (int p = 0; p < a.npass; ++p) {
+                            const PassDesc pd = a.pass[p];
+                            const u32 d = (u32)(pick_word<NW>(key, pd.word) >> pd.shift) & ((1u << pd.bits) - 1);
+                            atomicAdd(&s_hist[p * 256 + d], 1u);
+                        }
+                    }
+                }
+                run += (u32)__popcll(m);
             }
         }
-        if (tid == 0) s_rng[0] = out0;
-        if (valid && (tid == EXP_THREADS - 1 || item + 1 == toti)) s_rng[1] = out0 + cnt;
+        __syncthreads();                                              // the next tile's prologue rewrites the LDS tables
+    }
+    if (do_hist) {
         __syncthreads();
-        const u32 o0 = s_rng[0], nout = s_rng[1] - o0;
-        const u32 q0 = out0 - o0;                          // first record of this lane's item inside the step's range
-        // one key word (or the payload) at a time through the LDS buffer
-#pragma unroll
-        for (int x = 0; x < NW + (EXT ? 1 : 0); ++x) {
-            if (x > 0) __syncthreads();
-#pragma unroll
-            for (int r = 0; r < EXP_RUN; ++r)
-                if ((u32)r < cnt) { const u32 q = q0 + r; s_out[q + (q >> 3)] = (x < NW) ? keys[r][x < NW ? x : 0] : vals[EXT ? r : 0]; }
-            __syncthreads();
-            for (u32 q = tid; q < nout; q += EXP_THREADS) {
-                const u64 v = s_out[q + (q >> 3)];
-                if (x < NW) keys_out[(kbase + o0 + q) * NW + x] = v; else vals_out[kbase + o0 + q] = v;
-            }
+        for (int i = tid; i < a.npass * 256; i += EXP_THREADS) {
+            const u32 cv = s_hist[i];
+            if (cv) atomicAdd((unsigned long long *)&t.ghist[i], (unsigned long long)cv);
         }
-        __syncthreads();
     }
 }
 

@@ -26,20 +26,10 @@ namespace hsk {
 
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
-constexpr int MAX_PASSES = 24;
 
 template <int NW> struct SortTile { static constexpr int KPT = 16 / NW; static constexpr int TILE = SORT_THREADS * KPT; };
 template <> struct SortTile<3> { static constexpr int KPT = 5; static constexpr int TILE = SORT_THREADS * 5; };
 
-struct PassDesc { int word; int shift; int bits; };
-
-// k[word] without dynamic register indexing (which would spill the key array to scratch)
-template <int NW> __device__ __forceinline__ u64 pick_word(const u64 *k, int word)
-{
-    if (NW == 1) return k[0];
-    if (NW == 2) return word == 0 ? k[0] : k[1];
-    return word == 0 ? k[0] : (word == 1 ? k[1] : k[NW - 1]);
-}
 
 struct HistArgs {
     const u64 *keys; u64 n; int npass; PassDesc pass[MAX_PASSES];
