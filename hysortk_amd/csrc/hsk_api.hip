@@ -528,6 +528,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
     u32 rw = (u32)std::max(1, occ * 256 / (8 * nt));
     rw = (u32)std::min<u64>(rw, (max_tiles + 7) / 8);
     a.row_workers = std::max<u32>(rw, 1);
+    a.nrows = max_tiles;
     const u32 grid = 8u * (u32)nt * a.row_workers;
     if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);
     else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);

@@ -158,7 +158,7 @@ struct ExpandTask {
     u64 *keys_out, *vals_out;
     u64 *ghist;                    // [npass][256] digit histograms of this task (null: none)
 };
-struct ExpandArgs { ExpandTask t[EXP_BATCH]; int ntask, k; u32 row_workers; int npass; PassDesc pass[MAX_PASSES]; };
+struct ExpandArgs { ExpandTask t[EXP_BATCH]; int ntask, k; u32 row_workers; int npass; u64 nrows; PassDesc pass[MAX_PASSES]; };
 
 template <int NW, bool EXT>
 __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
@@ -181,7 +181,11 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
     const u64 lastmask = ~0ULL << low;
     __syncthreads();
 
-    for (u64 tile = xcd + 8ULL * row0; tile < t.ntiles; tile += 8ULL * a.row_workers) {
+    // rows are PROPORTIONAL positions in the tasks' tile lists: row r of a task with n tiles is the tiles
+    // [r * n / nrows, (r + 1) * n / nrows), so that one row of every task reads the same stretch of the packed reads
+    // even though the tasks differ in size by a few percent (nrows = the largest tile count of the batch)
+    for (u64 row = xcd + 8ULL * row0; row < a.nrows; row += 8ULL * a.row_workers)
+    for (u64 tile = row * t.ntiles / a.nrows, tile_hi = (row + 1) * t.ntiles / a.nrows; tile < tile_hi; ++tile) {
         const int sg = seg_of_tile(t.segs, t.nseg, tile);
         const ExpSeg seg = t.segs[sg];
         const u64 first = (tile - seg.tile_start) * EXP_TILE;

@@ -7,4 +7,4 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print('value %.3f G k-mers/s  ms/step %.1f' % (d['value']/1e9, d['ms_per_step']))
 print({k: round(v,1) for k,v in d['phases_ms_per_step'].items()})
-r=d['roofline']; print('onesweep %.0f GB/s frac %.3f avg %.3f ms; hist %.0f GB/s' % (r['achieved'], r['frac'], r['avg_launch_ms'], r['hist_GBs'])); print('agg %s GB/s, %s ms/launch' % (r.get('agg_GBs'), r.get('agg_avg_launch_ms')))"
+r=d["roofline"]; print("onesweep %.0f GB/s frac %.3f avg %.3f ms" % (r["achieved"], r["frac"], r["avg_launch_ms"])); print("agg %s GB/s, %s ms/launch" % (r.get("agg_GBs"), r.get("agg_avg_launch_ms")))"
