@@ -138,8 +138,8 @@ static void ev_put(hsk_ctx *c, hipEvent_t e) { c->ev_free.push_back(e); }
 struct PhaseTimer {
     hsk_ctx *c; std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[8];
     explicit PhaseTimer(hsk_ctx *c_) : c(c_) {}
-    void begin(int ph) { hipEvent_t a = ev_get(c); (void)hipEventRecord(a, c->stream); pairs[ph].push_back({a, nullptr}); }
-    void end(int ph) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream); pairs[ph].back().second = b; }
+    void begin(int ph, hipStream_t s = nullptr) { hipEvent_t a = ev_get(c); (void)hipEventRecord(a, s ? s : c->stream); pairs[ph].push_back({a, nullptr}); }
+    void end(int ph, hipStream_t s = nullptr) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, s ? s : c->stream); pairs[ph].back().second = b; }
     double collect(int ph)
     {
         double ms = 0;
@@ -458,24 +458,28 @@ static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
 struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr; };
 
 // tile sums + scans of n <= EXP_PREP_BATCH tasks with two launches
-static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, const u8 *const *sm_len, ExpandScratch *x)
+static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, const u8 *const *sm_len, ExpandScratch *x,
+                                hipStream_t stream = nullptr, bool prealloc = false)
 {
+    if (!stream) stream = c->stream;
     ExpandPrepArgs pa; memset(&pa, 0, sizeof pa);
     pa.k = c->cfg.kmer_size;
     u64 max_tiles = 0; int max_seg = 0;
     for (int i = 0; i < n; ++i) {
         const int nseg = (int)ts[i]->segs.size();
-        DALLOC(c, x[i].d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
-        DALLOC(c, x[i].d_tile_sum, u64 *, ts[i]->ntiles * 16);
-        DALLOC(c, x[i].d_tile_off, u64 *, ts[i]->ntiles * 16);
-        HIPCHK(c, hipMemcpyAsync(x[i].d_segs, ts[i]->segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, c->stream));
+        if (!prealloc) {
+            DALLOC(c, x[i].d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
+            DALLOC(c, x[i].d_tile_sum, u64 *, ts[i]->ntiles * 16);
+            DALLOC(c, x[i].d_tile_off, u64 *, ts[i]->ntiles * 16);
+        }
+        HIPCHK(c, hipMemcpyAsync(x[i].d_segs, ts[i]->segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, stream));
         pa.segs[i] = x[i].d_segs; pa.nseg[i] = nseg; pa.sm_len[i] = sm_len[i]; pa.ntiles[i] = ts[i]->ntiles;
         pa.tile_sum[i] = x[i].d_tile_sum; pa.tile_off[i] = x[i].d_tile_off;
         max_tiles = std::max(max_tiles, ts[i]->ntiles); max_seg = std::max(max_seg, nseg);
     }
     if (max_tiles == 0) return HSK_OK;
-    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)max_tiles, n), dim3(EXP_THREADS), 0, c->stream, pa);
-    hipLaunchKernelGGL(expand_scan_kernel, dim3(max_seg, n), dim3(EXP_THREADS), 0, c->stream, pa);
+    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)max_tiles, n), dim3(EXP_THREADS), 0, stream, pa);
+    hipLaunchKernelGGL(expand_scan_kernel, dim3(max_seg, n), dim3(EXP_THREADS), 0, stream, pa);
     return HSK_OK;
 }
 static int expand_prepare(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, ExpandScratch &x)
@@ -490,17 +494,20 @@ static void expand_release(hsk_ctx *c, ExpandScratch &x) { c->pool.release(x.d_s
 struct ExpandJob { const TaskSegs *ts; const u8 *sm_len; BaseSource src; const u32 *sm_pos; const int32_t *sm_rid; u64 *keys, *vals, *ghist; };
 
 template <int NW>
-static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass = 0, const PassDesc *plan = nullptr)
+static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass = 0, const PassDesc *plan = nullptr,
+                        hipStream_t stream = nullptr, ExpandScratch *pre = nullptr)
 {
     const bool ext = c->cfg.extension != 0;
+    if (!stream) stream = c->stream;
     ExpandArgs a; memset(&a, 0, sizeof a);
-    ExpandScratch x[EXP_BATCH];
+    ExpandScratch xown[EXP_BATCH];
+    ExpandScratch *x = pre ? pre : xown;
     int nt = 0; u64 max_tiles = 0;
     {
         const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH]; int m = 0;
         for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles) { tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; ++m; }
         // (ts.segs is host memory owned by the caller and stays alive until the next sync)
-        int rc = expand_prepare_batch(c, m, tsp, lens, x); if (rc) return rc;
+        int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, pre != nullptr); if (rc) return rc;
     }
     for (int i = 0; i < njobs; ++i) {
         const ExpandJob &j = jobs[i];
@@ -525,15 +532,18 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_kernel<NW, false>, EXP_THREADS, dyn);
         occ = (e == hipSuccess && nb > 0) ? nb : 4;
     }
-    u32 rw = (u32)std::max(1, occ * 256 / (8 * nt));
+    // pipelined with the sort of the previous batch (second stream): take only part of every CU, the rest is the sort's
+    static const int share_pct = getenv("HSK_EXPAND_SHARE") ? atoi(getenv("HSK_EXPAND_SHARE")) : 100;
+    const int occ_use = (stream != c->stream) ? std::max(1, occ * share_pct / 100) : occ;
+    u32 rw = (u32)std::max(1, occ_use * 256 / (8 * nt));
     rw = (u32)std::min<u64>(rw, (max_tiles + 7) / 8);
     a.row_workers = std::max<u32>(rw, 1);
     a.nrows = max_tiles;
     const u32 grid = 8u * (u32)nt * a.row_workers;
-    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);
-    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3(grid), dim3(EXP_THREADS), dyn, c->stream, a);
+    if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3(grid), dim3(EXP_THREADS), dyn, stream, a);
+    else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3(grid), dim3(EXP_THREADS), dyn, stream, a);
     HIPCHK(c, hipGetLastError());
-    for (int i = 0; i < nt; ++i) expand_release(c, x[i]);
+    if (!pre) for (int i = 0; i < nt; ++i) expand_release(c, x[i]);
     return HSK_OK;
 }
 
@@ -1257,54 +1267,97 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
     const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
     const int nsets = batch ? XCD_BATCH : 1;
-    u64 *kA[XCD_BATCH] = {nullptr}, *kB[XCD_BATCH] = {nullptr}, *vA[XCD_BATCH] = {nullptr}, *vB[XCD_BATCH] = {nullptr};
+    // Two batches in flight (single GPU): batch b+1 is expanded on the second stream while batch b is sorted and
+    // counted on the main stream.  The expand kernel waits on memory latency for most of its life, the radix passes
+    // are bandwidth-bound and the aggregation is issue-bound: side by side they fill each other's gaps.  Every
+    // buffer the second stream touches is allocated up front (the pool's reuse rule is per stream).
+    static const bool pipe_enabled = !(getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) == 0);
+    const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
+    const int nslot = piped ? 2 : 1;
+    u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
+    u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
     SortScratch sc;
     if (max_task) {
-        for (int i = 0; i < nsets; ++i) {
-            DALLOC(c, kA[i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kB[i], u64 *, max_task * NW * 8 + 64);
-            if (ext) { DALLOC(c, vA[i], u64 *, max_task * 8 + 64); DALLOC(c, vB[i], u64 *, max_task * 8 + 64); }
+        for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
+            DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kBs[sl][i], u64 *, max_task * NW * 8 + 64);
+            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, max_task * 8 + 64); }
         }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
-    u64 *d_ghist_batch = nullptr;
-    if (batch) DALLOC(c, d_ghist_batch, u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    u64 *d_ghist_slot[2] = {nullptr, nullptr};
+    ExpandScratch xpre[2][XCD_BATCH];
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
+    hipStream_t xstream = piped ? c->comm_stream : c->stream;
+    if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    if (piped) {
+        u64 max_tiles = 0; size_t max_seg = 1;
+        for (u32 t : mine) { max_tiles = std::max(max_tiles, segs[t].ntiles); max_seg = std::max(max_seg, segs[t].segs.size()); }
+        for (int sl = 0; sl < 2; ++sl) {
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                DALLOC(c, xpre[sl][i].d_segs, ExpSeg *, sizeof(ExpSeg) * max_seg);
+                DALLOC(c, xpre[sl][i].d_tile_sum, u64 *, max_tiles * 16 + 64);
+                DALLOC(c, xpre[sl][i].d_tile_off, u64 *, max_tiles * 16 + 64);
+            }
+            ev_ready[sl] = ev_get(c); ev_done[sl] = ev_get(c);
+        }
+        // everything the pool handed out above may still be in use by earlier main-stream work
+        hipEvent_t fence = ev_get(c);
+        HIPCHK(c, hipEventRecord(fence, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(xstream, fence, 0));
+        ev_put(c, fence);
+    }
     std::vector<TaskOut> touts(ntasks);
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
     { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
     TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
+    const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
+    const bool agg = fused && agg_enabled();
+    const int prefix_bits = agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+    PassDesc plan[MAX_PASSES];
+    const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
+    BatchTask bts[2][XCD_BATCH];
+    // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
+    auto issue_expand = [&](size_t bpos, int sl) -> int {
+        if (piped && done_valid[sl]) HIPCHK(c, hipStreamWaitEvent(xstream, ev_done[sl], 0));     // the slot's previous batch is counted
+        pt.begin(PH_EXTRACT, xstream);
+        HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, xstream));
+        ExpandJob jobs[XCD_BATCH];
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[bpos + i];
+            BatchTask &b = bts[sl][i];
+            b = BatchTask();
+            b.n = segs[t].nkmers; b.kA = kAs[sl][i]; b.kB = kBs[sl][i]; b.vA = vAs[sl][i]; b.vB = vBs[sl][i];
+            const TaskInput in = feeder ? feeder->input(t) : dflt;
+            jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
+            jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
+        }
+        int rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc;
+        pt.end(PH_EXTRACT, xstream);
+        if (piped) HIPCHK(c, hipEventRecord(ev_ready[sl], xstream));
+        return HSK_OK;
+    };
     size_t pos = 0;
-    while (batch && pos + XCD_BATCH <= mine.size()) {
-        BatchTask bt[XCD_BATCH];
+    const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
+    if (piped) { int rc = issue_expand(0, 0); if (rc) return rc; }
+    for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
+        const int sl = piped ? (int)(b & 1) : 0;
         if (feeder) {                                   // exposed (not overlapped) part of the exchange
             pt.begin(PH_EXCH);
             for (int i = 0; i < XCD_BATCH; ++i) { int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
             pt.end(PH_EXCH);
         }
-        const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
-        const bool agg = fused && agg_enabled();
-        const int prefix_bits = agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
-        // one launch expands the eight tasks and counts the digits of the passes that follow
-        PassDesc plan[MAX_PASSES];
-        const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
-        pt.begin(PH_EXTRACT);
-        HIPCHK(c, hipMemsetAsync(d_ghist_batch, 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
-        {
-            ExpandJob jobs[XCD_BATCH];
-            for (int i = 0; i < XCD_BATCH; ++i) {
-                const u32 t = mine[pos + i];
-                bt[i].n = segs[t].nkmers; bt[i].kA = kA[i]; bt[i].kB = kB[i]; bt[i].vA = vA[i]; bt[i].vB = vB[i];
-                const TaskInput in = feeder ? feeder->input(t) : dflt;
-                jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
-                jobs[i].keys = kA[i]; jobs[i].vals = vA[i]; jobs[i].ghist = d_ghist_batch + (size_t)i * MAX_PASSES * 256;
-            }
-            int rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan); if (rc) return rc;
+        if (!piped) { int rc = issue_expand(pos, 0); if (rc) return rc; }
+        else {
+            if (b + 1 < nbatch) { int rc = issue_expand(pos + XCD_BATCH, (int)((b + 1) & 1)); if (rc) return rc; }
+            HIPCHK(c, hipStreamWaitEvent(c->stream, ev_ready[sl], 0));
         }
-        pt.end(PH_EXTRACT);
+        BatchTask *bt = bts[sl];
         if (feeder) feeder->release_below(pos + XCD_BATCH < mine.size() ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_batch); if (rc) return rc; }
+        { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         if (fused) {
@@ -1322,7 +1375,14 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             }
         }
         pt.end(PH_COUNT);
-        pos += XCD_BATCH;
+        if (piped) { HIPCHK(c, hipEventRecord(ev_done[sl], c->stream)); done_valid[sl] = true; }
+    }
+    if (piped) {
+        HIPCHK(c, hipStreamSynchronize(xstream));
+        for (int sl = 0; sl < 2; ++sl) {
+            for (int i = 0; i < XCD_BATCH; ++i) expand_release(c, xpre[sl][i]);
+            ev_put(c, ev_ready[sl]); ev_put(c, ev_done[sl]);
+        }
     }
     for (; pos < mine.size(); ++pos) {
         const u32 t = mine[pos];
@@ -1347,9 +1407,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     {
         int rc = check_device_error(c); if (rc) return rc;
     }
-    for (int i = 0; i < nsets; ++i) { c->pool.release(kA[i]); c->pool.release(kB[i]); c->pool.release(vA[i]); c->pool.release(vB[i]); }
+    for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
     free_sort_scratch(c, sc);
-    c->pool.release(d_ghist_batch);
+    c->pool.release(d_ghist_slot[0]); c->pool.release(d_ghist_slot[1]);
 
     // ---- result ----------------------------------------------------------------------------------------
     pt.begin(PH_D2H);
