@@ -223,6 +223,10 @@ class Context:
         buf = (C.c_char * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
         self._check(self.lib.hsk_comm_init(self.h, comm.size, comm.rank, buf))
 
+    def comm_selftest(self):
+        """One-rank RCCL communicator on this GPU: all-reduce and grouped send/recv to self, results checked."""
+        self._check(self.lib.hsk_comm_selftest(self.h))
+
     # ---- the hot path -----------------------------------------------------------------------------
     def _wrap(self, res):
         n, nw, nt = int(res.n), int(res.nw), int(res.ntasks)

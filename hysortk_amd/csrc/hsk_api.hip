@@ -1999,6 +1999,50 @@ extern "C" int hsk_comm_init(hsk_ctx *c, int nranks, int rank, const void *id128
     if (rc) return fail(c, HSK_ERR_COMM, "RCCL init failed: %s", c->comm.last_error.c_str());
     return HSK_OK;
 }
+// One-rank communicator on this ctx's GPU: every RCCL entry point the exchange uses (unique id, init, all-reduce
+// sum/max of u64, grouped send/recv of bytes to self on the second stream, destroy) with checked results.  This is
+// how the RCCL binding (dlopen'ed symbols, enum values, by-value unique id) is exercised on a single-GPU box.
+extern "C" int hsk_comm_selftest(hsk_ctx *c)
+{
+    if (!c) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    char id[HSK_UNIQUE_ID_BYTES];
+    if (Comm::get_unique_id(id) != 0) return fail(c, HSK_ERR_COMM, "ncclGetUniqueId failed (librccl not loadable?)");
+    Comm cm;
+    int rc = cm.init(1, 0, id, true);
+    if (rc) return fail(c, HSK_ERR_COMM, "RCCL init failed: %s", cm.last_error.c_str());
+    const size_t n = 1 << 20;
+    u64 *d_a; u8 *d_src, *d_dst;
+    DALLOC(c, d_a, u64 *, 4096 * 8); DALLOC(c, d_src, u8 *, n); DALLOC(c, d_dst, u8 *, n);
+    std::vector<u64> h(4096), h2(4096);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = splitmix64(i);
+    std::vector<u8> hs(n), hd(n, 0);
+    for (size_t i = 0; i < n; ++i) hs[i] = (u8)(splitmix64(i) >> 13);
+    int out = HSK_OK;
+    do {
+        if (hipMemcpyAsync(d_a, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_src, hs.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(d_dst, 0, n, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { out = fail(c, HSK_ERR_HIP, "selftest upload"); break; }
+        if ((rc = cm.check(cm.api->AllReduce(d_a, d_a, h.size(), RCCL_UINT64, RCCL_SUM, cm.comm, c->stream), "ncclAllReduce(sum)")) ||
+            (rc = cm.check(cm.api->AllReduce(d_a, d_a, h.size(), RCCL_UINT64, RCCL_MAX, cm.comm, c->stream), "ncclAllReduce(max)"))) { out = fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str()); break; }
+        if (hipMemcpyAsync(h2.data(), d_a, h.size() * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { out = fail(c, HSK_ERR_HIP, "selftest download"); break; }
+        if (h2 != h) { out = fail(c, HSK_ERR_COMM, "one-rank all-reduce changed the data"); break; }
+        // two messages to self inside one group, on the second stream (as post_exchange does per peer and array)
+        hipStream_t s = c->comm_stream;
+        if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart")) ||
+            (rc = cm.check(cm.api->Send(d_src, n / 2, RCCL_UINT8, 0, cm.comm, s), "ncclSend")) ||
+            (rc = cm.check(cm.api->Send(d_src + n / 2, n - n / 2, RCCL_UINT8, 0, cm.comm, s), "ncclSend")) ||
+            (rc = cm.check(cm.api->Recv(d_dst, n / 2, RCCL_UINT8, 0, cm.comm, s), "ncclRecv")) ||
+            (rc = cm.check(cm.api->Recv(d_dst + n / 2, n - n / 2, RCCL_UINT8, 0, cm.comm, s), "ncclRecv")) ||
+            (rc = cm.check(cm.api->GroupEnd(), "ncclGroupEnd"))) { out = fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str()); break; }
+        if (hipMemcpyAsync(hd.data(), d_dst, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { out = fail(c, HSK_ERR_HIP, "selftest download"); break; }
+        if (hd != hs) { out = fail(c, HSK_ERR_COMM, "grouped send/recv to self delivered different bytes"); break; }
+    } while (0);
+    cm.destroy();
+    c->pool.release(d_a); c->pool.release(d_src); c->pool.release(d_dst);
+    return out;
+}
+
 extern "C" int hsk_comm_destroy(hsk_ctx *c)
 {
     if (!c) return HSK_ERR_INVALID_ARG;

@@ -82,11 +82,11 @@ struct Comm {
         if (!a) return -1;
         return a->GetUniqueId(id128);
     }
-    int init(int nranks_, int rank_, const void *id128)
+    int init(int nranks_, int rank_, const void *id128, bool even_alone = false)
     {
         destroy();
         nranks = nranks_; rank = rank_;
-        if (nranks_ == 1) return 0;
+        if (nranks_ == 1 && !even_alone) return 0;
         api = rccl_api(&last_error);
         if (!api) return -1;
         UidByValue id; memcpy(id.internal, id128, 128);

@@ -205,6 +205,9 @@ int hsk_plan_exchange(int nranks, int rank, int ntasks, const int32_t *owner, co
 int hsk_comm_get_unique_id(void *id128);                       /* rank 0, then broadcast by the caller */
 int hsk_comm_init(hsk_ctx *ctx, int nranks, int rank, const void *id128);
 int hsk_comm_destroy(hsk_ctx *ctx);
+/* One-rank communicator on this GPU: all-reduce and grouped send/recv to self with checked results (exercises the
+ * RCCL binding on a single-GPU box). */
+int hsk_comm_selftest(hsk_ctx *ctx);
 
 /* ---- synthetic reads, generated in HBM (bench / tests) ------------------------------------ */
 /* S-reads(G, c) of BASELINE.md: random genome of genome_len bases, error-free reads of read_len

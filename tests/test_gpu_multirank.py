@@ -113,3 +113,12 @@ def test_overlap_switch_gives_identical_lists():
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert outs[0] == outs[1], outs
     assert int(outs[0][1]) > 10000
+
+
+@pytest.mark.gpu
+def test_rccl_binding_selftest():
+    """The RCCL entry points the exchange uses (dlopen'ed symbols, enum values, by-value unique id, grouped send/recv on the
+    second stream) on a one-rank communicator: the only way to touch them on a single-GPU box."""
+    import hysortk_amd as H
+    with H.Context(K=31, M=17) as c:
+        c.comm_selftest()
