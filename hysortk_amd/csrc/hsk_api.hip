@@ -31,6 +31,7 @@
 #include "hsk_count.h"
 #include "hsk_finish.h"
 #include "hsk_agg.h"
+#include "hsk_heavy.h"
 #include "hsk_synth.h"
 #include "hsk_plan.h"
 #include "hsk_comm.h"
@@ -102,6 +103,7 @@ struct hsk_ctx {
     void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
     u32 *d_err = nullptr;
     Comm comm;
+    bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 
 static int fail(hsk_ctx *c, int code, const char *fmt, ...)
@@ -378,13 +380,15 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
 }
 
 // `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
-static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st)
+// skip (optional, [ntasks]): tasks whose supermers are not stored (they take no room and report zero totals)
+static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st, const std::vector<u8> *skip = nullptr)
 {
     const bool ext = c->cfg.extension != 0;
     const u32 ntasks = j.ntasks;
     st = SupermerStore();
     st.ntasks = ntasks; st.nblocks = j.nblocks; st.order = order;
     st.task_tot = j.task_tot;
+    if (skip) for (u32 t = 0; t < ntasks; ++t) if ((*skip)[t]) st.task_tot[3 * t] = st.task_tot[3 * t + 1] = st.task_tot[3 * t + 2] = 0;
     st.task_base.assign((size_t)ntasks * 3, 0);
     { u64 s = 0, b = 0, k = 0;
       for (u32 i = 0; i < ntasks; ++i) { const u32 t = order[i]; st.task_base[3 * t] = s; st.task_base[3 * t + 1] = b; st.task_base[3 * t + 2] = k;
@@ -398,7 +402,14 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
     DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
     HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_task_tot, d_task_base, d_blk_base);
+    u8 *d_skip = nullptr;
+    if (skip) {
+        DALLOC(c, d_skip, u8 *, ntasks);
+        HIPCHK(c, hipMemcpyAsync(d_skip, skip->data(), ntasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // the mask is host memory of the caller
+    }
+    a.task_skip = d_skip;
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base);
     DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
     DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);          // reference mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
@@ -413,7 +424,8 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     HIPCHK(c, hipGetLastError());
     // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
     // every later user of these blocks is enqueued on the same stream)
-    c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order);
+    c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order); c->pool.release(d_skip);
+    a.task_skip = nullptr;
     return HSK_OK;
 }
 
@@ -874,7 +886,7 @@ static int check_device_error(hsk_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // stage: merge-count one sorted task (a13)
 // ------------------------------------------------------------------------------------------------
-struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; };
+struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; bool failed = false; };
 
 template <int NW>
 static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n, u64 payoff_add, u64 *d_histo, u32 histo_len, TaskOut &out)
@@ -1007,6 +1019,7 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
     for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i) {
         outs[i] = TaskOut();
         if (bt[i].n == 0) continue;
+        if (h.flags[i] && c->forbid_long_way) { outs[i].failed = true; continue; }
         if (h.flags[i]) {
             // the long way for this task: full-width passes from the current order, then the two-pass counter
             c->stats.redone_tasks++;
@@ -1118,6 +1131,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
+        if (c->forbid_long_way) { outs[i].failed = true; continue; }
         // the long way for this task: full-width passes from the current order, then the two-pass counter
         c->stats.redone_tasks++;
         if (own_scratch[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
@@ -1243,12 +1257,56 @@ static bool overlap_enabled()
     return on;
 }
 
+// ---- heavy-hitter tasks (a8): the owner's side --------------------------------------------------------------
+// d_entries: the {k-mer, count} lists of all ranks for one task, concatenated (n entries, each list key-ordered,
+// a key at most once per list).  Orders them by key with the count as payload, sums equal keys, filters [L, U].
+static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_histo, u32 histo_len, TaskOut &out)
+{
+    out = TaskOut();
+    if (n == 0) return HSK_OK;
+    u64 *kA, *kB, *vA, *vB;
+    DALLOC(c, kA, u64 *, n * 8 + 64); DALLOC(c, kB, u64 *, n * 8 + 64); DALLOC(c, vA, u64 *, n * 8 + 64); DALLOC(c, vB, u64 *, n * 8 + 64);
+    hipLaunchKernelGGL(heavy_split_kernel, dim3((u32)std::min<u64>((n + HV_THREADS - 1) / HV_THREADS, 4096)), dim3(HV_THREADS), 0, c->stream, d_entries, n, kA, vA);
+    SortScratch sc; int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    u64 *sk, *sv;
+    rc = sort_task_device<1>(c, kA, kB, vA, vB, n, c->cfg.kmer_size, sc, &sk, &sv);
+    free_sort_scratch(c, sc);
+    if (rc) return rc;
+    const u64 ntiles = (n + HV_THREADS - 1) / HV_THREADS;
+    u64 *d_tile, *d_total;
+    DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
+    HeavyMergeArgs a; memset(&a, 0, sizeof a);
+    a.keys = sk; a.cnts = sv; a.n = n; a.lower = (u64)c->cfg.lower_freq; a.upper = (u64)c->cfg.upper_freq; a.tile_cnt = d_tile; a.histo = d_histo; a.histo_len = histo_len;
+    hipLaunchKernelGGL(heavy_merge_kernel<false>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out.n = tot[0];
+    if (out.n) {
+        DALLOC(c, out.entries, u64 *, out.n * 16);
+        a.entries = out.entries;
+        hipLaunchKernelGGL(heavy_merge_kernel<true>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pool.release(kA); c->pool.release(kB); c->pool.release(vA); c->pool.release(vB); c->pool.release(d_tile); c->pool.release(d_total);
+    return HSK_OK;
+}
+
+struct HeavyIn { u32 task; u64 *d_entries; u64 n; };       // a heavy task this rank owns: concatenated lists of all ranks
+struct ProcExtra {
+    bool force_batch = false;                              // every task through the batch kernels (partial batches padded)
+    const std::vector<HeavyIn> *heavy_in = nullptr;        // merged and filtered here (they have no supermers)
+};
+
 // Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
 // result of this rank.  `segs[t]` lists where the supermers of task t live (x_len / x_src / x_pos / x_rid).
 template <int NW>
 static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owner, int rank, std::vector<TaskSegs> &segs,
                         const u8 *x_len, const BaseSource &x_src, const u32 *x_pos, const int32_t *x_rid,
-                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open, GroupFeeder *feeder = nullptr)
+                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open, GroupFeeder *feeder = nullptr,
+                        const ProcExtra *ex = nullptr)
 {
     const bool ext = c->cfg.extension != 0;
     const int K = c->cfg.kmer_size;
@@ -1257,7 +1315,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     out->total_kmers = total_kmers;
 
     // ---- per task: expand, sort, count ---------------------------------------------------------------
-    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
+    const u32 histo_len = (u32)std::min<int64_t>((int64_t)c->cfg.upper_freq + 1, 65536);    // (U <= 65535 except in the unfiltered pre-aggregation)
     u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
     HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
     // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
@@ -1265,6 +1323,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
     std::vector<u32> mine;
     for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
+    // A remainder of three or more tasks is padded to a full batch with empty slots (an XCD without a task idles, which
+    // still beats eight full-width passes per task on the single-task path); ex->force_batch pads any remainder.
+    const u32 EMPTY_TASK = ~0u;
+    TaskSegs empty_segs;
+    const bool forced = ex && ex->force_batch && batch_enabled;
+    if ((batch_enabled && mine.size() >= (size_t)XCD_BATCH && mine.size() % XCD_BATCH >= 3) || (forced && !mine.empty()))
+        while (mine.size() % XCD_BATCH) mine.push_back(EMPTY_TASK);
     const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
     const int nsets = batch ? XCD_BATCH : 1;
     // Two batches in flight (single GPU): batch b+1 is expanded on the second stream while batch b is sorted and
@@ -1292,7 +1357,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
     if (piped) {
         u64 max_tiles = 0; size_t max_seg = 1;
-        for (u32 t : mine) { max_tiles = std::max(max_tiles, segs[t].ntiles); max_seg = std::max(max_seg, segs[t].segs.size()); }
+        for (u32 t : mine) { if (t == EMPTY_TASK) continue; max_tiles = std::max(max_tiles, segs[t].ntiles); max_seg = std::max(max_seg, segs[t].segs.size()); }
         for (int sl = 0; sl < 2; ++sl) {
             for (int i = 0; i < XCD_BATCH; ++i) {
                 DALLOC(c, xpre[sl][i].d_segs, ExpSeg *, sizeof(ExpSeg) * max_seg);
@@ -1311,7 +1376,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
-    { u64 acc = 0; for (u32 t : mine) { pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
+    { u64 acc = 0; for (u32 t : mine) { if (t == EMPTY_TASK) continue; pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
     TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
     const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
     const bool agg = fused && agg_enabled();
@@ -1329,7 +1394,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             const u32 t = mine[bpos + i];
             BatchTask &b = bts[sl][i];
             b = BatchTask();
-            b.n = segs[t].nkmers; b.kA = kAs[sl][i]; b.kB = kBs[sl][i]; b.vA = vAs[sl][i]; b.vB = vBs[sl][i];
+            b.kA = kAs[sl][i]; b.kB = kBs[sl][i]; b.vA = vAs[sl][i]; b.vB = vBs[sl][i];
+            if (t == EMPTY_TASK) { jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs; continue; }
+            b.n = segs[t].nkmers;
             const TaskInput in = feeder ? feeder->input(t) : dflt;
             jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
@@ -1346,7 +1413,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         const int sl = piped ? (int)(b & 1) : 0;
         if (feeder) {                                   // exposed (not overlapped) part of the exchange
             pt.begin(PH_EXCH);
-            for (int i = 0; i < XCD_BATCH; ++i) { int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
+            for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK) continue; int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
             pt.end(PH_EXCH);
         }
         if (!piped) { int rc = issue_expand(pos, 0); if (rc) return rc; }
@@ -1355,7 +1422,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             HIPCHK(c, hipStreamWaitEvent(c->stream, ev_ready[sl], 0));
         }
         BatchTask *bt = bts[sl];
-        if (feeder) feeder->release_below(pos + XCD_BATCH < mine.size() ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
+        if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         pt.begin(PH_SORT);
         { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
@@ -1366,11 +1433,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 int rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo)
                              : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
                 if (rc) return rc;
-                for (int i = 0; i < XCD_BATCH; ++i) touts[mine[pos + i]] = fo[i];
+                for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
             }
         } else {
             for (int i = 0; i < XCD_BATCH; ++i) {
                 const u32 t = mine[pos + i];
+                if (t == EMPTY_TASK) continue;
                 int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
             }
         }
@@ -1402,7 +1470,16 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
         pt.end(PH_COUNT);
     }
-    for (u32 t : mine) { n_total += touts[t].n; pay_total += touts[t].npay; }
+    // heavy-hitter tasks this rank owns arrive as k-mer lists: order, sum, filter
+    if (ex && ex->heavy_in) {
+        pt.begin(PH_COUNT);
+        for (const HeavyIn &hv : *ex->heavy_in) {
+            if constexpr (NW == 1) { int rc = heavy_merge_task(c, hv.d_entries, hv.n, d_histo, histo_len, touts[hv.task]); if (rc) return rc; }
+            mine.push_back(hv.task);
+        }
+        pt.end(PH_COUNT);
+    }
+    for (u32 t : mine) { if (t == EMPTY_TASK) continue; n_total += touts[t].n; pay_total += touts[t].npay; }
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     {
         int rc = check_device_error(c); if (rc) return rc;
@@ -1457,6 +1534,59 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     out->ms_extract = pt.collect(PH_EXTRACT); out->ms_sort = pt.collect(PH_SORT); out->ms_count = pt.collect(PH_COUNT);
     out->ms_d2h = pt.collect(PH_D2H);
     return HSK_OK;
+}
+
+// ---- heavy-hitter tasks (a8): the sending side ----------------------------------------------------------------
+// HeavyHitterClassifier (reference src/kmerops.cpp:1157-1199) on the GLOBAL k-mer counts; forced plain with
+// EXTENSION or PLAIN_CLASSIFIER (kmerops.cpp:109-113) and, here, for keys of more than one word.
+static bool heavy_enabled(hsk_ctx *c, int nw, int nranks)
+{
+    static const bool env_on = !(getenv("HSK_HEAVY") && atoi(getenv("HSK_HEAVY")) == 0);
+    return env_on && nranks > 1 && nw == 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0 &&
+           hybrid_enabled() && finish_enabled() && agg_enabled();
+}
+static double heavy_ratio() { static const double r = getenv("HSK_UNBALANCED_RATIO") ? atof(getenv("HSK_UNBALANCED_RATIO")) : 2.3; return r; }
+
+// Every rank turns its OWN supermers of the heavy tasks into unfiltered {k-mer, count} lists (ScatteredKmerList,
+// kmerops.cpp:363-398): only the heavy tasks are placed, then the ordinary expand / sort / aggregate kernels run with
+// L = 1, U = max.  lists[t] stays in HBM; failed[t] = the aggregating finish could not handle the task (it is then
+// sent as supermers like any other task -- on every rank, the flags are combined by the caller).
+template <int NW>
+static int heavy_preaggregate(hsk_ctx *c, ParseJob &job, const u8 *d_packed, u64 packed_bytes, const std::vector<u8> &is_heavy,
+                              std::vector<TaskOut> &lists, std::vector<u8> &failed)
+{
+    const u32 ntasks = job.ntasks;
+    lists.assign(ntasks, TaskOut()); failed.assign(ntasks, 0);
+    std::vector<u32> order; std::vector<u8> skip(ntasks, 0);
+    for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t]) order.push_back(t);
+    for (u32 t = 0; t < ntasks; ++t) if (!is_heavy[t]) { order.push_back(t); skip[t] = 1; }
+    SupermerStore sth;
+    int rc = parse_place(c, job, order, sth, &skip); if (rc) return rc;
+    std::vector<TaskSegs> segs(ntasks);
+    std::vector<int32_t> own(ntasks, -1);
+    for (u32 t = 0; t < ntasks; ++t) {
+        if (!is_heavy[t]) continue;
+        own[t] = 0;
+        if (sth.task_tot[3 * t] == 0) continue;
+        ExpSeg sg; sg.sup_off = sth.task_base[3 * t]; sg.n_sup = sth.task_tot[3 * t]; sg.byte_off = sth.task_base[3 * t + 1]; sg.kmer_off = 0; sg.tile_start = 0;
+        segs[t].segs.push_back(sg); segs[t].nkmers = sth.task_tot[3 * t + 2];
+    }
+    const hsk_config keep = c->cfg;
+    c->cfg.lower_freq = 1; c->cfg.upper_freq = INT32_MAX; c->cfg.flags |= HSK_FLAG_KEEP_DEVICE;
+    c->forbid_long_way = true;
+    hsk_result tmp; memset(&tmp, 0, sizeof tmp);
+    ResultPriv *rp = new ResultPriv(); tmp.priv = rp; tmp.nw = NW;
+    PhaseTimer pt(c);
+    ProcExtra ex; ex.force_batch = true;
+    rc = process_rank<NW>(c, ntasks, own, 0, segs, sth.sm_len, source_from_packed(d_packed, packed_bytes, sth.sm_gpos), nullptr, nullptr, &tmp, rp, pt, false, nullptr, &ex);
+    c->cfg = keep; c->forbid_long_way = false;
+    if (rc == HSK_OK) {
+        for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t] && t < rp->dev_tasks.size()) { lists[t] = rp->dev_tasks[t]; failed[t] = lists[t].failed ? 1 : 0; }
+        rp->dev_tasks.clear();                              // the lists are ours now
+    }
+    hsk_result_free(c, &tmp);
+    free_store(c, sth);
+    return rc;
 }
 
 template <int NW>
@@ -1574,9 +1704,37 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         if (rc) { release_jobs(); return rc; }
         for (u32 t = 0; t < ntasks; ++t) bytes[t] += jobs[r].task_tot[3 * t + 1] + jobs[r].task_tot[3 * t] * (ext ? 9 : 1);
     }
+    // 1b. heavy-hitter tasks: classify on the global k-mer counts, every rank pre-aggregates its share
+    std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<std::vector<TaskOut>> hlists(R);
+    auto free_hlists = [&]() { for (auto &v : hlists) for (auto &to : v) free_task_out(c, to); };
+    bool any_heavy = false;
+    if (heavy_enabled(c, NW, R)) {
+        std::vector<u64> kg(ntasks, 0); std::vector<int32_t> types(ntasks, 0);
+        for (int r = 0; r < R; ++r) for (u32 t = 0; t < ntasks; ++t) kg[t] += jobs[r].task_tot[3 * t + 2];
+        plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+        for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+    }
+    if (any_heavy) {
+        std::vector<u8> bad(ntasks, 0);
+        for (int r = 0; r < R; ++r) {
+            std::vector<u8> failed;
+            int rc = heavy_preaggregate<NW>(c, jobs[r], in[r].packed, packed_bytes[r], is_heavy, hlists[r], failed);
+            if (rc) { release_jobs(); free_hlists(); return rc; }
+            for (u32 t = 0; t < ntasks; ++t) bad[t] |= failed[t];
+        }
+        any_heavy = false;
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (!is_heavy[t]) continue;
+            if (bad[t]) { is_heavy[t] = 0; for (int r = 0; r < R; ++r) free_task_out(c, hlists[r][t]); continue; }   // travels as supermers after all
+            any_heavy = true; c->stats.heavy_tasks++;
+            bytes[t] = 0;
+            for (int r = 0; r < R; ++r) bytes[t] += hlists[r][t].n * (u64)(NW + 1) * 8;       // ScatteredKmerList::get_size_bytes
+        }
+    }
     std::vector<int32_t> owner(ntasks, 0);
     if (plan_dispatch(bytes.data(), (int)ntasks, R, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data())) {
-        release_jobs();
+        release_jobs(); free_hlists();
         return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
     }
     if (owner_out) memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks);
@@ -1585,12 +1743,33 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<SupermerStore> st(R);
     std::vector<u64> M((size_t)R * ntasks * 3, 0);
     for (int r = 0; r < R; ++r) {
-        int rc = parse_place(c, jobs[r], order, st[r]);
+        int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr);
         parse_release(c, jobs[r]);
         if (rc) { release_jobs(); return rc; }
         rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) { release_jobs(); return rc; }
         for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
     }
+    // 2b. the k-mer lists of the heavy tasks go to their owners (device copies here, send/recv in run_pipeline)
+    std::vector<std::vector<HeavyIn>> hin(R);
+    if (any_heavy) {
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (!is_heavy[t]) continue;
+            HeavyIn hv; hv.task = t; hv.n = 0; hv.d_entries = nullptr;
+            for (int r = 0; r < R; ++r) hv.n += hlists[r][t].n;
+            if (hv.n) {
+                DALLOC(c, hv.d_entries, u64 *, hv.n * (NW + 1) * 8);
+                u64 o = 0;
+                for (int r = 0; r < R; ++r) {
+                    if (hlists[r][t].n) HIPCHK(c, hipMemcpyAsync(hv.d_entries + o * (NW + 1), hlists[r][t].entries, hlists[r][t].n * (NW + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+                    o += hlists[r][t].n;
+                }
+            }
+            hin[owner[t]].push_back(hv);
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_hlists();
+    }
+    auto free_hin = [&]() { for (auto &v : hin) for (auto &hv : v) c->pool.release(hv.d_entries); };
     // 3. the exchange: same plans as the RCCL path (hsk_comm.h), device copies instead of send/recv
     if (overlap_enabled()) {
         // grouped exchange overlapped with the sort, exactly as run_pipeline drives it
@@ -1605,9 +1784,11 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             ResultPriv *rp = new ResultPriv();
             outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
             PhaseTimer pt(c);
-            rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r]);
+            ProcExtra ex; ex.heavy_in = &hin[r];
+            rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r], &ex);
         }
         for (int r = 0; r < R; ++r) free_store(c, st[r]);
+        free_hin();
         return rc_all;
     }
     std::vector<ExchangePlan> pl(R);
@@ -1638,10 +1819,12 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         ResultPriv *rp = new ResultPriv();
         outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
         PhaseTimer pt(c);
-        int rc = process_rank<NW>(c, ntasks, owner, r, segs[r], xb[r].len, source_from_bytes(xb[r].bytes, xb[r].nbytes), xb[r].pos, xb[r].rid, &outs[r], rp, pt, false);
+        ProcExtra ex; ex.heavy_in = &hin[r];
+        int rc = process_rank<NW>(c, ntasks, owner, r, segs[r], xb[r].len, source_from_bytes(xb[r].bytes, xb[r].nbytes), xb[r].pos, xb[r].rid, &outs[r], rp, pt, false, nullptr, &ex);
         xb[r].release(c->pool);
-        if (rc) return rc;
+        if (rc) { free_hin(); return rc; }
     }
+    free_hin();
     return HSK_OK;
 }
 
@@ -1885,7 +2068,7 @@ static int stage_count_impl(hsk_ctx *c, const uint64_t *keys, uint64_t n, uint64
 {
     u64 *dk; DALLOC(c, dk, u64 *, n * NW * 8 + 64);
     HIPCHK(c, hipMemcpyAsync(dk, keys, n * NW * 8, hipMemcpyHostToDevice, c->stream));
-    const u32 histo_len = (u32)c->cfg.upper_freq + 1;
+    const u32 histo_len = (u32)std::min<int64_t>((int64_t)c->cfg.upper_freq + 1, 65536);    // (U <= 65535 except in the unfiltered pre-aggregation)
     u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
     HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
     TaskOut to;

@@ -68,6 +68,7 @@ struct ParseArgs {
     u32 rec_cap;
     u32 place_group;           // tiles placed together by one place_kernel step (rec_cap * place_group <= PLACE_MAX_REC)
     u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
+    const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
 };
 
 enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
             for (u32 i = tid; i < nrec; i += PARSE_THREADS) {
                 const u32 r = s_srt[i];
                 const u32 d = r >> 18;
+                if (a.task_skip && a.task_skip[d]) continue;
                 const u64 slot = s_cur[d] + (i - s_tpre[d]);
                 a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);             // nk - 1 + K = bases in the supermer
                 a.sm_gpos[slot] = gbase + (u64)(r & 2047);
@@ -416,6 +418,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
         for (u32 i = tid; i < nrec; i += PARSE_THREADS) {
             const u32 r = s_srt[i];
             const u32 d = r >> 18;
+            if (a.task_skip && a.task_skip[d]) continue;
             const u64 slot = s_cur[d] + (i - s_tpre[d]);
             a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);
             a.sm_gpos[slot] = gbase + (u64)(r & 2047);
@@ -718,6 +721,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
         for (u32 i = tid; i < total; i += PARSE_THREADS) {
             const u32 r = s_srt[i];
             const u32 d = (r >> 18) & 1023u;
+            if (a.task_skip && a.task_skip[d]) continue;
             const u64 slot = s_cur[d] + (i - s_tpre[d]);
             a.sm_len[slot] = (u8)(((r >> 11) & 127) + K);
             a.sm_gpos[slot] = (tfirst + (r >> 28)) * PARSE_TILE + (u64)(r & 2047);
@@ -756,14 +760,15 @@ __global__ void task_totals_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, 
 // Exclusive scan of the COUNT matrix: per task totals, task bases (tasks laid out in `order`),
 // and per (block, task) cursors for EMIT.  One thread per task; the matrix is tiny.
 //   task_tot[t][3], task_base[t][3] (supermer slot, byte, kmer), blk_base[b][t][2]
-__global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, const u32 *order,
+__global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, const u32 *order, const u8 *skip,
                                   u64 *task_tot, u64 *task_base, u64 *blk_base)
 {
     __shared__ u64 s_tot[HSK_MAX_TASKS * 3];
     const u32 t = threadIdx.x;
+    const bool live = t < ntasks && !(skip && skip[t]);      // skipped tasks take no room
     if (t < ntasks) {
         u64 s = 0, b = 0, k = 0;
-        for (u32 blk = 0; blk < nblocks; ++blk) {
+        if (live) for (u32 blk = 0; blk < nblocks; ++blk) {
             const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
             s += c[0]; b += c[1]; k += c[2];
         }
@@ -786,7 +791,7 @@ __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, c
             const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
             u64 *o = blk_base + ((u64)blk * ntasks + t) * 2;
             o[0] = s; o[1] = b;
-            s += c[0]; b += c[1];
+            if (live) { s += c[0]; b += c[1]; }
         }
     }
 }

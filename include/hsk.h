@@ -58,6 +58,7 @@ typedef struct {
 
 #define HSK_FLAG_PROFILE      1   /* HIP-event timing of every radix scatter launch (hsk_stats) */
 #define HSK_FLAG_KEEP_DEVICE  2   /* hsk_count_device leaves the result in HBM (entries_dev) */
+#define HSK_FLAG_PLAIN_CLASSIFIER 4 /* PLAIN_CLASSIFIER: no heavy-hitter pre-aggregation (kmerops.cpp:109-113) */
 
 typedef struct hsk_ctx hsk_ctx;
 
@@ -116,7 +117,7 @@ typedef struct {
     double   agg_ms;
     int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
     int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
-    int64_t  reserved[1];
+    int64_t  heavy_tasks;         /* heavy-hitter tasks this rank pre-aggregated and shipped as k-mer lists (multi-GPU) */
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

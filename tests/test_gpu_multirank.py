@@ -122,3 +122,36 @@ def test_rccl_binding_selftest():
     import hysortk_amd as H
     with H.Context(K=31, M=17) as c:
         c.comm_selftest()
+
+
+@pytest.mark.parametrize("R,ntasks", [(2, 24), (3, 24), (4, 32)])
+def test_loopback_heavy_hitter_tasks(R, ntasks):
+    """A tandem repeat makes a few tasks several times larger than the mean: they are classified as heavy hitters
+    (reference HeavyHitterClassifier, kmerops.cpp:1157), every rank pre-aggregates its share into (k-mer, count) lists, the
+    owner sums the lists (GatheredKmerList::process, kmerops.cpp:575).  Per-rank results must still equal the oracle."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    from oracle import hsk_oracle as O
+    rng = np.random.default_rng(5)
+    seqs = synth.reads(80000, 150, 6000, 31)
+    unit = "ACGGTCATTGCA"
+    rep = (unit * 13)[:150]
+    seqs = list(seqs) + [rep] * 2500 + [(unit[5:] + unit[:5]) * 12 + "ACGTAC"] * 500
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]                                  # every rank sees repeat copies
+    parts = _split(H, seqs, R)
+    with H.Context(K=31, M=17, L=2, U=65535, ntasks=ntasks) as c:
+        res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])
+        st = c.stats()
+    assert st["heavy_tasks"] > 0, st
+    packed, off, lens = O.pack_reads(seqs)
+    total = 0
+    for r in range(R):
+        ores = O.count(packed, off, lens, k=31, m=17, L=2, U=65535, ntasks=ntasks, task_owner=owner, my_rank=r)
+        kl = res[r]
+        assert np.array_equal(kl.task_off, ores.task_off), r
+        assert np.array_equal(kl.kmers, ores.keys), r
+        assert np.array_equal(kl.cnt, ores.cnt), r
+        assert H.histogram_text(kl.histo) == O.histogram_text(ores.cnt)
+        total += len(kl)
+    assert total > 1000 and max(int(kl.cnt.max()) for kl in res if len(kl)) > 1000    # the repeat's k-mers made it through the merge
