@@ -1616,6 +1616,10 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
 
     // ---- parse ------------------------------------------------------------------------------------
     SupermerStore st;
+    std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<TaskOut> hlists;                         // this rank's {k-mer, count} lists of the heavy tasks
+    std::vector<HeavyIn> hin;                            // heavy tasks this rank owns: the lists of all ranks
+    bool any_heavy = false;
     pt.begin(PH_PARSE);
     {
         // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
@@ -1626,13 +1630,38 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         if (nranks > 1) {
             std::vector<u64> bytes(ntasks);
             for (u32 t = 0; t < ntasks; ++t) bytes[t] = job.task_tot[3 * t + 1] + job.task_tot[3 * t] * (ext ? 9 : 1);
+            // heavy-hitter tasks (a8): classified on the global k-mer counts; every rank pre-aggregates its own share
+            if (heavy_enabled(c, NW, nranks)) {
+                std::vector<u64> kg(ntasks); std::vector<int32_t> types(ntasks, 0);
+                for (u32 t = 0; t < ntasks; ++t) kg[t] = job.task_tot[3 * t + 2];
+                rc = c->comm.allreduce_sum_u64(kg.data(), ntasks, c->stream, c->pool);
+                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task k-mers) failed: %d", rc); }
+                plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+                for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+            }
+            if (any_heavy) {
+                std::vector<u8> failed;
+                rc = heavy_preaggregate<NW>(c, job, d_packed, packed_bytes, is_heavy, hlists, failed);
+                if (rc) { parse_release(c, job); return rc; }
+                std::vector<u64> bad(ntasks);
+                for (u32 t = 0; t < ntasks; ++t) bad[t] = failed[t];
+                rc = c->comm.allreduce_max_u64(bad.data(), ntasks, c->stream, c->pool);     // a task one rank could not aggregate travels as supermers everywhere
+                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(heavy flags) failed: %d", rc); }
+                any_heavy = false;
+                for (u32 t = 0; t < ntasks; ++t) {
+                    if (!is_heavy[t]) continue;
+                    if (bad[t]) { is_heavy[t] = 0; free_task_out(c, hlists[t]); continue; }
+                    any_heavy = true; c->stats.heavy_tasks++;
+                    bytes[t] = hlists[t].n * (u64)(NW + 1) * 8;                               // ScatteredKmerList::get_size_bytes
+                }
+            }
             rc = c->comm.allreduce_sum_u64(bytes.data(), ntasks, c->stream, c->pool);
             if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc); }
             rc = plan_dispatch(bytes.data(), (int)ntasks, nranks, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data());
             if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }
             std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
         }
-        rc = parse_place(c, job, order, st);
+        rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr);
         parse_release(c, job);
         if (rc) return rc;
     }
@@ -1672,8 +1701,57 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             segs[t].segs.push_back(s); segs[t].nkmers = st.task_tot[3 * t + 2];
         }
     }
+    if (any_heavy) {
+        // the k-mer lists of the heavy tasks go to their owners: counts by all-reduce, one grouped send/recv
+        std::vector<u32> hv_tasks; for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t]) hv_tasks.push_back(t);
+        const size_t nh = hv_tasks.size();
+        std::vector<u64> Hn((size_t)nranks * nh, 0);
+        for (size_t i = 0; i < nh; ++i) Hn[(size_t)rank * nh + i] = hlists[hv_tasks[i]].n;
+        int rc = c->comm.allreduce_sum_u64(Hn.data(), Hn.size(), c->stream, c->pool);
+        if (rc) return fail(c, HSK_ERR_COMM, "allreduce(heavy list sizes) failed: %d (%s)", rc, c->comm.last_error.c_str());
+        const size_t ew = (size_t)(NW + 1) * 8;
+        for (size_t i = 0; i < nh; ++i) {
+            const u32 t = hv_tasks[i];
+            if (owner[t] != rank) continue;
+            HeavyIn hv; hv.task = t; hv.n = 0; hv.d_entries = nullptr;
+            for (int p = 0; p < nranks; ++p) hv.n += Hn[(size_t)p * nh + i];
+            if (hv.n) DALLOC(c, hv.d_entries, u64 *, hv.n * ew);
+            hin.push_back(hv);
+        }
+        Comm &cm = c->comm;
+        if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str());
+        size_t hi = 0;
+        for (size_t i = 0; i < nh && rc == 0; ++i) {
+            const u32 t = hv_tasks[i];
+            if (owner[t] == rank) {
+                HeavyIn &hv = hin[hi++];
+                u64 o = 0;
+                for (int p = 0; p < nranks && rc == 0; ++p) {
+                    const u64 n = Hn[(size_t)p * nh + i];
+                    if (n && p != rank) rc = cm.check(cm.api->Recv((char *)hv.d_entries + o * ew, n * ew, RCCL_UINT8, p, cm.comm, c->stream), "ncclRecv(heavy list)");
+                    o += n;
+                }
+            } else if (hlists[t].n) {
+                rc = cm.check(cm.api->Send(hlists[t].entries, hlists[t].n * ew, RCCL_UINT8, owner[t], cm.comm, c->stream), "ncclSend(heavy list)");
+            }
+        }
+        const int rc2 = cm.check(cm.api->GroupEnd(), "ncclGroupEnd");
+        if (rc || rc2) return fail(c, HSK_ERR_COMM, "heavy-hitter list exchange failed: %s", cm.last_error.c_str());
+        hi = 0;
+        for (size_t i = 0; i < nh; ++i) {                                   // own share: device copy
+            const u32 t = hv_tasks[i];
+            if (owner[t] != rank) continue;
+            HeavyIn &hv = hin[hi++];
+            u64 o = 0; for (int p = 0; p < rank; ++p) o += Hn[(size_t)p * nh + i];
+            if (hlists[t].n) HIPCHK(c, hipMemcpyAsync((char *)hv.d_entries + o * ew, hlists[t].entries, hlists[t].n * ew, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &to : hlists) free_task_out(c, to);
+    }
     pt.end(PH_EXCH);
-    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr);
+    ProcExtra ex; ex.heavy_in = &hin;
+    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
+    for (auto &hv : hin) c->pool.release(hv.d_entries);
     if (nranks > 1 && !fed) xb.release(c->pool); else free_store(c, st);
     return rc;
 }
