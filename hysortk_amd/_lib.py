@@ -60,7 +60,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhsk.so")
+    # HSK_LIB: an alternative build of the same sources (kernel-variant experiments, tools/gpu_ab.sh)
+    return os.environ.get("HSK_LIB") or os.path.join(_HERE, "libhsk.so")
 
 
 def load():
@@ -69,7 +70,7 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path) or _build.needs_build():
+    if not os.environ.get("HSK_LIB") and (not os.path.exists(path) or _build.needs_build()):
         try:
             _build.build()
         except Exception as e:  # no hipcc on this machine: use the shipped .so if there is one

@@ -27,7 +27,10 @@ namespace hsk {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 
-template <int NW> struct SortTile { static constexpr int KPT = 16 / NW; static constexpr int TILE = SORT_THREADS * KPT; };
+#ifndef HSK_SORT_KPT1
+#define HSK_SORT_KPT1 16
+#endif
+template <int NW> struct SortTile { static constexpr int KPT = (NW == 1 ? HSK_SORT_KPT1 : 16 / NW); static constexpr int TILE = SORT_THREADS * KPT; };
 template <> struct SortTile<3> { static constexpr int KPT = 5; static constexpr int TILE = SORT_THREADS * 5; };
 
 
