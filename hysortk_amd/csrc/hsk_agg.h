@@ -38,25 +38,25 @@ enum { AG_FLAG_OVERFLOW = 1 };
 
 struct AggTask {
     const u64 *keys; u64 n;        // sorted on the top AG_PREFIX_BITS bits
-    u64 *bounds;                   // [AG_BINS + 1] first record of every prefix bin (bin_bounds_kernel)
+    u64 *bounds;                   // [nbins + 1] first record of every prefix bin (bin_bounds_kernel)
     u64 *scratch; u32 slot_shift;  // bin b writes entry e {key, count} to scratch[((bounds[b] >> slot_shift) + e) * 2 ..]
     u32 active;
-    u64 *bin_cnt;                  // [AG_BINS (+1 for the scan total)] kept entries of each bin
+    u64 *bin_cnt;                  // [nbins (+1 for the scan total)] kept entries of each bin
     u32 *flags;                    // out: AG_FLAG_*
 };
-struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; };
+struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
 
 // bounds[b] = index of the first key whose top bits are >= b (b = 0 .. AG_BINS); one thread per bound
 __global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
 {
     const AggTask &t = a.t[blockIdx.y];
     const u32 b = blockIdx.x * AG_THREADS + threadIdx.x;
-    if (!t.active || b > AG_BINS) return;
-    u64 lo = 0, hi = t.n;                               // first index in [0, n] with (key >> AG_SHIFT) >= b
-    if (b == AG_BINS) lo = t.n;
+    if (!t.active || b > a.nbins) return;
+    u64 lo = 0, hi = t.n;                               // first index in [0, n] with (key >> shift) >= b
+    if (b == a.nbins) lo = t.n;
     else while (lo < hi) {
         const u64 mid = lo + ((hi - lo) >> 1);
-        if ((u32)(t.keys[mid] >> AG_SHIFT) < b) lo = mid + 1; else hi = mid;
+        if ((u32)(t.keys[mid] >> a.shift) < b) lo = mid + 1; else hi = mid;
     }
     t.bounds[b] = lo;
 }
@@ -178,6 +178,134 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     if (tid == 0) t.bin_cnt[b] = tot;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One scatter pass, then aggregate: bins of the top 8 key bits.  With tasks of ~2^24 k-mers a bin holds ~65 000
+// records and ~2 500 distinct keys (32 x coverage): too many records for LDS, but the hash table only has to hold
+// the DISTINCT keys.  One workgroup of 1024 threads per bin, 8192 slots (96 KB of the CU's 160 KB LDS): the bin
+// is streamed once from HBM, the distinct keys are compacted and ordered with a bitonic network in LDS, filtered
+// and written in key order.  The per-bin fixed work (table init, compaction, ordering, output) is spread over
+// ~65 000 records instead of ~3 000, and the second scatter pass (16 B of HBM traffic per k-mer) is not needed.
+// More distinct keys than the table takes (low coverage, or a skewed bin) raise AG_FLAG_OVERFLOW: the host sorts
+// that task on the next 8 bits as well and finishes it with agg_finish_kernel.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int AGB_THREADS = 1024;
+constexpr int AGB_LOG2CAP = 13;
+constexpr int AGB_CAP = 1 << AGB_LOG2CAP;
+constexpr int AGB_MAX_LOAD = AGB_CAP * 3 / 4;      // distinct keys accepted (beyond that probes get long: overflow)
+
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_1024(T v, T *scratch /* >= 16 */, T *total)
+{
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    T inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) scratch[w] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { T x = scratch[i]; if (i < w) base += x; tot += x; }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
+{
+    constexpr int CAP = AGB_CAP;
+    constexpr int PER = CAP / AGB_THREADS;          // 8 slots per thread
+    __shared__ u64 s_key[CAP];
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_scr[16];
+    __shared__ u32 s_ovf;
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    const u32 b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_key[j * AGB_THREADS + tid] = AG_EMPTY; s_cnt[j * AGB_THREADS + tid] = 0; }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    // ---- 1. stream the bin: 8 loads per lane in flight ---------------------------------------------------------
+    constexpr int UNR = 8;
+    for (u64 i = s + tid; i < e; i += (u64)AGB_THREADS * UNR) {
+        u64 k[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AGB_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (k[u] == AG_EMPTY) continue;
+            const u32 x = (u32)(k[u] >> 32) ^ (u32)k[u];
+            u32 h = (x * 0x9E3779B1u) >> (32 - AGB_LOG2CAP);
+            bool done = false;
+            for (int p = 0; p < AG_MAX_PROBE; ++p) {
+                u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
+                if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_cnt[h], 1u); done = true; break; }
+                h = (h + 1) & (CAP - 1);
+            }
+            if (!done) s_ovf = 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. compact the occupied slots ---------------------------------------------------------------------------
+    u32 D;
+    {
+        u64 mk[PER]; u32 mc[PER];
+        u32 occ = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { mk[j] = s_key[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
+        u32 o = block_excl_scan_1024<u32>(occ, s_scr, &D);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
+    }
+    __syncthreads();
+    if (s_ovf || D > (u32)AGB_MAX_LOAD) {
+        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        return;
+    }
+
+    // ---- 3. order the distinct keys (bitonic network over the next power of two) --------------------------------
+    u32 P = 2; while (P < D) P <<= 1;
+    for (u32 i = D + tid; i < P; i += AGB_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; }
+    __syncthreads();
+    for (u32 kk = 2; kk <= P; kk <<= 1) {
+        for (u32 j = kk >> 1; j > 0; j >>= 1) {
+            // each thread owns the compare-exchanges whose lower index has bit j clear: i = insert a 0 at bit log2(j)
+            for (u32 x = tid; x < (P >> 1); x += AGB_THREADS) {
+                const u32 i = ((x & ~(j - 1)) << 1) | (x & (j - 1));
+                const u32 q = i | j;
+                const u64 ki = s_key[i], kq = s_key[q];
+                const bool up = (i & kk) == 0;
+                if ((ki > kq) == up) { const u32 ci = s_cnt[i], cq = s_cnt[q]; s_key[i] = kq; s_key[q] = ki; s_cnt[i] = cq; s_cnt[q] = ci; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- 4. filter, entries in key order to the bin's slots ------------------------------------------------------
+    u32 kept = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) { const u32 c = s_cnt[i]; kept += (c >= a.lower && c <= a.upper); }
+    }
+    u32 tot;
+    const u32 w = block_excl_scan_1024<u32>(kept, s_scr, &tot);
+    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 2;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) {
+            const u32 c = s_cnt[i];
+            if (c >= a.lower && c <= a.upper) { dst[0] = s_key[i]; dst[1] = (u64)c; dst += 2; }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+}
+
 // exclusive scan of bin_cnt[AG_BINS] of every active task (total behind the last bin); one workgroup per task
 __global__ __launch_bounds__(AG_THREADS) void agg_scan_kernel(AggArgs a)
 {
@@ -188,25 +316,25 @@ __global__ __launch_bounds__(AG_THREADS) void agg_scan_kernel(AggArgs a)
     constexpr int IPT = 8;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (u32 b = 0; b < AG_BINS; b += AG_THREADS * IPT) {
+    for (u32 b = 0; b < a.nbins; b += AG_THREADS * IPT) {
         const u32 t0 = b + threadIdx.x * IPT;
         u64 v[IPT], sum = 0;
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) { v[i] = t.bin_cnt[t0 + i]; sum += v[i]; }
+        for (int i = 0; i < IPT; ++i) { v[i] = (t0 + i < a.nbins) ? t.bin_cnt[t0 + i] : 0; sum += v[i]; }
         u64 tot;
         u64 ex = block_excl_scan_256<u64>(sum, s_scr, &tot) + s_carry;
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) { t.bin_cnt[t0 + i] = ex; ex += v[i]; }
+        for (int i = 0; i < IPT; ++i) { if (t0 + i < a.nbins) t.bin_cnt[t0 + i] = ex; ex += v[i]; }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) t.bin_cnt[AG_BINS] = s_carry;
+    if (threadIdx.x == 0) t.bin_cnt[a.nbins] = s_carry;
 }
 
 // Moves the kept entries from the per-bin slots to their final place (bin_off = exclusive scan of bin_cnt,
 // bin_off[AG_BINS] = total) and builds the count histogram.  One wave per bin, persistent workgroups.
-struct AggCompactArgs { const u64 *scratch[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH]; u64 *entries[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; };
+struct AggCompactArgs { const u64 *scratch[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH]; u64 *entries[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; };
 __global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(AggCompactArgs ca)
 {
     __shared__ u32 s_hist[AG_LDS_HIST];
@@ -218,11 +346,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(AggCompactArgs 
     for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) s_hist[i] = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (u32 b = blockIdx.x * 4 + wave; b < AG_BINS; b += gridDim.x * 4) {
+    for (u32 b = blockIdx.x * 4 + wave; b < ca.nbins; b += gridDim.x * 4) {
         const u64 o = bin_off[b];
-        const u32 cnt = (u32)(bin_off[b + 1] - o);
+        const u64 cnt = bin_off[b + 1] - o;
         const u64 *src = scratch + (bounds[b] >> slot_shift) * 2;
-        for (u32 i = lane; i < cnt * 2; i += 64) {
+        for (u64 i = lane; i < cnt * 2; i += 64) {
             const u64 v = src[i];
             entries[o * 2 + i] = v;
             if (i & 1) {

@@ -103,6 +103,7 @@ struct hsk_ctx {
     void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
     u32 *d_err = nullptr;
     Comm comm;
+    int onepass_misses = 0;            // tasks of the current call the one-pass plan could not finish (many misses: two passes from then on)
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 
@@ -958,12 +959,32 @@ static void *host_alloc(ResultPriv *rp, size_t bytes)
     return p;
 }
 
+static bool finish_enabled();
+static bool agg_enabled();
+// One scatter pass + aggregation over 8-bit prefix bins (hsk_agg.h: agg_big_kernel) for tasks of up to ONEPASS_MAX_TASK
+// k-mers; HSK_ONEPASS=0 keeps two passes + 16-bit bins for every task.
+constexpr u64 ONEPASS_TASK_KMERS = 1ULL << 24;          // auto_ntasks aims at this many base positions per task
+constexpr u64 ONEPASS_MAX_TASK = 3ULL << 23;            // larger tasks: bins with too many distinct keys for the LDS table
+// EXPERIMENTAL, off unless HSK_ONEPASS=1: at 10 Gbp it needs ~600 tasks of 13 M k-mers, and launches of 8 such tasks are
+// too small for the scatter pass (2.0 instead of 4.6 TB/s) and the bitonic ordering of ~2 500 distinct keys per bin is
+// LDS-bound (241 ms per step against 166 ms with two passes); kept because it is the plan that removes 16 B of HBM
+// traffic per k-mer once the launches cover 64 tasks and the bins are ordered without a sorting network.
+static bool onepass_enabled()
+{
+    static const bool on = getenv("HSK_ONEPASS") && atoi(getenv("HSK_ONEPASS")) != 0;
+    return on;
+}
+
 static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
 {
     // one task per ~2^28 k-mers (2 GB of 8-byte keys): large enough to saturate the chip, small
     // enough that key + ping-pong + look-back buffers of one task stay a small share of HBM
     u64 est = packed_bytes * 4 * (u64)std::max(nranks, 1);
     u64 t = (est + (1ULL << 28) - 1) >> 28;
+    // one-word keys without payload: tasks small enough for ONE scatter pass + aggregation over 8-bit prefix bins
+    // (as many as HSK_MAX_TASKS allows; beyond that the tasks grow and the two-pass plan takes over by itself)
+    if (c->nw == 1 && c->cfg.extension == 0 && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled())
+        t = std::max(t, std::min<u64>((est + ONEPASS_TASK_KMERS - 1) / ONEPASS_TASK_KMERS, HSK_MAX_TASKS / 8 * 8));
     t = std::max<u64>(t, (u64)std::max(nranks, 1));
     // tasks are sorted eight at a time (one per XCD): give every rank a multiple of eight when there are that many
     const u64 per = 8ULL * (u64)std::max(nranks, 1);
@@ -1056,20 +1077,25 @@ static bool agg_enabled()
 }
 
 template <int NW>
-static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs)
+// prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way;
+// prefix_bits = 8: bins of the top 8 bits (one scatter pass), agg_big_kernel; a task it cannot take is reported in
+// outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
+static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
 {
     static_assert(NW == 1, "the aggregating finish handles one-word keys");
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const u32 L = (u32)c->cfg.lower_freq;
     const u32 slot_shift = L >= 2 ? 1 : 0;              // a bin of n records keeps at most n / L entries of 16 bytes
-    const size_t per = (size_t)AG_BINS + 8;
+    const bool big = prefix_bits == 8;
+    const u32 nbins = 1u << prefix_bits;
+    const size_t per = (size_t)nbins + 8;
     u64 *d_bounds, *d_cnt; u32 *d_flags;
     DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
     DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
     DALLOC(c, d_flags, u32 *, 256);
     HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
     AggArgs a; memset(&a, 0, sizeof a);
-    a.lower = L; a.upper = (u32)c->cfg.upper_freq;
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits;
     bool own_scratch[AG_BATCH] = {false};
     u64 ntot = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
@@ -1088,23 +1114,24 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto run = [&](int log2cap) -> int {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
-        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(AG_BINS, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
+        else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
-        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + AG_BINS, 8, hipMemcpyDeviceToHost, c->stream));
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return HSK_OK;
     };
     memset(&h, 0, sizeof h);
-    hipLaunchKernelGGL(bin_bounds_kernel, dim3(AG_BINS / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
     bool retry = false, done[AG_BATCH];
     u64 total[AG_BATCH];
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
-    if (retry) {
+    if (retry && !big) {
         // second chance with the large table for the tasks that overflowed
         AggArgs keep = a;
         for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
@@ -1115,7 +1142,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         a = keep;
     }
     AggCompactArgs ca; memset(&ca, 0, sizeof ca);
-    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len;
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
     bool any = false;
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || !done[i]) continue;
@@ -1128,10 +1155,10 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
             any = true;
         }
     }
-    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(big ? 64 : 256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
-        if (c->forbid_long_way) { outs[i].failed = true; continue; }
+        if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
         // the long way for this task: full-width passes from the current order, then the two-pass counter
         c->stats.redone_tasks++;
         if (own_scratch[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
@@ -1336,7 +1363,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // counted on the main stream.  The expand kernel waits on memory latency for most of its life, the radix passes
     // are bandwidth-bound and the aggregation is issue-bound: side by side they fill each other's gaps.  Every
     // buffer the second stream touches is allocated up front (the pool's reuse rule is per stream).
-    static const bool pipe_enabled = !(getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) == 0);
+    // (off unless HSK_PIPELINE=1: the gain is ~1.5 % and every per-kernel duration, hence the reported roofline of the
+    // scatter pass, is inflated by whatever runs beside it)
+    static const bool pipe_enabled = getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) != 0;
     const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = piped ? 2 : 1;
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
@@ -1380,12 +1409,17 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
     const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
     const bool agg = fused && agg_enabled();
-    const int prefix_bits = agg ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
-    PassDesc plan[MAX_PASSES];
-    const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
+    const bool onepass_ok = agg && onepass_enabled() && max_task <= ONEPASS_MAX_TASK;
+    c->onepass_misses = 0;
+    int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
     BatchTask bts[2][XCD_BATCH];
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
+        // one pass while the table keeps up; after a batch worth of misses (low coverage: every bin overflows) two passes
+        const int prefix_bits = !agg ? 64 - HYBRID_SHIFT : ((onepass_ok && c->onepass_misses < XCD_BATCH) ? 8 : AG_PREFIX_BITS);
+        slot_prefix[sl] = prefix_bits;
+        PassDesc plan[MAX_PASSES];
+        const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
         if (piped && done_valid[sl]) HIPCHK(c, hipStreamWaitEvent(xstream, ev_done[sl], 0));     // the slot's previous batch is counted
         pt.begin(PH_EXTRACT, xstream);
         HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, xstream));
@@ -1423,6 +1457,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         BatchTask *bt = bts[sl];
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
+        const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
         { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
@@ -1430,9 +1465,26 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (fused) {
             if constexpr (NW == 1) {
                 TaskOut fo[XCD_BATCH];
-                int rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo)
+                int rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits)
                              : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
                 if (rc) return rc;
+                if (agg && prefix_bits == 8) {
+                    // tasks the 8-bit bins could not take (a bin with too many distinct keys): order them on the next 8 bits
+                    // too (two more passes from where they are) and finish them over 16-bit bins
+                    BatchTask b2[XCD_BATCH]; bool any_miss = false;
+                    for (int i = 0; i < XCD_BATCH; ++i) {
+                        b2[i] = BatchTask();
+                        if (!fo[i].failed) continue;
+                        any_miss = true; c->onepass_misses++; c->stats.onepass_misses++;
+                        b2[i].n = bt[i].n; b2[i].kA = bt[i].out_k; b2[i].kB = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+                    }
+                    if (any_miss) {
+                        rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
+                        TaskOut f2[XCD_BATCH];
+                        rc = agg_finish_batch_device<1>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
+                        for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
+                    }
+                }
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
             }
         } else {

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
 // ======================================================================================================
 constexpr int SCAN_MAX_M = 25;
 constexpr u32 SCAN_REC_CAP = 512;                     // default records kept per tile (expected ~270 at K=31, M=17)
-constexpr u32 PLACE_MAX_REC = 2048;                   // records of one placement step (rec_cap * place_group)
+constexpr u32 PLACE_MAX_REC = 8192;                   // records of one placement step (rec_cap * place_group)
 // LDS layout of the tile's hashes: position p = 8*t + i lives at [i][t] (row stride SCAN_HSTRIDE), so that the 64
 // lanes of a wave, which all touch the same i of consecutive t, hit consecutive 8-byte words (a lane-major layout
 // puts them 64 bytes apart: 8-way bank conflicts on every access)

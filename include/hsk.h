@@ -118,6 +118,7 @@ typedef struct {
     int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
     int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
     int64_t  heavy_tasks;         /* heavy-hitter tasks this rank pre-aggregated and shipped as k-mer lists (multi-GPU) */
+    int64_t  onepass_misses;      /* tasks the one-pass plan (8-bit prefix bins) could not finish; they took two more passes */
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
