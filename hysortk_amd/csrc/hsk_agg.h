@@ -44,7 +44,7 @@ struct AggTask {
     u64 *bin_cnt;                  // [nbins (+1 for the scan total)] kept entries of each bin
     u32 *flags;                    // out: AG_FLAG_*
 };
-struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
+struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
 
 // bounds[b] = index of the first key whose top bits are >= b (b = 0 .. AG_BINS); one thread per bound
 __global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
     if (b == a.nbins) lo = t.n;
     else while (lo < hi) {
         const u64 mid = lo + ((hi - lo) >> 1);
-        if ((u32)(t.keys[mid] >> a.shift) < b) lo = mid + 1; else hi = mid;
+        if ((u32)(t.keys[mid * a.nw + (a.nw - 1)] >> a.shift) < b) lo = mid + 1; else hi = mid;    // the most significant word
     }
     t.bounds[b] = lo;
 }
@@ -173,6 +173,145 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         if (i < D) {
             const u32 c = sc[i];
             if (c >= a.lower && c <= a.upper) { dst[0] = sk[i]; dst[1] = (u64)c; dst += 2; }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Two-word keys (32 < K < 64): the same aggregation over 16-bit prefix bins of the MOST significant word (word 1:
+// the keys are ordered as little-endian two-word integers, hsk_sort.h).  There is no 128-bit LDS compare-and-swap,
+// so a slot is claimed with a CAS on word 1 and the claimer then publishes word 0; a lane that finds its word 1 in
+// a slot waits until word 0 is there (the claimer never waits for anything: claimers of the same wave have already
+// issued their store, LDS operations of a wave execute in order) and compares it.  The "not yet published" marker
+// ~0 is no valid word 0: a canonical k-mer that starts with 32 T needs a reverse complement that starts with 32 T
+// too, i.e. a k-mer whose last 32 bases are A, impossible for K < 64 next to 32 leading T.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool key2_less(u64 a1, u64 a0, u64 b1, u64 b0) { return a1 < b1 || (a1 == b1 && a0 < b0); }
+
+template <int LOG2CAP>
+__global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
+{
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    __shared__ u64 s_k1[CAP];
+    __shared__ u64 s_k0[CAP];
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_ovf;
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    const u32 b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_k1[j * AG_THREADS + tid] = AG_EMPTY; s_k0[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    constexpr int UNR = 8;
+    const ulonglong2 *recs = reinterpret_cast<const ulonglong2 *>(t.keys);       // {word 0, word 1}
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+        ulonglong2 k[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? recs[idx] : make_ulonglong2(AG_EMPTY, AG_EMPTY); }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const u64 w0 = k[u].x, w1 = k[u].y;
+            if (w1 == AG_EMPTY) continue;
+            const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
+            const u32 x = (u32)(m >> 32) ^ (u32)m;
+            u32 h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
+            bool done = false;
+            for (int p = 0; p < AG_MAX_PROBE && !done; ++p) {
+                u64 cur = __hip_atomic_load(&s_k1[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_k1[h], (unsigned long long)AG_EMPTY, (unsigned long long)w1);
+                const bool claimed = cur == AG_EMPTY;
+                if (claimed) {                                   // publish word 0 (before any lane of this wave starts to wait)
+                    __hip_atomic_store(&s_k0[h], w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicAdd(&s_cnt[h], 1u); done = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (!claimed && cur == w1) {
+                    u64 v = AG_EMPTY;
+                    for (u32 spin = 0; spin < (1u << 22); ++spin) {
+                        v = __hip_atomic_load(&s_k0[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (v != AG_EMPTY) break;
+                    }
+                    if (v == AG_EMPTY) { s_ovf = 1; done = true; }          // (never: the claimer does not wait for anyone)
+                    else if (v == w0) { atomicAdd(&s_cnt[h], 1u); done = true; }
+                }
+                h = (h + 1) & (CAP - 1);
+            }
+            if (!done) s_ovf = 1;
+        }
+    }
+    __syncthreads();
+    if (s_ovf) {
+        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        return;
+    }
+
+    // ---- compact, order by (word 1, word 0) ----------------------------------------------------------------------
+    u32 D;
+    {
+        u64 m1[PER], m0[PER]; u32 mc[PER];
+        u32 occ = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { m1[j] = s_k1[tid * PER + j]; m0[j] = s_k0[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += m1[j] != AG_EMPTY; }
+        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (m1[j] != AG_EMPTY) { s_k1[o] = m1[j]; s_k0[o] = m0[j]; s_cnt[o] = mc[j]; ++o; }
+    }
+    __syncthreads();
+    if (D <= (u32)AG_THREADS) {
+        u64 k1 = 0, k0 = 0; u32 c = 0, r = 0;
+        if ((u32)tid < D) {
+            k1 = s_k1[tid]; k0 = s_k0[tid]; c = s_cnt[tid];
+            for (u32 j = 0; j < D; ++j) r += key2_less(s_k1[j], s_k0[j], k1, k0);
+        }
+        __syncthreads();
+        if ((u32)tid < D) { s_k1[r] = k1; s_k0[r] = k0; s_cnt[r] = c; }
+        __syncthreads();
+    } else {
+        u32 P = 512; while (P < D) P <<= 1;
+        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_k1[i] = AG_EMPTY; s_k0[i] = AG_EMPTY; s_cnt[i] = 0; }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < P; i += AG_THREADS) {
+                    const u32 q = i ^ j;
+                    if (q > i) {
+                        const u64 x1 = s_k1[i], x0 = s_k0[i], y1 = s_k1[q], y0 = s_k0[q];
+                        const bool up = (i & kk) == 0;
+                        if (key2_less(y1, y0, x1, x0) == up) {
+                            const u32 cx = s_cnt[i], cy = s_cnt[q];
+                            s_k1[i] = y1; s_k0[i] = y0; s_cnt[i] = cy; s_k1[q] = x1; s_k0[q] = x0; s_cnt[q] = cx;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- filter, entries {word 0, word 1, count} in key order to the bin's slots -----------------------------------
+    u32 kept = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) { const u32 c = s_cnt[i]; kept += (c >= a.lower && c <= a.upper); }
+    }
+    u32 tot;
+    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);
+    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 3;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) {
+            const u32 c = s_cnt[i];
+            if (c >= a.lower && c <= a.upper) { dst[0] = s_k0[i]; dst[1] = s_k1[i]; dst[2] = (u64)c; dst += 3; }
         }
     }
     if (tid == 0) t.bin_cnt[b] = tot;
@@ -334,7 +473,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_scan_kernel(AggArgs a)
 
 // Moves the kept entries from the per-bin slots to their final place (bin_off = exclusive scan of bin_cnt,
 // bin_off[AG_BINS] = total) and builds the count histogram.  One wave per bin, persistent workgroups.
-struct AggCompactArgs { const u64 *scratch[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH]; u64 *entries[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; };
+struct AggCompactArgs { const u64 *scratch[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH]; u64 *entries[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; u32 ew; };   // ew = words per entry (key words + count)
 __global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(AggCompactArgs ca)
 {
     __shared__ u32 s_hist[AG_LDS_HIST];
@@ -349,11 +488,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_compact_kernel(AggCompactArgs 
     for (u32 b = blockIdx.x * 4 + wave; b < ca.nbins; b += gridDim.x * 4) {
         const u64 o = bin_off[b];
         const u64 cnt = bin_off[b + 1] - o;
-        const u64 *src = scratch + (bounds[b] >> slot_shift) * 2;
-        for (u64 i = lane; i < cnt * 2; i += 64) {
+        const u64 *src = scratch + (bounds[b] >> slot_shift) * ca.ew;
+        for (u64 i = lane; i < cnt * ca.ew; i += 64) {
             const u64 v = src[i];
-            entries[o * 2 + i] = v;
-            if (i & 1) {
+            entries[o * ca.ew + i] = v;
+            if (i % ca.ew == ca.ew - 1) {
                 if (v < (u64)AG_LDS_HIST) atomicAdd(&s_hist[(u32)v], 1u);
                 else if (v < histo_len) atomicAdd((unsigned long long *)&histo[v], 1ULL);
             }

@@ -608,16 +608,22 @@ static int make_pass_plan(int K, int nw, int rb, PassDesc *out)
 // copies of ONE k-mer and passes through untouched; 24 bits left 40 % of the records in multi-key bins whose
 // in-LDS ordering (serial, LDS-latency bound) cost more than the fourth pass.
 constexpr int HYBRID_SHIFT = 32;
-static int make_hybrid_plan(PassDesc *out, int prefix_bits = 64 - HYBRID_SHIFT)
+static int make_hybrid_plan(PassDesc *out, int prefix_bits = 64 - HYBRID_SHIFT, int word = 0)
 {
-    const int np = prefix_bits / 8;                     // LSD passes over the top prefix_bits bits
-    for (int i = 0; i < np; ++i) out[i] = PassDesc{0, 64 - prefix_bits + 8 * i, 8};
+    const int np = prefix_bits / 8;                     // LSD passes over the top prefix_bits bits (of the most significant word)
+    for (int i = 0; i < np; ++i) out[i] = PassDesc{word, 64 - prefix_bits + 8 * i, 8};
     return np;
 }
 static bool hybrid_enabled()
 {
     static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
     return on;
+}
+// Two-word keys take the prefix plan when the aggregating finish follows and the most significant word carries at
+// least the 16 prefix bits (K >= 40)
+template <int NW> static bool prefix_plan_ok(int K, bool finish_follows)
+{
+    return hybrid_enabled() && (NW == 1 || (NW == 2 && finish_follows && K - 32 >= 8));
 }
 
 struct SortScratch {
@@ -734,8 +740,8 @@ static void launch_onesweep_multi(hsk_ctx *c, const MultiSortArgs &m, u32 grid)
 template <int NW>
 static int batch_pass_plan(hsk_ctx *c, int K, bool finish_follows, int prefix_bits, PassDesc *plan)
 {
-    const bool hybrid = NW == 1 && hybrid_enabled();
-    return hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
+    const bool hybrid = prefix_plan_ok<NW>(K, finish_follows);
+    return hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT, NW - 1) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
 }
 
 // d_ghist_pre: [XCD_BATCH][MAX_PASSES][256] digit histograms already counted by expand_batch (null: hist_kernel runs here)
@@ -755,7 +761,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     DALLOC(c, d_tickets, u32 *, (size_t)XCD_BATCH * MAX_PASSES * 4 + 256);       // + 8 flag words behind the tickets
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, (size_t)XCD_BATCH * MAX_PASSES * 4 + 64, c->stream));
     PassDesc plan[MAX_PASSES];
-    const bool hybrid = NW == 1 && hybrid_enabled();
+    const bool hybrid = prefix_plan_ok<NW>(K, finish_follows);
     const int npass = batch_pass_plan<NW>(c, K, finish_follows, prefix_bits, plan);
     u64 ntot = 0; bool wide = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
@@ -1082,7 +1088,8 @@ template <int NW>
 // outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
 static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
 {
-    static_assert(NW == 1, "the aggregating finish handles one-word keys");
+    static_assert(NW <= 2, "the aggregating finish handles one- and two-word keys");
+    constexpr u32 EW = NW + 1;                          // words per entry
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const u32 L = (u32)c->cfg.lower_freq;
     const u32 slot_shift = L >= 2 ? 1 : 0;              // a bin of n records keeps at most n / L entries of 16 bytes
@@ -1095,7 +1102,7 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     DALLOC(c, d_flags, u32 *, 256);
     HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
     AggArgs a; memset(&a, 0, sizeof a);
-    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits;
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
     bool own_scratch[AG_BATCH] = {false};
     u64 ntot = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
@@ -1107,13 +1114,17 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         t.slot_shift = slot_shift; t.active = 1; ntot += bt[i].n;
         if (slot_shift) t.scratch = other;               // the idle ping-pong buffer: n / 2 entries
         else {
-            t.scratch = (u64 *)c->pool.alloc(bt[i].n * 16 + 64); own_scratch[i] = true;
-            if (!t.scratch) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)(bt[i].n * 16));
+            t.scratch = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); own_scratch[i] = true;
+            if (!t.scratch) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)(bt[i].n * EW * 8));
         }
     }
     struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto run = [&](int log2cap) -> int {
-        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+        if (NW == 2) {
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        } else
         if (big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
         else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
@@ -1142,15 +1153,15 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         a = keep;
     }
     AggCompactArgs ca; memset(&ca, 0, sizeof ca);
-    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
     bool any = false;
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || !done[i]) continue;
         c->stats.fused_tasks++;
         outs[i].n = total[i];
         if (outs[i].n) {
-            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16);
-            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * 16)); break; }
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * EW * 8);
+            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * EW * 8)); break; }
             ca.scratch[i] = a.t[i].scratch; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt; ca.entries[i] = outs[i].entries;
             any = true;
         }
@@ -1407,9 +1418,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     std::vector<u64> pay_before(ntasks, 0);
     { u64 acc = 0; for (u32 t : mine) { if (t == EMPTY_TASK) continue; pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
     TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
-    const bool fused = NW == 1 && !ext && hybrid_enabled() && finish_enabled();
+    // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
+    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
     const bool agg = fused && agg_enabled();
-    const bool onepass_ok = agg && onepass_enabled() && max_task <= ONEPASS_MAX_TASK;
+    const bool onepass_ok = NW == 1 && agg && onepass_enabled() && max_task <= ONEPASS_MAX_TASK;
     c->onepass_misses = 0;
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
     BatchTask bts[2][XCD_BATCH];
@@ -1463,10 +1475,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         if (fused) {
-            if constexpr (NW == 1) {
+            if constexpr (NW <= 2) {
                 TaskOut fo[XCD_BATCH];
-                int rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits)
-                             : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
+                int rc;
+                if constexpr (NW == 1) rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits)
+                                                : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
+                else rc = agg_finish_batch_device<NW>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits);
                 if (rc) return rc;
                 if (agg && prefix_bits == 8) {
                     // tasks the 8-bit bins could not take (a bin with too many distinct keys): order them on the next 8 bits
@@ -1481,7 +1495,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                     if (any_miss) {
                         rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
                         TaskOut f2[XCD_BATCH];
-                        rc = agg_finish_batch_device<1>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
+                        rc = agg_finish_batch_device<NW>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
                         for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
                     }
                 }

@@ -402,3 +402,34 @@ def test_fused_finish_equals_two_pass_path(H):
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
+
+
+@pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 50), (41, 2, 50), (63, 1, 65535), (35, 2, 50)])
+def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
+    """32 < K < 64: two scatter passes on the top 16 bits of the most significant word + aggregation of 128-bit keys in LDS
+    (slot claimed on word 1, word 0 published by the claimer).  Many k-mers here share word 1 and differ only in word 0
+    (variants of one 40-base suffix), others share word 0; K=35 (fewer than 16 prefix bits in word 1) takes the full-width passes."""
+    rng = np.random.default_rng(K)
+    g = "".join(rng.choice(list("ACGT"), 30000))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 4000)]
+    suffix = "".join(rng.choice(list("ACGT"), 45))
+    prefix = "".join(rng.choice(list("ACGT"), 45))
+    for v in range(1500):
+        reads.append("".join(rng.choice(list("ACGT"), 40)) + suffix)          # same last bases, different first
+        reads.append(prefix + "".join(rng.choice(list("ACGT"), 40)))          # same first bases, different last
+    reads += reads[-300:]
+    reads += ["AC" * 75] * 40 + ["A" * 150] * 20
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=17, L=L, U=U, ntasks=16, fast=True)
+    with H.Context(K=K, M=17, L=L, U=U, ntasks=16) as c:
+        res = c.count(dna)
+        st = c.stats()
+    if K >= 40:
+        assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
+    else:
+        assert st["fused_tasks"] == 0, st
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
