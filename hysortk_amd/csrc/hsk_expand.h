@@ -315,13 +315,40 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
     }
 }
 
-// Multi-GPU only: materialise the re-aligned byte stream of reference-mode supermers for the
-// exchange.  One lane per output byte (coalesced), the supermer of a byte is found by binary search
-// over the tile's byte prefix sums; layout identical to what parse_kernel's copy mode writes.
+// Multi-GPU only: materialise the re-aligned byte stream of reference-mode supermers for the exchange (what
+// SupermerEncoder::copy_bits writes in the reference, src/kmerops.cpp:1096-1107; `(len + 3) / 4` bytes per supermer,
+// tail bits zero).  One lane per aligned 8-byte word of the OUTPUT: the supermer under the word's first byte is found
+// by binary search over the tile's byte prefix sums, then the word is assembled from one or two (for tiny K: a few)
+// supermers, each piece one unaligned 64-bit pull from the packed reads.  The bytes of a tile before its first and
+// behind its last aligned word are written one by one (the neighbouring tiles write the rest of those words).
+__device__ __forceinline__ u64 pack_pull(const u32 *s_boff, const u64 *s_gpos, const u8 *s_len, u32 ns, u32 o, u32 n,
+                                         const u64 *src8, u64 src_bit0, u64 src_words)
+{
+    u32 lo = 0, hi = ns - 1;                                      // supermer under tile-relative byte o
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_boff[mid] <= o) lo = mid; else hi = mid - 1; }
+    u64 r = 0;
+    u32 i = 0;
+    while (i < n && lo < ns) {
+        const u32 jb = o + i - s_boff[lo];                        // first byte wanted inside supermer `lo`
+        const u32 nbs = s_boff[lo + 1] - s_boff[lo];
+        u32 take = nbs - jb; if (take > n - i) take = n - i;
+        const u64 bits = bits64_bytes_clamped(src8, src_bit0 + 2 * s_gpos[lo] + 8 * (u64)jb, src_words);
+        u64 le = __builtin_bswap64(bits);                         // byte j of `le` = j-th byte of the stream
+        const u32 len = s_len[lo];
+        if ((len & 3) && jb + take == nbs) le &= ~((u64)(0xFFu >> (2 * (len & 3))) << (8 * (take - 1)));   // tail bits of the supermer's last byte
+        if (take < 8) le &= (1ULL << (8 * take)) - 1;
+        r |= le << (8 * i);
+        i += take; ++lo;
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(EXP_THREADS) void pack_kernel(const ExpSeg *segs, int nseg, const u8 *sm_len, const u64 *src8, u64 src_bit0, u64 src_words,
                                                             const u64 *sm_gpos, const u64 *tile_off, u8 *bytes_out)
 {
     __shared__ u32 s_boff[EXP_TILE + 1];
+    __shared__ u64 s_gpos[EXP_TILE];
+    __shared__ u8 s_len[EXP_TILE];
     __shared__ u32 s_scr[8];
     const u64 tile = blockIdx.x;
     const int sg = seg_of_tile(segs, nseg, tile);
@@ -332,10 +359,12 @@ __global__ __launch_bounds__(EXP_THREADS) void pack_kernel(const ExpSeg *segs, i
     u32 nb[EXP_SPT], sb = 0;
 #pragma unroll
     for (int i = 0; i < EXP_SPT; ++i) {
-        u32 s = tid * EXP_SPT + i;
-        u32 len = (s < ns) ? sm_len[seg.sup_off + first + s] : 0;
-        nb[i] = (s < ns) ? ((len + 3) >> 2) : 0;
+        const u32 sidx = tid * EXP_SPT + i;
+        const u32 len = (sidx < ns) ? sm_len[seg.sup_off + first + sidx] : 0;
+        nb[i] = (sidx < ns) ? ((len + 3) >> 2) : 0;
         sb += nb[i];
+        s_len[sidx] = (u8)len;
+        if (sidx < ns) s_gpos[sidx] = sm_gpos[seg.sup_off + first + sidx];
     }
     u32 totb;
     u32 eb = block_excl_scan_256<u32>(sb, s_scr, &totb);
@@ -343,18 +372,18 @@ __global__ __launch_bounds__(EXP_THREADS) void pack_kernel(const ExpSeg *segs, i
     for (int i = 0; i < EXP_SPT; ++i) { s_boff[tid * EXP_SPT + i] = eb; eb += nb[i]; }
     if (tid == EXP_THREADS - 1) s_boff[EXP_TILE] = eb;
     __syncthreads();
-    const u64 byte_abs = tile_off[2 * tile];
-    for (u32 b = tid; b < totb; b += EXP_THREADS) {
-        u32 lo = 0, hi = ns - 1;
-        while (lo < hi) { u32 mid = (lo + hi + 1) >> 1; if (s_boff[mid] <= b) lo = mid; else hi = mid - 1; }
-        const u32 jb = b - s_boff[lo];
-        const u32 len = sm_len[seg.sup_off + first + lo];
-        const u64 bit = src_bit0 + 2 * sm_gpos[seg.sup_off + first + lo] + 8 * (u64)jb;
-        u8 byte = (u8)(bits64_bytes_clamped(src8, bit, src_words) >> 56);
-        const u32 nbs = (len + 3) >> 2;
-        if (jb == nbs - 1 && (len & 3)) byte &= (u8)(0xFF << (2 * (4 - (len & 3))));
-        bytes_out[byte_abs + b] = byte;
-    }
+    if (ns == 0 || totb == 0) return;
+    // (s_boff[ns .. EXP_TILE] all equal totb: the search and the walk stop at ns)
+    u8 *out = bytes_out + tile_off[2 * tile];                     // first byte of the tile in the output stream
+    const uintptr_t a0 = (uintptr_t)out;
+    const u32 head = (u32)((8 - (a0 & 7)) & 7) < totb ? (u32)((8 - (a0 & 7)) & 7) : totb;       // bytes before the first aligned word
+    const u32 nwords = (totb - head) >> 3;
+    const u32 tail0 = head + nwords * 8;                          // first byte behind the last aligned word
+    u64 *outw = reinterpret_cast<u64 *>(out + head);
+    for (u32 w = tid; w < nwords; w += EXP_THREADS)
+        outw[w] = pack_pull(s_boff, s_gpos, s_len, ns, head + 8 * w, 8, src8, src_bit0, src_words);
+    if ((u32)tid < head) out[tid] = (u8)pack_pull(s_boff, s_gpos, s_len, ns, (u32)tid, 1, src8, src_bit0, src_words);
+    if ((u32)tid < totb - tail0) out[tail0 + tid] = (u8)pack_pull(s_boff, s_gpos, s_len, ns, tail0 + tid, 1, src8, src_bit0, src_words);
 }
 
 } // namespace hsk
