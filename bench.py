@@ -207,6 +207,7 @@ def main():
                          "hist_GBs": (st["hist_bytes"] / max(st["hist_ms"], 1e-9) / 1e6) if st["hist_ms"] else None,
                          "agg_GBs": (st["agg_bytes"] / max(st["agg_ms"], 1e-9) / 1e6) if st["agg_ms"] else None,
                          "agg_avg_launch_ms": (st["agg_ms"] / max(int(st["agg_launches"]), 1)) if st["agg_ms"] else None},
+            "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks", "onepass_misses") if k_ in st},
             "phases_ms_per_step": {k_: v / a.steps for k_, v in sorted(phase.items())},
             "whole_path_algorithmic_GBs": ((152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)) * nk_rank) / (phase.get("ms_total", 0) / a.steps * 1e-3) / 1e9 if phase.get("ms_total") else None,
         }

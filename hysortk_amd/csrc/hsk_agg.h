@@ -331,6 +331,8 @@ constexpr int AGB_THREADS = 1024;
 constexpr int AGB_LOG2CAP = 13;
 constexpr int AGB_CAP = 1 << AGB_LOG2CAP;
 constexpr int AGB_MAX_LOAD = AGB_CAP * 3 / 4;      // distinct keys accepted (beyond that probes get long: overflow)
+constexpr int AGB_NBKT = 4096;                     // buckets of the in-LDS counting sort: the 12 key bits below the 8-bit bin prefix
+constexpr int AGB_BKT_SHIFT = 64 - 8 - 12;
 
 template <typename T>
 __device__ __forceinline__ T block_excl_scan_1024(T v, T *scratch /* >= 16 */, T *total)
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
     constexpr int PER = CAP / AGB_THREADS;          // 8 slots per thread
     __shared__ u64 s_key[CAP];
     __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_hist[AGB_NBKT];
     __shared__ u32 s_scr[16];
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
@@ -372,11 +375,18 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
         u64 k[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AGB_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+        // first probes of all 8 records together (independent LDS reads: one latency instead of eight); a record whose key
+        // already sits in its home slot -- nearly all of them after a key's first occurrence -- is one more LDS atomic
+        u32 hh[UNR]; u64 cur0[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { const u32 x = (u32)(k[u] >> 32) ^ (u32)k[u]; hh[u] = (x * 0x9E3779B1u) >> (32 - AGB_LOG2CAP); }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) cur0[u] = __hip_atomic_load(&s_key[hh[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if (k[u] == AG_EMPTY) continue;
-            const u32 x = (u32)(k[u] >> 32) ^ (u32)k[u];
-            u32 h = (x * 0x9E3779B1u) >> (32 - AGB_LOG2CAP);
+            if (cur0[u] == k[u]) { atomicAdd(&s_cnt[hh[u]], 1u); continue; }
+            u32 h = hh[u];
             bool done = false;
             for (int p = 0; p < AG_MAX_PROBE; ++p) {
                 u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -406,7 +416,48 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
         return;
     }
 
-    // ---- 3. order the distinct keys (bitonic network over the next power of two) --------------------------------
+    // ---- 3. order the distinct keys ------------------------------------------------------------------------------
+    // Up to CAP / 2 keys (the usual case): counting sort on the 12 bits below the bin prefix into the idle upper half of
+    // the table (the keys of a bin are close to uniform there: about one key per bucket), then every key ranks itself
+    // inside its bucket.  ~10 LDS operations per key instead of the ~400 of a sorting network over {key, count} pairs;
+    // a bucket that collects many keys (a shared 10-base prefix) only costs its own square.
+    if (D <= (u32)(CAP / 2)) {
+        constexpr int EPT = CAP / 2 / AGB_THREADS;          // 4 elements per thread
+        for (int i = tid; i < AGB_NBKT; i += AGB_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        u64 ek[EPT]; u32 ec[EPT], er[EPT];
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            const u32 i = x * AGB_THREADS + tid;
+            ek[x] = AG_EMPTY; ec[x] = 0; er[x] = 0;
+            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_hist[(u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1)], 1u); }
+        }
+        __syncthreads();
+        {
+            u32 v[AGB_NBKT / AGB_THREADS], sum = 0;
+#pragma unroll
+            for (int x = 0; x < AGB_NBKT / AGB_THREADS; ++x) { v[x] = s_hist[tid * (AGB_NBKT / AGB_THREADS) + x]; sum += v[x]; }
+            u32 ex = block_excl_scan_1024<u32>(sum, s_scr, nullptr);
+#pragma unroll
+            for (int x = 0; x < AGB_NBKT / AGB_THREADS; ++x) { s_hist[tid * (AGB_NBKT / AGB_THREADS) + x] = ex; ex += v[x]; }
+        }
+        __syncthreads();
+        u64 *ok = s_key + CAP / 2; u32 *oc = s_cnt + CAP / 2;
+#pragma unroll
+        for (int x = 0; x < EPT; ++x)
+            if (ek[x] != AG_EMPTY) { const u32 p = s_hist[(u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1)] + er[x]; ok[p] = ek[x]; oc[p] = ec[x]; }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            if (ek[x] == AG_EMPTY) continue;
+            const u32 bk = (u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1);
+            const u32 b0 = s_hist[bk], b1 = (bk + 1 < (u32)AGB_NBKT) ? s_hist[bk + 1] : D;
+            u32 r = b0;
+            for (u32 q = b0; q < b1; ++q) r += ok[q] < ek[x];
+            s_key[r] = ek[x]; s_cnt[r] = ec[x];
+        }
+        __syncthreads();
+    } else {
     u32 P = 2; while (P < D) P <<= 1;
     for (u32 i = D + tid; i < P; i += AGB_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; }
     __syncthreads();
@@ -422,6 +473,7 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
             }
             __syncthreads();
         }
+    }
     }
 
     // ---- 4. filter, entries in key order to the bin's slots ------------------------------------------------------

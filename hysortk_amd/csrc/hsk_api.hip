@@ -865,6 +865,74 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     return rc;
 }
 
+// ---- the one-pass plan: ONE scatter pass (top 8 bits) over `nb` tasks in ONE launch (onesweep_many_kernel) ------
+// d_ghist: [nb][MAX_PASSES][256], histogram of pass 0 (bits 56..63) counted by expand_batch.  nb is a multiple of 8.
+constexpr int MANY_MAX = 64;
+template <int NW>
+static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    constexpr int TILE = SortTile<NW>::TILE;
+    const int per_xcd = nb / 8;
+    std::vector<u64> hh((size_t)nb * MAX_PASSES * 256), hb((size_t)nb * 256, 0);
+    HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 ntiles[MANY_MAX]; size_t lb_off[MANY_MAX + 1]; lb_off[0] = 0;
+    u64 ntot = 0;
+    for (int i = 0; i < nb; ++i) {
+        bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
+        u64 run = 0; bool trivial = false;
+        for (int d = 0; d < 256; ++d) { const u64 v = hh[((size_t)i * MAX_PASSES) * 256 + d]; if (v == bt[i].n) trivial = true; hb[(size_t)i * 256 + d] = run; run += v; }
+        ntiles[i] = (bt[i].n < 2 || trivial) ? 0 : (bt[i].n + TILE - 1) / TILE;      // one digit value only: already "sorted"
+        if (bt[i].n >= (1ULL << 30)) return fail(c, HSK_ERR_INTERNAL, "one-pass plan on a task of 2^30 keys");
+        lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * 4;
+        if (ntiles[i]) ntot += bt[i].n;
+    }
+    if (lb_off[nb] == 0) return HSK_OK;
+    u64 *d_gbase; u32 *d_tk, *d_pre; void *d_lb; SortArgs *d_tasks;
+    DALLOC(c, d_gbase, u64 *, (size_t)nb * 256 * 8);
+    DALLOC(c, d_tk, u32 *, (size_t)(nb + 8) * 4 + 64);                 // task tickets, then the 8 XCD counters
+    DALLOC(c, d_pre, u32 *, (size_t)8 * (per_xcd + 1) * 4);
+    DALLOC(c, d_lb, void *, lb_off[nb] + 256);
+    DALLOC(c, d_tasks, SortArgs *, sizeof(SortArgs) * nb);
+    HIPCHK(c, hipMemsetAsync(d_tk, 0, (size_t)(nb + 8) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_lb, 0, lb_off[nb], c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<SortArgs> ta(nb); std::vector<u32> pre((size_t)8 * (per_xcd + 1), 0);
+    u64 max_xcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        u32 run = 0;
+        for (int j = 0; j < per_xcd; ++j) { pre[(size_t)x * (per_xcd + 1) + j] = run; run += (u32)ntiles[x + 8 * j]; }
+        pre[(size_t)x * (per_xcd + 1) + per_xcd] = run;
+        max_xcd = std::max<u64>(max_xcd, run);
+    }
+    for (int i = 0; i < nb; ++i) {
+        SortArgs &a = ta[i]; memset(&a, 0, sizeof a);
+        a.keys_in = bt[i].kA; a.keys_out = bt[i].kB; a.vals_in = nullptr; a.vals_out = nullptr; a.n = bt[i].n; a.ntiles = ntiles[i];
+        a.word = NW - 1; a.shift = 56; a.bits = 8;
+        a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lb + lb_off[i]; a.ticket = d_tk + i; a.err = c->d_err;
+    }
+    HIPCHK(c, hipMemcpyAsync(d_tasks, ta.data(), sizeof(SortArgs) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pre, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                       // ta / pre / hb are host stack memory
+    ManySortArgs m; m.tasks = d_tasks; m.xcd_prefix = d_pre; m.xcd_counter = d_tk + nb; m.per_xcd = per_xcd;
+    const u32 grid = (u32)(8 * (max_xcd + max_xcd / 8) + 64);
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+    hipLaunchKernelGGL((onesweep_many_kernel<NW, false, u32>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, m);
+    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<u32> tk(nb + 8);
+    HIPCHK(c, hipMemcpyAsync(tk.data(), d_tk, (size_t)(nb + 8) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = HSK_OK;
+    for (int i = 0; i < nb && rc == HSK_OK; ++i) {
+        if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain sort task %d (%u of %llu tiles)", i & 7, i, tk[i], (unsigned long long)ntiles[i]);
+        if (ntiles[i]) bt[i].out_k = bt[i].kB;
+    }
+    c->pool.release(d_gbase); c->pool.release(d_tk); c->pool.release(d_pre); c->pool.release(d_lb); c->pool.release(d_tasks);
+    return rc;
+}
+
 static int alloc_sort_scratch(hsk_ctx *c, SortScratch &sc)
 {
     DALLOC(c, sc.ghist, u64 *, (size_t)MAX_PASSES * 256 * 8);
@@ -971,10 +1039,11 @@ static bool agg_enabled();
 // k-mers; HSK_ONEPASS=0 keeps two passes + 16-bit bins for every task.
 constexpr u64 ONEPASS_TASK_KMERS = 1ULL << 24;          // auto_ntasks aims at this many base positions per task
 constexpr u64 ONEPASS_MAX_TASK = 3ULL << 23;            // larger tasks: bins with too many distinct keys for the LDS table
-// EXPERIMENTAL, off unless HSK_ONEPASS=1: at 10 Gbp it needs ~600 tasks of 13 M k-mers, and launches of 8 such tasks are
-// too small for the scatter pass (2.0 instead of 4.6 TB/s) and the bitonic ordering of ~2 500 distinct keys per bin is
-// LDS-bound (241 ms per step against 166 ms with two passes); kept because it is the plan that removes 16 B of HBM
-// traffic per k-mer once the launches cover 64 tasks and the bins are ordered without a sorting network.
+// EXPERIMENTAL, off unless HSK_ONEPASS=1: at 10 Gbp it means ~600 tasks of 13 M k-mers, processed in batches of 64
+// (one scatter launch per batch).  It removes 16 B of HBM traffic per k-mer and the scatter phase drops from 57 to 36
+// ms, but the whole step is slower today (226 ms against 168 ms): the aggregation over 51 000-record bins runs one
+// 1024-thread workgroup per CU (112 KB of LDS) and only reaches 20 % issue utilisation (82 ms against 27 ms), placing
+// supermers into 600 tasks costs +8 ms and 76 small expand launches +8 ms.
 static bool onepass_enabled()
 {
     static const bool on = getenv("HSK_ONEPASS") && atoi(getenv("HSK_ONEPASS")) != 0;
@@ -1365,6 +1434,72 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // still beats eight full-width passes per task on the single-task path); ex->force_batch pads any remainder.
     const u32 EMPTY_TASK = ~0u;
     TaskSegs empty_segs;
+    std::vector<TaskOut> touts(ntasks);
+    std::vector<u32> mine_done;                          // tasks finished by the one-pass loop below
+    // ---- the one-pass plan (HSK_ONEPASS=1): batches of up to 64 small tasks -------------------------------------
+    // expand (8 tasks per launch, digit histogram of the top 8 bits) -> ONE scatter pass over all tasks of the batch in
+    // one launch -> aggregation over 8-bit prefix bins (8 tasks per launch); tasks whose bins overflow the LDS table are
+    // ordered on the next 8 bits too and finished over 16-bit bins.  Single GPU only (the exchange feeds groups of 8).
+    if constexpr (NW == 1) {
+        const bool op = !ext && !feeder && batch_enabled && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled() &&
+                        max_task <= ONEPASS_MAX_TASK && !mine.empty() && !(ex && ex->heavy_in && !ex->heavy_in->empty());
+        if (op) {
+            const int nbmax = (int)std::min<size_t>(MANY_MAX, (mine.size() + 7) / 8 * 8);
+            std::vector<u64 *> kAm(nbmax, nullptr), kBm(nbmax, nullptr);
+            for (int i = 0; i < nbmax; ++i) { DALLOC(c, kAm[i], u64 *, max_task * 8 + 64); DALLOC(c, kBm[i], u64 *, max_task * 8 + 64); }
+            u64 *d_gh; DALLOC(c, d_gh, u64 *, (size_t)nbmax * MAX_PASSES * 256 * 8);
+            PassDesc plan1[MAX_PASSES];
+            const int np1 = make_hybrid_plan(plan1, 8, 0);
+            TaskInput dflt1; dflt1.len = x_len; dflt1.src = x_src; dflt1.pos = x_pos; dflt1.rid = x_rid;
+            for (size_t mb = 0; mb < mine.size(); mb += MANY_MAX) {
+                const int nreal = (int)std::min<size_t>(MANY_MAX, mine.size() - mb);
+                const int nb = (nreal + 7) / 8 * 8;
+                BatchTask bt[MANY_MAX];
+                pt.begin(PH_EXTRACT);
+                HIPCHK(c, hipMemsetAsync(d_gh, 0, (size_t)nb * MAX_PASSES * 256 * 8, c->stream));
+                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
+                    ExpandJob jobs[XCD_BATCH];
+                    for (int i = 0; i < XCD_BATCH; ++i) {
+                        BatchTask &b = bt[c0 + i]; b = BatchTask(); b.kA = kAm[c0 + i]; b.kB = kBm[c0 + i];
+                        jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs;
+                        if (c0 + i >= nreal) continue;
+                        const u32 t = mine[mb + c0 + i];
+                        b.n = segs[t].nkmers;
+                        jobs[i].ts = &segs[t]; jobs[i].sm_len = dflt1.len; jobs[i].src = dflt1.src; jobs[i].sm_pos = dflt1.pos; jobs[i].sm_rid = dflt1.rid;
+                        jobs[i].keys = b.kA; jobs[i].vals = nullptr; jobs[i].ghist = d_gh + (size_t)(c0 + i) * MAX_PASSES * 256;
+                    }
+                    int rc = expand_batch<NW>(c, jobs, XCD_BATCH, np1, plan1); if (rc) return rc;
+                }
+                pt.end(PH_EXTRACT);
+                pt.begin(PH_SORT);
+                { int rc = sort_many_onepass<NW>(c, bt, nb, d_gh); if (rc) return rc; }
+                pt.end(PH_SORT);
+                pt.begin(PH_COUNT);
+                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
+                    TaskOut fo[XCD_BATCH];
+                    int rc = agg_finish_batch_device<1>(c, bt + c0, K, max_task, d_histo, histo_len, fo, 8); if (rc) return rc;
+                    BatchTask b2[XCD_BATCH]; bool any_miss = false;
+                    for (int i = 0; i < XCD_BATCH; ++i) {
+                        b2[i] = BatchTask();
+                        if (!fo[i].failed) continue;
+                        any_miss = true; c->stats.onepass_misses++;
+                        b2[i].n = bt[c0 + i].n; b2[i].kA = bt[c0 + i].out_k; b2[i].kB = (bt[c0 + i].out_k == bt[c0 + i].kA) ? bt[c0 + i].kB : bt[c0 + i].kA;
+                    }
+                    if (any_miss) {
+                        rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
+                        TaskOut f2[XCD_BATCH];
+                        rc = agg_finish_batch_device<1>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
+                        for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
+                    }
+                    for (int i = 0; i < XCD_BATCH; ++i) if (c0 + i < nreal) touts[mine[mb + c0 + i]] = fo[i];
+                }
+                pt.end(PH_COUNT);
+            }
+            for (int i = 0; i < nbmax; ++i) { c->pool.release(kAm[i]); c->pool.release(kBm[i]); }
+            c->pool.release(d_gh);
+            mine_done.swap(mine);                            // nothing left for the two-pass loops
+        }
+    }
     const bool forced = ex && ex->force_batch && batch_enabled;
     if ((batch_enabled && mine.size() >= (size_t)XCD_BATCH && mine.size() % XCD_BATCH >= 3) || (forced && !mine.empty()))
         while (mine.size() % XCD_BATCH) mine.push_back(EMPTY_TASK);
@@ -1412,7 +1547,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         HIPCHK(c, hipStreamWaitEvent(xstream, fence, 0));
         ev_put(c, fence);
     }
-    std::vector<TaskOut> touts(ntasks);
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
@@ -1428,7 +1562,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
         // one pass while the table keeps up; after a batch worth of misses (low coverage: every bin overflows) two passes
-        const int prefix_bits = !agg ? 64 - HYBRID_SHIFT : ((onepass_ok && c->onepass_misses < XCD_BATCH) ? 8 : AG_PREFIX_BITS);
+        const int prefix_bits = !agg ? 64 - HYBRID_SHIFT : AG_PREFIX_BITS;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
         const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
@@ -1546,6 +1680,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.end(PH_COUNT);
     }
     for (u32 t : mine) { if (t == EMPTY_TASK) continue; n_total += touts[t].n; pay_total += touts[t].npay; }
+    for (u32 t : mine_done) { n_total += touts[t].n; pay_total += touts[t].npay; }
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     {
         int rc = check_device_error(c); if (rc) return rc;

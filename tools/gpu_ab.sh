@@ -6,6 +6,6 @@ for kv in "$@"; do
   python - "$kv" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab.json").read())
-print("%-40s %.3f G k-mers/s  %.1f ms/step  %s" % (sys.argv[1], d["value"] / 1e9, d["ms_per_step"], {k[3:]: round(v, 1) for k, v in d["phases_ms_per_step"].items() if k not in ("ms_d2h", "ms_exchange")}))
+print("%-40s %.3f G k-mers/s  %.1f ms/step  %s ntasks %s %s" % (sys.argv[1], d["value"] / 1e9, d["ms_per_step"], {k[3:]: round(v, 1) for k, v in d["phases_ms_per_step"].items() if k not in ("ms_d2h", "ms_exchange")}, d["config"]["ntasks"], d.get("path_stats")))
 PY
 done
