@@ -318,6 +318,225 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// EXTENSION (every k-mer carries (PosInRead, ReadId)): the same 16-bit prefix bins, but the records must come out
+// GROUPED by key, because an entry owns a slice of the task's payload array (count_sorted_kmers copies the run's
+// pos/rid, reference src/kmerops.cpp:1430-1437).  Two sweeps over the bin instead of ordering its records:
+//   1. count the distinct keys in the LDS table (as above), order them, prefix-sum the counts in key order:
+//      group g of the bin starts at record offset goff[g] of the bin's range;
+//   2. read the records again (they are in L2), find each record's group through the table and give it the next free
+//      place of the group (LDS atomic): pos / rid are written straight to their final arrays.  The order of the
+//      payloads inside one k-mer is free (the reference's sorts are not stable either).
+// Entries {key, count} and their payload offsets go to per-bin slots and are compacted afterwards.
+// ------------------------------------------------------------------------------------------------------------
+struct AggExtTask {
+    const u64 *keys, *vals; u64 n;
+    u64 *bounds, *bin_cnt;
+    u64 *scratch_e;                // {key, count} of kept entries, bin b from entry slot (bounds[b] >> slot_shift)
+    u64 *scratch_p;                // their payload offsets, same slots
+    u32 slot_shift, active;
+    u32 *pos; int32_t *rid;        // [n] payloads grouped by key, bins in order
+    u64 payoff_add;                // offset of this task's payload range in the rank's payload arrays
+    u32 *flags;
+};
+struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; };
+
+__global__ __launch_bounds__(AG_THREADS) void bin_bounds_ext_kernel(AggExtArgs a)
+{
+    const AggExtTask &t = a.t[blockIdx.y];
+    const u32 b = blockIdx.x * AG_THREADS + threadIdx.x;
+    if (!t.active || b > a.nbins) return;
+    u64 lo = 0, hi = t.n;
+    if (b == a.nbins) lo = t.n;
+    else while (lo < hi) {
+        const u64 mid = lo + ((hi - lo) >> 1);
+        if ((u32)(t.keys[mid] >> a.shift) < b) lo = mid + 1; else hi = mid;
+    }
+    t.bounds[b] = lo;
+}
+
+template <int LOG2CAP>
+__global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
+{
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    __shared__ u64 s_tkey[CAP];     // the table: stays as it is for the second sweep
+    __shared__ u32 s_tcnt[CAP];
+    __shared__ u16 s_trank[CAP];    // slot -> index of its key in key order
+    __shared__ u64 s_key[CAP];      // distinct keys compacted, then in key order
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u16 s_slot[CAP];     // origin slot of s_key[i]
+    __shared__ u32 s_goff[CAP];     // first record of group i inside the bin
+    __shared__ u32 s_cur[CAP];      // next free place of group i
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_ovf;
+    const AggExtTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    const u32 b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_tkey[j * AG_THREADS + tid] = AG_EMPTY; s_tcnt[j * AG_THREADS + tid] = 0; s_cur[j * AG_THREADS + tid] = 0; }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    // ---- 1. first sweep: count ----------------------------------------------------------------------------------
+    constexpr int UNR = 8;
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+        u64 k[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (k[u] == AG_EMPTY) continue;
+            u32 h = agg_slot<LOG2CAP>(k[u]);
+            bool done = false;
+            for (int p = 0; p < AG_MAX_PROBE; ++p) {
+                u64 cur = __hip_atomic_load(&s_tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_tkey[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
+                if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_tcnt[h], 1u); done = true; break; }
+                h = (h + 1) & (CAP - 1);
+            }
+            if (!done) s_ovf = 1;
+        }
+    }
+    __syncthreads();
+    if (s_ovf) {
+        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        return;
+    }
+
+    // ---- 2. distinct keys in key order, group offsets --------------------------------------------------------------
+    u32 D;
+    {
+        u32 occ = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) occ += s_tkey[tid * PER + j] != AG_EMPTY;
+        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 sl = tid * PER + j;
+            const u64 kk = s_tkey[sl];
+            if (kk != AG_EMPTY) { s_key[o] = kk; s_cnt[o] = s_tcnt[sl]; s_slot[o] = (u16)sl; ++o; }
+        }
+    }
+    __syncthreads();
+    if (D <= (u32)AG_THREADS) {
+        u64 k = 0; u32 c = 0, r = 0; u16 sl = 0;
+        if ((u32)tid < D) {
+            k = s_key[tid]; c = s_cnt[tid]; sl = s_slot[tid];
+            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
+        }
+        __syncthreads();
+        if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; s_slot[r] = sl; }
+        __syncthreads();
+    } else {
+        u32 P = 512; while (P < D) P <<= 1;
+        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; s_slot[i] = 0; }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < P; i += AG_THREADS) {
+                    const u32 q = i ^ j;
+                    if (q > i) {
+                        const u64 x = s_key[i], y = s_key[q];
+                        const bool up = (i & kk) == 0;
+                        if ((x > y) == up) {
+                            const u32 cx = s_cnt[i], cy = s_cnt[q]; const u16 sx = s_slot[i], sy = s_slot[q];
+                            s_key[i] = y; s_key[q] = x; s_cnt[i] = cy; s_cnt[q] = cx; s_slot[i] = sy; s_slot[q] = sx;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    u32 kept = 0;
+    {
+        u32 csum = 0, cv[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            cv[j] = i < D ? s_cnt[i] : 0;
+            csum += cv[j];
+            kept += (i < D && cv[j] >= a.lower && cv[j] <= a.upper);
+        }
+        u32 go = block_excl_scan_256<u32>(csum, s_scr, nullptr);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            if (i < D) { s_goff[i] = go; s_trank[s_slot[i]] = (u16)i; }
+            go += cv[j];
+        }
+    }
+    u32 tot;
+    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);      // (barriers inside: s_goff / s_trank are complete for the second sweep)
+    {
+        const u64 slot0 = (s >> t.slot_shift) + w;
+        u64 *de = t.scratch_e + slot0 * 2; u64 *dp = t.scratch_p + slot0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            if (i < D) {
+                const u32 c = s_cnt[i];
+                if (c >= a.lower && c <= a.upper) { de[0] = s_key[i]; de[1] = (u64)c; dp[0] = t.payoff_add + s + s_goff[i]; de += 2; ++dp; }
+            }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+
+    // ---- 3. second sweep: every record to the next free place of its group -----------------------------------------
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+        u64 k[UNR], v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; const bool ok = idx < e; k[u] = ok ? t.keys[idx] : AG_EMPTY; v[u] = ok ? t.vals[idx] : 0; }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (k[u] == AG_EMPTY) continue;
+            u32 h = agg_slot<LOG2CAP>(k[u]);
+            while (s_tkey[h] != k[u]) h = (h + 1) & (CAP - 1);             // present: the first sweep put it there
+            const u32 g = s_trank[h];
+            const u64 o = s + s_goff[g] + atomicAdd(&s_cur[g], 1u);
+            t.pos[o] = (u32)v[u]; t.rid[o] = (int32_t)(v[u] >> 32);
+        }
+    }
+}
+
+// entries and payload offsets from the per-bin slots to their final places; count histogram.  One wave per bin.
+struct AggExtCompactArgs { const u64 *scratch_e[AG_BATCH]; const u64 *scratch_p[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH];
+                           u64 *entries[AG_BATCH]; u64 *payoff[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; };
+__global__ __launch_bounds__(AG_THREADS) void agg_ext_compact_kernel(AggExtCompactArgs ca)
+{
+    __shared__ u32 s_hist[AG_LDS_HIST];
+    u64 *entries = ca.entries[blockIdx.y];
+    if (!entries) return;
+    const u64 *se = ca.scratch_e[blockIdx.y], *sp = ca.scratch_p[blockIdx.y], *bounds = ca.bounds[blockIdx.y], *bin_off = ca.bin_off[blockIdx.y];
+    u64 *payoff = ca.payoff[blockIdx.y];
+    for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) s_hist[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (u32 b = blockIdx.x * 4 + wave; b < ca.nbins; b += gridDim.x * 4) {
+        const u64 o = bin_off[b];
+        const u64 cnt = bin_off[b + 1] - o;
+        const u64 slot0 = bounds[b] >> ca.slot_shift;
+        for (u64 i = lane; i < cnt * 2; i += 64) {
+            const u64 v = se[slot0 * 2 + i];
+            entries[o * 2 + i] = v;
+            if (i & 1) {
+                if (v < (u64)AG_LDS_HIST) atomicAdd(&s_hist[(u32)v], 1u);
+                else if (v < ca.histo_len) atomicAdd((unsigned long long *)&ca.histo[v], 1ULL);
+            }
+        }
+        for (u64 i = lane; i < cnt; i += 64) payoff[o + i] = sp[slot0 + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < AG_LDS_HIST; i += AG_THREADS) {
+        const u32 c = s_hist[i];
+        if (c && (u32)i < ca.histo_len) atomicAdd((unsigned long long *)&ca.histo[i], (unsigned long long)c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // One scatter pass, then aggregate: bins of the top 8 key bits.  With tasks of ~2^24 k-mers a bin holds ~65 000
 // records and ~2 500 distinct keys (32 x coverage): too many records for LDS, but the hash table only has to hold
 // the DISTINCT keys.  One workgroup of 1024 threads per bin, 8192 slots (96 KB of the CU's 160 KB LDS): the bin

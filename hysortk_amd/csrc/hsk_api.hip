@@ -311,12 +311,14 @@ struct ParseJob {
     ParseArgs a; u32 nblocks = 0, ntasks = 0; bool fast = false, empty = true;
     const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
     u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
+    u32 *d_tile_r0 = nullptr;     // EXTENSION: first read of every tile (hint for the (pos, rid) lookup)
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
 };
 
 static void parse_release(hsk_ctx *c, ParseJob &j)
 {
     c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
+    c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr;
     j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
 }
 
@@ -355,6 +357,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         DALLOC(c, j.d_overflow, u32 *, 256);
         HIPCHK(c, hipMemsetAsync(j.d_overflow, 0, 4, c->stream));
         a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec; a.overflow = j.d_overflow;
+        if (c->cfg.extension && nreads < (1ULL << 32)) { DALLOC(c, j.d_tile_r0, u32 *, (size_t)a.ntiles * 4 + 64); a.tile_r0 = j.d_tile_r0; }
         hipLaunchKernelGGL(scan_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
         HIPCHK(c, hipMemcpyAsync(h_ovf, j.d_overflow, 4, hipMemcpyDeviceToHost, c->stream));
@@ -362,6 +365,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
+            c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; a.tile_r0 = nullptr;
             c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); j.d_tile_rec = j.d_tile_nrec = nullptr;
             a.tile_rec = a.tile_nrec = nullptr;
         }
@@ -420,7 +424,7 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
         else if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                                    st.sm_gpos, st.tot_sup, j.d_roff, j.nreads, j.rid_base, st.sm_pos, st.sm_rid);
+                                    st.sm_gpos, st.tot_sup, j.d_roff, j.nreads, j.rid_base, st.sm_pos, st.sm_rid, (const u32 *)j.d_tile_r0, a.ntiles);
     }
     HIPCHK(c, hipGetLastError());
     // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
@@ -1256,6 +1260,112 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     return rc;
 }
 
+// ---- EXTENSION: two passes + grouping aggregation (hsk_agg.h: agg_ext_kernel) ---------------------------------------
+// pay_before[i]: offset of task i's payload range in the rank's payload arrays (payload_off values are global over the
+// owned tasks in ascending id).
+static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u64 *pay_before, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 slot_shift = L >= 2 ? 1 : 0;
+    const u32 nbins = AG_BINS;
+    const size_t per = (size_t)nbins + 8;
+    u64 *d_bounds, *d_cnt; u32 *d_flags;
+    DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_flags, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+    AggExtArgs a; memset(&a, 0, sizeof a);
+    AggArgs sa; memset(&sa, 0, sizeof sa);               // the view agg_scan_kernel needs
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT;
+    sa.nbins = nbins; sa.shift = AG_SHIFT; sa.nw = 1;
+    bool own_scratch[AG_BATCH] = {false};
+    u64 ntot = 0;
+    for (int i = 0; i < AG_BATCH; ++i) {
+        AggExtTask &t = a.t[i];
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        u64 *other_k = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        u64 *other_v = (bt[i].out_v == bt[i].vA) ? bt[i].vB : bt[i].vA;
+        t.keys = bt[i].out_k; t.vals = bt[i].out_v; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
+        t.slot_shift = slot_shift; t.active = 1; t.payoff_add = pay_before[i]; ntot += bt[i].n;
+        if (slot_shift) { t.scratch_e = other_k; t.scratch_p = other_v; }       // n / 2 entries of 16 + 8 bytes: the idle ping-pong buffers
+        else {
+            t.scratch_e = (u64 *)c->pool.alloc(bt[i].n * 16 + 64); t.scratch_p = (u64 *)c->pool.alloc(bt[i].n * 8 + 64); own_scratch[i] = true;
+            if (!t.scratch_e || !t.scratch_p) return fail(c, HSK_ERR_OOM, "finish scratch");
+        }
+        outs[i].npay = bt[i].n;
+        DALLOC(c, outs[i].pos, u32 *, bt[i].n * 4); DALLOC(c, outs[i].rid, int32_t *, bt[i].n * 4);
+        t.pos = outs[i].pos; t.rid = outs[i].rid;
+        sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].active = 1;
+    }
+    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
+    auto run = [&](int log2cap) -> int {
+        for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HSK_OK;
+    };
+    memset(&h, 0, sizeof h);
+    hipLaunchKernelGGL(bin_bounds_ext_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
+    bool retry = false, done[AG_BATCH];
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
+    if (retry) {
+        AggExtArgs keep = a;
+        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
+        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+        memset(&h, 0, sizeof h);
+        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
+        a = keep;
+    }
+    AggExtCompactArgs ca; memset(&ca, 0, sizeof ca);
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
+    bool any = false;
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || !done[i]) continue;
+        c->stats.fused_tasks++;
+        outs[i].n = total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16); outs[i].payoff = (u64 *)c->pool.alloc(outs[i].n * 8);
+            if (!outs[i].entries || !outs[i].payoff) { rc = fail(c, HSK_ERR_OOM, "task output"); break; }
+            ca.scratch_e[i] = a.t[i].scratch_e; ca.scratch_p[i] = a.t[i].scratch_p; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt;
+            ca.entries[i] = outs[i].entries; ca.payoff[i] = outs[i].payoff;
+            any = true;
+        }
+    }
+    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_ext_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || done[i]) continue;
+        // the long way for this task: full-width passes (payload carried) from the current order, then the two-pass counter
+        c->stats.redone_tasks++;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); own_scratch[i] = false; }
+        const u64 payadd = pay_before[i];
+        free_task_out(c, outs[i]);
+        SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+        u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+        u64 *vcur = bt[i].out_v, *vother = (vcur == bt[i].vA) ? bt[i].vB : bt[i].vA;
+        rc = sort_task_device<1>(c, cur, other, vcur, vother, bt[i].n, K, sc1, &sk, &sv, false);
+        free_sort_scratch(c, sc1);
+        if (rc == HSK_OK) rc = count_task_device<1>(c, sk, sv, bt[i].n, payadd, d_histo, histo_len, outs[i]);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); }
+    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Exchange / sort overlap (multi-GPU).  The owned tasks of every rank are cut into groups of
 // XCD_BATCH consecutive tasks; group g+1 travels on `comm_stream` (RCCL send/recv, or device copies
@@ -1555,6 +1665,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
     const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
     const bool agg = fused && agg_enabled();
+    // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
+    const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
     const bool onepass_ok = NW == 1 && agg && onepass_enabled() && max_task <= ONEPASS_MAX_TASK;
     c->onepass_misses = 0;
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
@@ -1562,10 +1674,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
         // one pass while the table keeps up; after a batch worth of misses (low coverage: every bin overflows) two passes
-        const int prefix_bits = !agg ? 64 - HYBRID_SHIFT : AG_PREFIX_BITS;
+        const int prefix_bits = (agg || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
-        const int npass = batch_pass_plan<NW>(c, K, fused, prefix_bits, plan);
+        const int npass = batch_pass_plan<NW>(c, K, fused || fused_ext, prefix_bits, plan);
         if (piped && done_valid[sl]) HIPCHK(c, hipStreamWaitEvent(xstream, ev_done[sl], 0));     // the slot's previous batch is counted
         pt.begin(PH_EXTRACT, xstream);
         HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, xstream));
@@ -1605,10 +1717,17 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K, fused, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
+        { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
-        if (fused) {
+        if (fused_ext) {
+            if constexpr (NW == 1) {
+                TaskOut fo[XCD_BATCH]; u64 pb[XCD_BATCH];
+                for (int i = 0; i < XCD_BATCH; ++i) pb[i] = mine[pos + i] != EMPTY_TASK ? pay_before[mine[pos + i]] : 0;
+                int rc = agg_ext_finish_batch_device(c, bt, K, pb, d_histo, histo_len, fo); if (rc) return rc;
+                for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
+            }
+        } else if (fused) {
             if constexpr (NW <= 2) {
                 TaskOut fo[XCD_BATCH];
                 int rc;

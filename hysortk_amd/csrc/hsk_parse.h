@@ -68,6 +68,7 @@ struct ParseArgs {
     u32 rec_cap;
     u32 place_group;           // tiles placed together by one place_kernel step (rec_cap * place_group <= PLACE_MAX_REC)
     u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
+    u32 *tile_r0;              // optional [ntiles] (EXTENSION): first read overlapping the tile, kept for resolve_pos_rid_kernel
     const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
 };
 
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                     r1 = find_read(a.roff, r0, a.nreads - 1, blast);
                 }
                 s_rng[0] = r0; s_rng[1] = r1; s_rng[2] = rb; s_rng[3] = fast ? 1 : 0;
+                if (a.tile_r0) a.tile_r0[tile] = (u32)r0;
             }
         }
         __syncthreads();
@@ -733,12 +735,22 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
 
 // EXTENSION: (PosInRead, ReadId) of every supermer from its base position (one index search per supermer;
 // the reference carries them in length_t, include/kmer.hpp:350-360)
-__global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *roff, u64 nreads, int64_t rid_base, u32 *sm_pos, int32_t *sm_rid)
+__device__ __forceinline__ u64 s_gpos_load(const u64 *p, u64 i) { return p[i]; }
+__global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *roff, u64 nreads, int64_t rid_base, u32 *sm_pos, int32_t *sm_rid,
+                                       const u32 *tile_r0, u64 ntiles)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) {
-        const u64 g = sm_gpos[s];
-        const u64 r = find_read(roff, 0, nreads - 1, g >> 2);
+        const u64 g = s_gpos_load(sm_gpos, s);
+        // with the per-tile hint the read is among the few that start inside the supermer's 2048-position tile
+        u64 lo = 0, hi = nreads - 1;
+        if (tile_r0) {
+            const u64 tile = g / PARSE_TILE;
+            lo = tile_r0[tile];
+            hi = (tile + 1 < ntiles) ? tile_r0[tile + 1] : nreads - 1;      // the next tile's first read starts at or before that tile's first byte
+            if (hi < lo) hi = lo;
+        }
+        const u64 r = find_read(roff, lo, hi, g >> 2);
         sm_pos[s] = (u32)(g - roff[r] * 4);
         sm_rid[s] = (int32_t)(rid_base + (int64_t)r);
     }

@@ -433,3 +433,34 @@ def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     assert np.array_equal(res.kmers, ores.keys)
     assert np.array_equal(res.cnt, ores.cnt)
     assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+
+
+@pytest.mark.parametrize("L,U", [(1, 65535), (2, 40)])
+def test_extension_grouping_aggregation(H, O, L, U):
+    """EXTENSION=1 through the batch path (>= 8 tasks): two passes on the top 16 bits with the payload carried, then
+    agg_ext_kernel groups every prefix bin by key and writes (pos, rid) to the entry's slice.  Every kept k-mer's payload set
+    must equal the oracle's; prefix-sharing variants and repeats go through the table ladder and the long way."""
+    from hysortk_amd import synth
+    rng = np.random.default_rng(3)
+    seqs = list(synth.reads(150000, 150, 9000, 17))
+    pre = "ACGTTGCAAGGCTTAACCGG"
+    seqs += [pre + "".join(rng.choice(list("ACGT"), 40)) for _ in range(2500)]
+    seqs += ["AC" * 75] * 30 + [("ACGGTCATTGCA" * 13)[:150]] * 200
+    dna = H.DnaBuffer.from_sequences(seqs)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=31, m=17, L=L, U=U, ext=1, ntasks=16, rid_base=1000, fast=True)
+    with H.Context(K=31, M=17, L=L, U=U, EXT=1, ntasks=16) as c:
+        res = c.count(dna, rid_base=1000)
+        st = c.stats()
+    assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+    for i in list(range(0, len(res), 37)) + [len(res) - 1]:
+        pos, rid = res.payload(i)
+        a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+        assert len(pos) == int(res.cnt[i])
+        assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), i
+    sel = np.concatenate([np.arange(int(o), int(o) + int(c)) for o, c in zip(res.payload_off[:-1], res.cnt)])
+    assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
