@@ -171,6 +171,45 @@ class KmerList:
         return [r.tobytes().decode() for r in arr]
 
 
+class DeviceResult:
+    """A k-mer list that stays in HBM (HSK_FLAG_KEEP_DEVICE).  task(t) gives the device addresses of task t's entries and,
+    with EXTENSION, its CSR payload (payload_off / pos / rid); fetch(t) copies them to numpy arrays."""
+
+    def __init__(self, ctx, res):
+        self.ctx, self.res = ctx, res
+        self.ntasks, self.nw, self.n = int(res.ntasks), int(res.nw), int(res.n)
+        self.task_off = np.ctypeslib.as_array(res.task_off, shape=(self.ntasks + 1,)).copy()
+
+    def task(self, t):
+        e, po, pos, rid = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, npay, base = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.ctx.lib.hsk_result_device_task(C.byref(self.res), t, C.byref(e), C.byref(n), C.byref(po), C.byref(pos), C.byref(rid), C.byref(npay), C.byref(base)))
+        return dict(entries=e.value, n=int(n.value), payload_off=po.value, pos=pos.value, rid=rid.value, npay=int(npay.value), payload_base=int(base.value))
+
+    def fetch(self, t):
+        d = self.task(t)
+        out = dict(n=d["n"], npay=d["npay"], payload_base=d["payload_base"])
+        ent = self.ctx.d2h(d["entries"], d["n"] * (self.nw + 1) * 8).view(np.uint64).reshape(d["n"], self.nw + 1) if d["n"] else np.zeros((0, self.nw + 1), np.uint64)
+        out["kmers"], out["cnt"] = ent[:, :self.nw].copy(), ent[:, self.nw].copy()
+        if d["payload_off"] and d["n"]:
+            out["payload_off"] = self.ctx.d2h(d["payload_off"], d["n"] * 8).view(np.uint64)
+        if d["pos"] and d["npay"]:
+            out["pos"] = self.ctx.d2h(d["pos"], d["npay"] * 4).view(np.uint32)
+            out["rid"] = self.ctx.d2h(d["rid"], d["npay"] * 4).view(np.int32)
+        return out
+
+    def close(self):
+        if self.res is not None:
+            self.ctx.lib.hsk_result_free(self.ctx.h, C.byref(self.res))
+            self.res = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Context:
     """One hsk_ctx (one process, one GPU)."""
 
@@ -181,6 +220,7 @@ class Context:
         cfg.kmer_size, cfg.minimizer_size, cfg.lower_freq, cfg.upper_freq = K, M, L, U
         cfg.extension, cfg.ntasks, cfg.device, cfg.plain_dispatcher, cfg.radix_bits = EXT, ntasks, device, plain_dispatcher, radix_bits
         cfg.flags = (_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_KEEP_DEVICE if keep_device else 0)
+        self.keep_device = bool(keep_device)
         self.cfg = cfg
         self.K, self.EXT = K, EXT
         self.nw = (K + 31) // 32
@@ -251,6 +291,19 @@ class Context:
         if kmers is None:
             kmers, cnt = np.zeros((0, nw), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
         return KmerList(self.K, kmers, cnt, task_off, payoff, pos, rid, histo, info)
+
+    def count_resident(self, dna, rid_base=0):
+        """kmer_count with the result LEFT IN HBM (the context must have keep_device=True): returns a DeviceResult whose
+        per-task entry / CSR payload arrays a following GPU stage reads in place (hsk_result_device_task)."""
+        if not self.keep_device:
+            raise ValueError("count_resident needs Context(keep_device=True)")
+        packed, off, lens = dna.arrays() if isinstance(dna, DnaBuffer) else dna
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        res = _lib.Result()
+        self._check(self.lib.hsk_count(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, rid_base, C.byref(res)))
+        return DeviceResult(self, res)
 
     def count(self, dna, rid_base=0):
         packed, off, lens = dna.arrays() if isinstance(dna, DnaBuffer) else dna

@@ -103,7 +103,6 @@ struct hsk_ctx {
     void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
     u32 *d_err = nullptr;
     Comm comm;
-    int onepass_misses = 0;            // tasks of the current call the one-pass plan could not finish (many misses: two passes from then on)
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 
@@ -965,7 +964,7 @@ static int check_device_error(hsk_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // stage: merge-count one sorted task (a13)
 // ------------------------------------------------------------------------------------------------
-struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; bool failed = false; };
+struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; bool failed = false; u64 pay_base = 0; };
 
 template <int NW>
 static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n, u64 payoff_add, u64 *d_histo, u32 histo_len, TaskOut &out)
@@ -1667,13 +1666,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool agg = fused && agg_enabled();
     // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
     const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
-    const bool onepass_ok = NW == 1 && agg && onepass_enabled() && max_task <= ONEPASS_MAX_TASK;
-    c->onepass_misses = 0;
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
     BatchTask bts[2][XCD_BATCH];
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
-        // one pass while the table keeps up; after a batch worth of misses (low coverage: every bin overflows) two passes
         const int prefix_bits = (agg || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
@@ -1735,23 +1731,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                                                 : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
                 else rc = agg_finish_batch_device<NW>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits);
                 if (rc) return rc;
-                if (agg && prefix_bits == 8) {
-                    // tasks the 8-bit bins could not take (a bin with too many distinct keys): order them on the next 8 bits
-                    // too (two more passes from where they are) and finish them over 16-bit bins
-                    BatchTask b2[XCD_BATCH]; bool any_miss = false;
-                    for (int i = 0; i < XCD_BATCH; ++i) {
-                        b2[i] = BatchTask();
-                        if (!fo[i].failed) continue;
-                        any_miss = true; c->onepass_misses++; c->stats.onepass_misses++;
-                        b2[i].n = bt[i].n; b2[i].kA = bt[i].out_k; b2[i].kB = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
-                    }
-                    if (any_miss) {
-                        rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
-                        TaskOut f2[XCD_BATCH];
-                        rc = agg_finish_batch_device<NW>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
-                        for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
-                    }
-                }
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
             }
         } else {
@@ -1798,7 +1777,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         pt.end(PH_COUNT);
     }
-    for (u32 t : mine) { if (t == EMPTY_TASK) continue; n_total += touts[t].n; pay_total += touts[t].npay; }
+    for (u32 t : mine) { if (t == EMPTY_TASK) continue; touts[t].pay_base = pay_before[t]; n_total += touts[t].n; pay_total += touts[t].npay; }
     for (u32 t : mine_done) { n_total += touts[t].n; pay_total += touts[t].npay; }
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     {
@@ -2249,6 +2228,23 @@ extern "C" void hsk_result_free(hsk_ctx *c, hsk_result *r)
         delete rp;
     }
     memset(r, 0, sizeof *r);
+}
+
+extern "C" int hsk_result_device_task(const hsk_result *r, int32_t task, const void **entries, uint64_t *n,
+                                      const void **payload_off, const void **pos, const void **rid, uint64_t *npay, uint64_t *payload_base)
+{
+    if (!r || !r->priv || task < 0 || task >= r->ntasks) return HSK_ERR_INVALID_ARG;
+    const ResultPriv *rp = (const ResultPriv *)r->priv;
+    if ((size_t)task >= rp->dev_tasks.size()) return HSK_ERR_INVALID_ARG;        // not a KEEP_DEVICE result
+    const TaskOut &to = rp->dev_tasks[task];
+    if (entries) *entries = to.entries;
+    if (n) *n = to.n;
+    if (payload_off) *payload_off = to.payoff;
+    if (pos) *pos = to.pos;
+    if (rid) *rid = to.rid;
+    if (npay) *npay = to.npay;
+    if (payload_base) *payload_base = to.pay_base;
+    return HSK_OK;
 }
 
 // Uploads the DnaBuffer description; returns device arrays with nreads+1 offsets.

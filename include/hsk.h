@@ -158,6 +158,13 @@ int hsk_count_loopback(hsk_ctx *ctx, int nranks, const uint8_t *const *packed, c
                        hsk_result *outs, int32_t *owner_out, int32_t owner_capacity);
 
 void hsk_result_free(hsk_ctx *ctx, hsk_result *res);
+/* HSK_FLAG_KEEP_DEVICE: where task `task`'s share of the result lives in HBM -- entries (n records of nw + 1 words), and with
+ * EXTENSION the CSR payload: payload_off (n values in the rank's payload numbering), pos / rid (npay values each, the
+ * task's whole sorted payload) and payload_base: entry i owns pos / rid[payload_off[i] - payload_base ...][0 .. cnt_i).
+ * A downstream GPU stage (e.g. an overlap detector consuming (ReadId, PosInRead) lists, reference README.md:52,74) reads
+ * them in place; the memory belongs to the result. */
+int hsk_result_device_task(const hsk_result *res, int32_t task, const void **entries, uint64_t *n,
+                           const void **payload_off, const void **pos, const void **rid, uint64_t *npay, uint64_t *payload_base);
 int  hsk_get_stats(hsk_ctx *ctx, hsk_stats *out, int reset);
 
 /* ---- stage entry points (each one is a reference function of SURVEY 8a; used by the parity

@@ -464,3 +464,32 @@ def test_extension_grouping_aggregation(H, O, L, U):
         assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), i
     sel = np.concatenate([np.arange(int(o), int(o) + int(c)) for o, c in zip(res.payload_off[:-1], res.cnt)])
     assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
+
+
+def test_resident_result_csr_on_device(H, O):
+    """HSK_FLAG_KEEP_DEVICE: the list stays in HBM and hsk_result_device_task hands out the per-task entry arrays and, with
+    EXTENSION, the CSR payload (payload_off / pos / rid) for a following GPU stage; read back they equal the host result."""
+    from hysortk_amd import synth
+    seqs = synth.reads(120000, 150, 8000, 29)
+    dna = H.DnaBuffer.from_sequences(seqs)
+    with H.Context(K=31, M=17, L=2, U=50, EXT=1, ntasks=16) as c:
+        host = c.count(dna, rid_base=7)
+    with H.Context(K=31, M=17, L=2, U=50, EXT=1, ntasks=16, keep_device=True) as c:
+        with c.count_resident(dna, rid_base=7) as dev:
+            assert dev.n == len(host) and np.array_equal(dev.task_off, host.task_off)
+            got = 0
+            for t in range(dev.ntasks):
+                a, b = int(host.task_off[t]), int(host.task_off[t + 1])
+                d = dev.fetch(t)
+                assert d["n"] == b - a
+                if not d["n"]:
+                    continue
+                assert np.array_equal(d["kmers"], host.kmers[a:b]) and np.array_equal(d["cnt"], host.cnt[a:b])
+                assert np.array_equal(d["payload_off"], host.payload_off[a:b])      # same numbering as the host arrays
+                for i in range(0, d["n"], 41):
+                    first = int(d["payload_off"][i]) - d["payload_base"]
+                    cnt = int(d["cnt"][i])
+                    hp, hr = host.payload(a + i)
+                    assert sorted(zip(d["rid"][first:first + cnt].tolist(), d["pos"][first:first + cnt].tolist())) == sorted(zip(hr.tolist(), hp.tolist()))
+                got += d["n"]
+            assert got == len(host)
