@@ -463,6 +463,63 @@ def read_fai(path):
     return recs
 
 
+def read_fai5(path):
+    """Same with the line width in bytes (column 5; the reference assumes linebases + 1, src/fastaindex.cpp:285)."""
+    recs = []
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            if len(p) >= 4:
+                recs.append((p[0], int(p[1]), int(p[2]), int(p[3]), int(p[4]) if len(p) >= 5 else int(p[3]) + 1))
+    return recs
+
+
+class DeviceDna:
+    """A DnaBuffer that lives in HBM (packed reads + read index), as hsk_pack_fasta / hsk_synth_reads produce it."""
+
+    def __init__(self, ctx, dp, nbytes, do, dl, nreads, first_read_id=0):
+        self.ctx, self.dp, self.nbytes, self.do, self.dl, self.nreads, self.first_read_id = ctx, dp, nbytes, do, dl, nreads, first_read_id
+
+    def count(self, rid_base=None):
+        return self.ctx.count_device(self.dp, self.nbytes, self.do, self.dl, self.nreads, rid_base=self.first_read_id if rid_base is None else rid_base)
+
+    def packed(self):
+        return self.ctx.d2h(self.dp, self.nbytes) if self.nbytes else np.zeros(0, np.uint8)
+
+    def free(self):
+        if self.dp is not None:
+            self.ctx.synth_free(self.dp, self.do, self.dl)
+            self.dp = None
+
+
+def read_dna_buffer_device(ctx, fasta_fname, comm=None):
+    """FASTA + .fai -> this rank's reads, 2-bit packed ON THE GPU (hsk_pack_fasta): the host only maps the file.
+    Same partition of the records over the ranks as read_dna_buffer."""
+    recs = read_fai5(fasta_fname + ".fai")
+    size = 1 if comm is None else comm.size
+    rank = 0 if comm is None else comm.rank
+    counts = plan_partition_reads([r[1] for r in recs], size) if size > 1 else np.array([len(recs)], dtype=np.uint64)
+    first = int(counts[:rank].sum())
+    mine = recs[first:first + int(counts[rank])]
+    n = len(mine)
+    pos = np.array([r[2] for r in mine], dtype=np.uint64)
+    rlen = np.array([r[1] for r in mine], dtype=np.uint32)
+    lb = np.array([r[3] for r in mine], dtype=np.uint32)
+    lw = np.array([r[4] for r in mine], dtype=np.uint32)
+    text = np.zeros(0, dtype=np.uint8)
+    if n:
+        lo = int(pos.min())
+        ends = [int(p) + (((l + b - 1) // b - 1) * w + (l - ((l + b - 1) // b - 1) * b) if b and l else l) for p, l, b, w in zip(pos, rlen.astype(np.int64), lb.astype(np.int64), lw.astype(np.int64))]
+        hi = max(ends)
+        text = np.memmap(fasta_fname, dtype=np.uint8, mode="r")[lo:hi]
+        pos = pos - np.uint64(lo)
+    text = np.ascontiguousarray(text)
+    dp, do, dl, nb = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    ctx._check(ctx.lib.hsk_pack_fasta(ctx.h, _p(text) if text.size else None, text.size, _p(pos) if n else None, _p(rlen) if n else None,
+                                      _p(lb) if n else None, _p(lw) if n else None, n, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
+    return DeviceDna(ctx, dp.value, int(nb.value), do.value, dl.value, n, first)
+
+
 def read_dna_buffer(fasta_fname, comm=None):
     """FASTA + .fai -> this rank's DnaBuffer: rank r gets a contiguous run of records chosen by
     FastaIndex::getpartition (reference src/fastaindex.cpp:52-100), 2-bit packed."""

@@ -2654,6 +2654,44 @@ extern "C" int hsk_synth_reads(hsk_ctx *c, uint64_t genome_len, uint32_t read_le
     return HSK_OK;
 }
 
+extern "C" int hsk_pack_fasta(hsk_ctx *c, const char *text, uint64_t text_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,
+                              const uint32_t *line_bases, const uint32_t *line_width, uint64_t nrec,
+                              void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
+{
+    if (!c || !d_packed || !packed_bytes || !d_off || !d_len || (nrec && (!text || !rec_pos || !rec_len || !line_bases || !line_width))) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    *d_packed = nullptr; *d_off = nullptr; *d_len = nullptr; *packed_bytes = 0;
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < nrec; ++r) {
+        const uint64_t nl = line_bases[r] ? ((uint64_t)rec_len[r] + line_bases[r] - 1) / line_bases[r] : 0;
+        const uint64_t last = rec_len[r] ? rec_pos[r] + (line_bases[r] ? (nl - 1) * (uint64_t)line_width[r] + ((uint64_t)rec_len[r] - (nl - 1) * line_bases[r]) : rec_len[r]) : rec_pos[r];
+        if (last > text_bytes) return fail(c, HSK_ERR_INVALID_ARG, "record %llu extends past the text", (unsigned long long)r);
+        if (line_bases[r] && line_width[r] < line_bases[r]) return fail(c, HSK_ERR_INVALID_ARG, "record %llu: line width < bases per line", (unsigned long long)r);
+        total += ((uint64_t)rec_len[r] + 3) / 4;
+    }
+    u8 *d_text, *pk; u64 *d_pos, *roff; u32 *rlen, *d_lb, *d_lw;
+    DALLOC(c, pk, u8 *, total + 64);
+    DALLOC(c, roff, u64 *, (nrec + 1) * 8);
+    DALLOC(c, rlen, u32 *, (nrec + 1) * 4);
+    if (nrec) {
+        DALLOC(c, d_text, u8 *, text_bytes + 64);
+        DALLOC(c, d_pos, u64 *, nrec * 8); DALLOC(c, d_lb, u32 *, nrec * 4); DALLOC(c, d_lw, u32 *, nrec * 4);
+        HIPCHK(c, hipMemcpyAsync(d_text, text, text_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_pos, rec_pos, nrec * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(rlen, rec_len, nrec * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_lb, line_bases, nrec * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_lw, line_width, nrec * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pack_fasta_offsets_kernel, dim3(1), dim3(256), 0, c->stream, rlen, nrec, roff);
+        if (total) hipLaunchKernelGGL(pack_fasta_kernel, dim3((u32)std::min<u64>((total + 255) / 256, 1u << 20)), dim3(256), 0, c->stream,
+                                      d_text, text_bytes, d_pos, rlen, d_lb, d_lw, roff, nrec, total, pk);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->pool.release(d_text); c->pool.release(d_pos); c->pool.release(d_lb); c->pool.release(d_lw);
+    }
+    *d_packed = pk; *packed_bytes = total; *d_off = roff; *d_len = rlen;
+    return HSK_OK;
+}
+
 extern "C" int hsk_synth_free(hsk_ctx *c, void *d_packed, void *d_off, void *d_len)
 {
     if (!c) return HSK_ERR_INVALID_ARG;

@@ -45,4 +45,61 @@ __global__ void synth_index_kernel(u64 *roff, u32 *rlen, u64 nreads, u32 read_le
     if (r < nreads) rlen[r] = read_len;
 }
 
+// FASTA text -> DnaBuffer bytes on the device (what DnaSeq::compress does on the host, reference src/dnaseq.cpp:9-31,
+// fed by FastaIndex's line arithmetic, src/fastaindex.cpp:285: base i of a record sits at
+// pos + (i / linebases) * linewidth + i % linebases).  One lane per output byte; the record of a byte is found by
+// binary search over the output offsets.  Codes A/a/N/n = 0, C/c = 1, G/g = 2, T/t = 3; any other character gets the
+// reference's code 4, OR-ed in at the base's shift and truncated to the byte exactly as `uint8_t |= 4 << shift` does.
+__global__ void pack_fasta_kernel(const u8 *text, u64 text_bytes, const u64 *rec_pos, const u32 *rec_len, const u32 *line_bases, const u32 *line_width,
+                                  const u64 *roff, u64 nrec, u64 out_bytes, u8 *out)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < out_bytes; b += stride) {
+        u64 lo = 0, hi = nrec - 1;                                 // last record whose first output byte is <= b
+        while (lo < hi) { const u64 mid = lo + (hi - lo + 1) / 2; if (roff[mid] <= b) lo = mid; else hi = mid - 1; }
+        const u64 r = lo;
+        const u32 len = rec_len[r], lb = line_bases[r], lw = line_width[r];
+        const u64 pos = rec_pos[r];
+        const u64 i0 = (b - roff[r]) * 4;
+        u32 byte = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 i = i0 + j;
+            if (i >= len) break;
+            const u64 src = pos + (lb ? (i / lb) * (u64)lw + (i % lb) : i);
+            const u8 ch = src < text_bytes ? text[src] : (u8)'A';
+            u32 code;
+            switch (ch) {
+            case 'A': case 'a': case 'N': case 'n': code = 0; break;
+            case 'C': case 'c': code = 1; break;
+            case 'G': case 'g': code = 2; break;
+            case 'T': case 't': code = 3; break;
+            default: code = 4; break;
+            }
+            byte |= code << (6 - 2 * j);
+        }
+        out[b] = (u8)byte;
+    }
+}
+
+// roff[r] = sum of (len + 3) / 4 over the records before r (nrec + 1 values); single workgroup, sequential chunks
+__global__ void pack_fasta_offsets_kernel(const u32 *rec_len, u64 nrec, u64 *roff)
+{
+    __shared__ u64 s_scr[8];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nrec; base += 256) {
+        const u64 r = base + threadIdx.x;
+        const u64 nb = r < nrec ? ((u64)rec_len[r] + 3) / 4 : 0;
+        u64 tot;
+        const u64 e = block_excl_scan_256<u64>(nb, s_scr, &tot);
+        if (r < nrec) roff[r] = s_carry + e;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) roff[nrec] = s_carry;
+}
+
 } // namespace hsk

@@ -226,6 +226,17 @@ int hsk_synth_reads(hsk_ctx *ctx, uint64_t genome_len, uint32_t read_len, uint64
                     uint64_t first_read, /* index of read 0 in the global read stream (rank * nreads for weak scaling) */
                     void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
 int hsk_synth_free(hsk_ctx *ctx, void *d_packed, void *d_read_byte_off, void *d_read_len);
+
+/* ---- FASTA ingest on the device (what read_dna_buffer + DnaSeq::compress do on the host, reference src/hysortk.cpp:18-33,
+ *      src/dnaseq.cpp:9-31) -------------------------------------------------------------------------------------------- */
+/* `text` = the FASTA file's bytes (host memory, e.g. an mmap); record r has rec_len[r] bases, the first at text[rec_pos[r]],
+ * with line_bases[r] bases per line and line_width[r] bytes per line including the line break (the .fai columns 2-5;
+ * line_bases 0 = no line breaks).  Builds the 2-bit packed DnaBuffer of these records in HBM (every record byte-aligned,
+ * same bytes as the reference's packer incl. its code-4 spill for non-ACGTN characters) and returns device arrays that
+ * hsk_count_device takes (free them with hsk_synth_free). */
+int hsk_pack_fasta(hsk_ctx *ctx, const char *text, uint64_t text_bytes, const uint64_t *rec_pos, const uint32_t *rec_len,
+                   const uint32_t *line_bases, const uint32_t *line_width, uint64_t nrec,
+                   void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
 int hsk_memcpy_d2h(hsk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
 
 #ifdef __cplusplus

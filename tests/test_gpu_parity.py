@@ -493,3 +493,42 @@ def test_resident_result_csr_on_device(H, O):
                     assert sorted(zip(d["rid"][first:first + cnt].tolist(), d["pos"][first:first + cnt].tolist())) == sorted(zip(hr.tolist(), hp.tolist()))
                 got += d["n"]
             assert got == len(host)
+
+
+def test_fasta_ingest_on_device(H, O, tmp_path):
+    """hsk_pack_fasta: FASTA text -> DnaBuffer bytes in HBM must equal the host packer byte for byte (line breaks at any width,
+    CRLF, lower case, N, a character outside ACGTN with the reference's code-4 spill, empty and 1-base records), and counting
+    from the device buffer equals counting from the host DnaBuffer."""
+    rng = np.random.default_rng(11)
+    seqs = ["".join(rng.choice(list("ACGT"), n)) for n in (3000, 1500, 10, 31, 250, 1, 0, 77, 4, 5, 801)]
+    seqs[3] = seqs[3].lower()
+    seqs[4] = seqs[4][:100] + "NNNNnnnn" + seqs[4][108:]
+    seqs[7] = seqs[7][:30] + "R" + seqs[7][31:]                     # non-nucleotide: code 4 corrupts the neighbouring bits as in the reference
+    fa = tmp_path / "x.fa"
+    with open(fa, "wb") as f, open(str(fa) + ".fai", "w") as fai:
+        for i, s in enumerate(seqs):
+            width, eol = ((60, b"\n"), (80, b"\r\n"), (7, b"\n"))[i % 3]
+            f.write(b">r%d some text\n" % i)
+            pos = f.tell()
+            for j in range(0, len(s), width):
+                f.write(s[j:j + width].encode() + eol)
+            if not s:
+                f.write(b"\n")
+            fai.write("r%d\t%d\t%d\t%d\t%d\n" % (i, len(s), pos, width, width + len(eol)))
+    host = H.DnaBuffer.from_sequences(seqs)
+    packed, off, lens = host.arrays()
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=3) as c:
+        dd = H.read_dna_buffer_device(c, str(fa))
+        assert dd.nreads == len(seqs) and dd.nbytes == packed.size
+        assert dd.packed().tobytes() == packed.tobytes()
+        res_d = dd.count()
+        dd.free()
+        res_h = c.count(host)
+    assert np.array_equal(res_d.kmers, res_h.kmers) and np.array_equal(res_d.cnt, res_h.cnt) and np.array_equal(res_d.task_off, res_h.task_off)
+    # and the golden FASTA of the reference runs: same list as through read_dna_buffer
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=5) as c:
+        dd = H.read_dna_buffer_device(c, util.GOLDEN + "/reads_small.fa")
+        res_d = dd.count()
+        dd.free()
+        res_h = c.count(H.read_dna_buffer(util.GOLDEN + "/reads_small.fa"))
+    assert np.array_equal(res_d.kmers, res_h.kmers) and np.array_equal(res_d.cnt, res_h.cnt)
