@@ -532,3 +532,46 @@ def test_fasta_ingest_on_device(H, O, tmp_path):
         dd.free()
         res_h = c.count(H.read_dna_buffer(util.GOLDEN + "/reads_small.fa"))
     assert np.array_equal(res_d.kmers, res_h.kmers) and np.array_equal(res_d.cnt, res_h.cnt)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_configurations_vs_oracle(H, O, seed):
+    """Seeded sweep over K (one, two and three key words), M (window widths below and above 8, M > 25 takes the general parse
+    kernels), task counts (single-task path, padded batches, full batches), L/U, EXTENSION and ragged reads (shorter than K,
+    exactly K, with N and lower case): every combination must give the oracle's list."""
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.choice([5, 11, 15, 21, 27, 31, 33, 39, 41, 51, 63, 65, 77, 95]))
+    M = int(rng.integers(max(1, min(K - 60, 20)), min(K, 32)))
+    EXT = int(rng.integers(0, 2)) if K < 64 else 0
+    ntasks = int(rng.choice([1, 2, 5, 8, 11, 16, 24]))
+    L = int(rng.choice([1, 1, 2, 3])); U = int(rng.choice([4, 40, 65535]))
+    if U < L:
+        U = L
+    g = "".join(rng.choice(list("ACGT"), 40000))
+    reads = []
+    for _ in range(1500):
+        n = int(rng.choice([rng.integers(1, K + 2), K, rng.integers(K, 400), 150]))
+        p = int(rng.integers(0, len(g) - n))
+        s = g[p:p + n]
+        if rng.random() < 0.5:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        if rng.random() < 0.05 and n > 3:
+            q = int(rng.integers(0, n - 1)); s = s[:q] + "N" + s[q + 1:]
+        if rng.random() < 0.05:
+            s = s.lower()
+        reads.append(s)
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=M, L=L, U=U, ext=EXT, ntasks=ntasks, rid_base=seed, fast=True)
+    with H.Context(K=K, M=M, L=L, U=U, EXT=EXT, ntasks=ntasks) as c:
+        res = c.count(dna, rid_base=seed)
+    tag = (K, M, EXT, ntasks, L, U)
+    assert np.array_equal(res.task_off, ores.task_off), tag
+    assert np.array_equal(res.kmers, ores.keys), tag
+    assert np.array_equal(res.cnt, ores.cnt), tag
+    assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt), tag
+    if EXT and len(res):
+        for i in list(range(0, len(res), max(1, len(res) // 40))) + [len(res) - 1]:
+            pos, rid = res.payload(i)
+            a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+            assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
