@@ -540,8 +540,8 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
     if (npass) memcpy(a.pass, plan, sizeof(PassDesc) * npass);
     const size_t dyn = (size_t)std::max(npass, 1) * 256 * 4;
     // persistent workgroups: exactly what is resident at once (a second wave would start when the first is done)
-    static int occ_c[2] = {0, 0};
-    int &occ = occ_c[ext ? 1 : 0];
+    static std::map<size_t, int> occ_c[2];               // per dynamic-LDS size (the histogram area grows with the pass count)
+    int &occ = occ_c[ext ? 1 : 0][dyn];
     if (!occ) {
         int nb = 0;
         hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_kernel<NW, true>, EXP_THREADS, dyn)
