@@ -1,0 +1,407 @@
+// hsk_host_finish.h -- host side of the count stage: two-pass counter, fused tile finish, aggregating finishes (kernels: hsk_count.h, hsk_finish.h, hsk_agg.h).
+// Part of the single translation unit hsk_api.hip (included in this order; everything here is file-local).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// stage: merge-count one sorted task (a13)
+// ------------------------------------------------------------------------------------------------
+struct TaskOut { u64 n = 0, npay = 0; u64 *entries = nullptr; u64 *payoff = nullptr; u32 *pos = nullptr; int32_t *rid = nullptr; bool failed = false; u64 pay_base = 0; };
+
+template <int NW>
+static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n, u64 payoff_add, u64 *d_histo, u32 histo_len, TaskOut &out)
+{
+    out = TaskOut();
+    if (n == 0) return HSK_OK;
+    const bool ext = vals != nullptr;
+    const u64 ntiles = (n + CNT_TILE - 1) / CNT_TILE;
+    u64 *d_tile_cnt, *d_total;
+    DALLOC(c, d_tile_cnt, u64 *, ntiles * 8);
+    DALLOC(c, d_total, u64 *, 256);
+    CountArgs a; memset(&a, 0, sizeof a);
+    a.keys = keys; a.n = n; a.lower = (u32)c->cfg.lower_freq; a.upper = (u32)c->cfg.upper_freq;
+    a.tile_cnt = d_tile_cnt; a.histo = d_histo; a.histo_len = histo_len; a.payoff_add = payoff_add;
+    hipLaunchKernelGGL((count_kernel<NW, false, false>), dim3((u32)ntiles), dim3(CNT_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile_cnt, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out.n = tot[0]; out.npay = ext ? n : 0;
+    if (ext) {
+        // the payload of a kept run is its slice of the sorted payload array: split the whole array once
+        DALLOC(c, out.pos, u32 *, n * 4);
+        DALLOC(c, out.rid, int32_t *, n * 4);
+        hipLaunchKernelGGL(payload_split_kernel, dim3((u32)std::min<u64>((n + 255) / 256, 4096)), dim3(256), 0, c->stream, vals, n, out.pos, out.rid);
+    }
+    if (out.n) {
+        DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
+        if (ext) DALLOC(c, out.payoff, u64 *, out.n * 8);
+        a.entries = out.entries; a.run_start = out.payoff;
+        // persistent: one histogram flush per workgroup; exactly the resident workgroup count, so no ragged second wave
+        static int occ_e[2] = {0, 0};
+        int &occ = occ_e[ext ? 1 : 0];
+        if (!occ) {
+            int nb = 0;
+            hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_kernel<NW, true, true>, CNT_THREADS, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_kernel<NW, true, false>, CNT_THREADS, 0);
+            occ = (e == hipSuccess && nb > 0) ? nb : 4;
+        }
+        hipDeviceProp_t *pr = nullptr; (void)pr;
+        const u32 egrid = (u32)std::min<u64>(ntiles, (u64)occ * 256);
+        if (ext) hipLaunchKernelGGL((count_kernel<NW, true, true>), dim3(egrid), dim3(CNT_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((count_kernel<NW, true, false>), dim3(egrid), dim3(CNT_THREADS), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(d_tile_cnt); c->pool.release(d_total);
+    return HSK_OK;
+}
+
+static void free_task_out(hsk_ctx *c, TaskOut &o)
+{
+    c->pool.release(o.entries); c->pool.release(o.payoff); c->pool.release(o.pos); c->pool.release(o.rid);
+    o = TaskOut();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the whole path
+// ------------------------------------------------------------------------------------------------
+struct ResultPriv {
+    std::vector<void *> host_blocks;     // hipHostMalloc'ed
+    std::vector<TaskOut> dev_tasks;      // kept in HBM with HSK_FLAG_KEEP_DEVICE
+};
+
+static void *host_alloc(ResultPriv *rp, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    rp->host_blocks.push_back(p);
+    return p;
+}
+
+static bool finish_enabled();
+static bool agg_enabled();
+// One scatter pass + aggregation over 8-bit prefix bins (hsk_agg.h: agg_big_kernel) for tasks of up to ONEPASS_MAX_TASK
+// k-mers; HSK_ONEPASS=0 keeps two passes + 16-bit bins for every task.
+constexpr u64 ONEPASS_TASK_KMERS = 1ULL << 24;          // auto_ntasks aims at this many base positions per task
+constexpr u64 ONEPASS_MAX_TASK = 3ULL << 23;            // larger tasks: bins with too many distinct keys for the LDS table
+// EXPERIMENTAL, off unless HSK_ONEPASS=1: at 10 Gbp it means ~600 tasks of 13 M k-mers, processed in batches of 64
+// (one scatter launch per batch).  It removes 16 B of HBM traffic per k-mer and the scatter phase drops from 57 to 36
+// ms, but the whole step is slower today (226 ms against 168 ms): the aggregation over 51 000-record bins runs one
+// 1024-thread workgroup per CU (112 KB of LDS) and only reaches 20 % issue utilisation (82 ms against 27 ms), placing
+// supermers into 600 tasks costs +8 ms and 76 small expand launches +8 ms.
+static bool onepass_enabled()
+{
+    static const bool on = getenv("HSK_ONEPASS") && atoi(getenv("HSK_ONEPASS")) != 0;
+    return on;
+}
+
+static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
+{
+    // one task per ~2^28 k-mers (2 GB of 8-byte keys): large enough to saturate the chip, small
+    // enough that key + ping-pong + look-back buffers of one task stay a small share of HBM
+    u64 est = packed_bytes * 4 * (u64)std::max(nranks, 1);
+    u64 t = (est + (1ULL << 28) - 1) >> 28;
+    // one-word keys without payload: tasks small enough for ONE scatter pass + aggregation over 8-bit prefix bins
+    // (as many as HSK_MAX_TASKS allows; beyond that the tasks grow and the two-pass plan takes over by itself)
+    if (c->nw == 1 && c->cfg.extension == 0 && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled())
+        t = std::max(t, std::min<u64>((est + ONEPASS_TASK_KMERS - 1) / ONEPASS_TASK_KMERS, HSK_MAX_TASKS / 8 * 8));
+    t = std::max<u64>(t, (u64)std::max(nranks, 1));
+    // tasks are sorted eight at a time (one per XCD): give every rank a multiple of eight when there are that many
+    const u64 per = 8ULL * (u64)std::max(nranks, 1);
+    if (t >= per) t = (t + per - 1) / per * per;
+    return (u32)std::min<u64>(std::max<u64>(t, 1), HSK_MAX_TASKS);
+}
+
+// Fused finish of a batch (hybrid sort, one-word keys, no payload): one finish_multi_kernel launch turns the
+// prefix-ordered keys of eight tasks into their (k-mer, count) lists.  Tasks the kernel could not finish (a
+// long bin with several keys, see hsk_finish.h) are redone with the full-width passes and the two-pass counter.
+static bool finish_enabled()
+{
+    static const bool on = !(getenv("HSK_FUSED_FINISH") && atoi(getenv("HSK_FUSED_FINISH")) == 0);
+    return on;
+}
+
+template <int NW>
+static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    static_assert(NW == 1, "fused finish handles one-word keys");
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 cap_t = (u32)FN_NL / L + 1;                  // a tile keeps at most (2048 + 512) / L runs
+    u64 ntiles[XCD_BATCH], cnt_off[XCD_BATCH + 1]; cnt_off[0] = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) { ntiles[i] = (bt[i].n + FN_TILE - 1) / FN_TILE; cnt_off[i + 1] = cnt_off[i] + ntiles[i] + 1; }
+    // control block: [8] flags (u32), then per task the tile counts (+1 word for the total)
+    const size_t ctl_bytes = 64;
+    char *d_ctl = (char *)c->pool.alloc(ctl_bytes + cnt_off[XCD_BATCH] * 8 + 64);
+    if (!d_ctl) return fail(c, HSK_ERR_OOM, "finish control block");
+    HIPCHK(c, hipMemsetAsync(d_ctl, 0, ctl_bytes, c->stream));
+    u32 *d_flags = (u32 *)d_ctl; u64 *d_cnt = (u64 *)(d_ctl + ctl_bytes);
+    // scratch: the idle ping-pong buffer of the task when the per-tile slots fit into it (L >= 3), else its own block
+    u64 *scratch[XCD_BATCH] = {nullptr}; bool own_scratch[XCD_BATCH] = {false};
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        if (bt[i].n == 0) continue;
+        u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        const u64 need = ntiles[i] * (u64)cap_t * 16;
+        if (need <= max_task * 8) scratch[i] = other;
+        else { scratch[i] = (u64 *)c->pool.alloc(need + 64); own_scratch[i] = true; if (!scratch[i]) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)need); }
+        FinishArgs a; memset(&a, 0, sizeof a);
+        a.keys = bt[i].out_k; a.n = bt[i].n; a.scratch = scratch[i]; a.cap_t = cap_t; a.tile_cnt = d_cnt + cnt_off[i]; a.flags = d_flags + i;
+        a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.hi_shift = HYBRID_SHIFT;
+        hipLaunchKernelGGL(finish_kernel, dim3((u32)ntiles[i]), dim3(FN_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_cnt + cnt_off[i], ntiles[i], d_cnt + cnt_off[i] + ntiles[i]);
+    }
+    HIPCHK(c, hipGetLastError());
+    struct { u32 flags[8]; u64 total[8]; } h; memset(&h, 0, sizeof h);
+    HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < XCD_BATCH; ++i) if (bt[i].n) HIPCHK(c, hipMemcpyAsync(&h.total[i], d_cnt + cnt_off[i] + ntiles[i], 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    static int occ = 0;
+    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, finish_compact_kernel, FN_THREADS, 0) == hipSuccess && nb > 0) ? nb : 4; }
+    int rc = HSK_OK;
+    for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i) {
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        if (h.flags[i] && c->forbid_long_way) { outs[i].failed = true; continue; }
+        if (h.flags[i]) {
+            // the long way for this task: full-width passes from the current order, then the two-pass counter
+            c->stats.redone_tasks++;
+            if (own_scratch[i]) { c->pool.release(scratch[i]); scratch[i] = nullptr; own_scratch[i] = false; }
+            SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+            u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+            rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+            free_sort_scratch(c, sc1);
+            if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
+            continue;
+        }
+        c->stats.fused_tasks++;
+        outs[i].n = h.total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16);
+            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * 16)); break; }
+            const u32 grid = (u32)std::min<u64>((ntiles[i] + 3) / 4, (u64)occ * 256);
+            hipLaunchKernelGGL(finish_compact_kernel, dim3(grid), dim3(FN_THREADS), 0, c->stream, scratch[i], cap_t, d_cnt + cnt_off[i], ntiles[i],
+                               outs[i].entries, d_histo, histo_len);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
+    for (int i = 0; i < XCD_BATCH; ++i) if (own_scratch[i]) c->pool.release(scratch[i]);
+    c->pool.release(d_ctl);
+    return rc;
+}
+
+// ---- two passes + aggregation (hsk_agg.h): the batch's keys are sorted on their top 16 bits ---------------
+static bool agg_enabled()
+{
+    static const bool on = !(getenv("HSK_AGG") && atoi(getenv("HSK_AGG")) == 0);
+    return on;
+}
+
+template <int NW>
+// prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way;
+// prefix_bits = 8: bins of the top 8 bits (one scatter pass), agg_big_kernel; a task it cannot take is reported in
+// outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
+static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
+{
+    static_assert(NW <= 2, "the aggregating finish handles one- and two-word keys");
+    constexpr u32 EW = NW + 1;                          // words per entry
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 slot_shift = L >= 2 ? 1 : 0;              // a bin of n records keeps at most n / L entries of 16 bytes
+    const bool big = prefix_bits == 8;
+    const u32 nbins = 1u << prefix_bits;
+    const size_t per = (size_t)nbins + 8;
+    u64 *d_bounds, *d_cnt; u32 *d_flags;
+    DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_flags, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+    AggArgs a; memset(&a, 0, sizeof a);
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
+    bool own_scratch[AG_BATCH] = {false};
+    u64 ntot = 0;
+    for (int i = 0; i < AG_BATCH; ++i) {
+        AggTask &t = a.t[i];
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
+        t.slot_shift = slot_shift; t.active = 1; ntot += bt[i].n;
+        if (slot_shift) t.scratch = other;               // the idle ping-pong buffer: n / 2 entries
+        else {
+            t.scratch = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); own_scratch[i] = true;
+            if (!t.scratch) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)(bt[i].n * EW * 8));
+        }
+    }
+    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
+    auto run = [&](int log2cap) -> int {
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+        if (NW == 2) {
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        } else
+        if (big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
+        else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HSK_OK;
+    };
+    memset(&h, 0, sizeof h);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
+    bool retry = false, done[AG_BATCH];
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
+    if (retry && !big) {
+        // second chance with the large table for the tasks that overflowed
+        AggArgs keep = a;
+        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
+        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+        memset(&h, 0, sizeof h);
+        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
+        a = keep;
+    }
+    AggCompactArgs ca; memset(&ca, 0, sizeof ca);
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
+    bool any = false;
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || !done[i]) continue;
+        c->stats.fused_tasks++;
+        outs[i].n = total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * EW * 8);
+            if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * EW * 8)); break; }
+            ca.scratch[i] = a.t[i].scratch; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt; ca.entries[i] = outs[i].entries;
+            any = true;
+        }
+    }
+    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(big ? 64 : 256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || done[i]) continue;
+        if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
+        // the long way for this task: full-width passes from the current order, then the two-pass counter
+        c->stats.redone_tasks++;
+        if (own_scratch[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
+        SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+        u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+        rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+        free_sort_scratch(c, sc1);
+        if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
+    for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) c->pool.release(a.t[i].scratch);
+    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
+    (void)max_task;
+    return rc;
+}
+
+// ---- EXTENSION: two passes + grouping aggregation (hsk_agg.h: agg_ext_kernel) ---------------------------------------
+// pay_before[i]: offset of task i's payload range in the rank's payload arrays (payload_off values are global over the
+// owned tasks in ascending id).
+static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u64 *pay_before, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const u32 L = (u32)c->cfg.lower_freq;
+    const u32 slot_shift = L >= 2 ? 1 : 0;
+    const u32 nbins = AG_BINS;
+    const size_t per = (size_t)nbins + 8;
+    u64 *d_bounds, *d_cnt; u32 *d_flags;
+    DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, d_flags, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+    AggExtArgs a; memset(&a, 0, sizeof a);
+    AggArgs sa; memset(&sa, 0, sizeof sa);               // the view agg_scan_kernel needs
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT;
+    sa.nbins = nbins; sa.shift = AG_SHIFT; sa.nw = 1;
+    bool own_scratch[AG_BATCH] = {false};
+    u64 ntot = 0;
+    for (int i = 0; i < AG_BATCH; ++i) {
+        AggExtTask &t = a.t[i];
+        outs[i] = TaskOut();
+        if (bt[i].n == 0) continue;
+        u64 *other_k = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
+        u64 *other_v = (bt[i].out_v == bt[i].vA) ? bt[i].vB : bt[i].vA;
+        t.keys = bt[i].out_k; t.vals = bt[i].out_v; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
+        t.slot_shift = slot_shift; t.active = 1; t.payoff_add = pay_before[i]; ntot += bt[i].n;
+        if (slot_shift) { t.scratch_e = other_k; t.scratch_p = other_v; }       // n / 2 entries of 16 + 8 bytes: the idle ping-pong buffers
+        else {
+            t.scratch_e = (u64 *)c->pool.alloc(bt[i].n * 16 + 64); t.scratch_p = (u64 *)c->pool.alloc(bt[i].n * 8 + 64); own_scratch[i] = true;
+            if (!t.scratch_e || !t.scratch_p) return fail(c, HSK_ERR_OOM, "finish scratch");
+        }
+        outs[i].npay = bt[i].n;
+        DALLOC(c, outs[i].pos, u32 *, bt[i].n * 4); DALLOC(c, outs[i].rid, int32_t *, bt[i].n * 4);
+        t.pos = outs[i].pos; t.rid = outs[i].rid;
+        sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].active = 1;
+    }
+    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
+    auto run = [&](int log2cap) -> int {
+        for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
+        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HSK_OK;
+    };
+    memset(&h, 0, sizeof h);
+    hipLaunchKernelGGL(bin_bounds_ext_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
+    bool retry = false, done[AG_BATCH];
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
+    if (retry) {
+        AggExtArgs keep = a;
+        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
+        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+        memset(&h, 0, sizeof h);
+        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
+        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
+        a = keep;
+    }
+    AggExtCompactArgs ca; memset(&ca, 0, sizeof ca);
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
+    bool any = false;
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || !done[i]) continue;
+        c->stats.fused_tasks++;
+        outs[i].n = total[i];
+        if (outs[i].n) {
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16); outs[i].payoff = (u64 *)c->pool.alloc(outs[i].n * 8);
+            if (!outs[i].entries || !outs[i].payoff) { rc = fail(c, HSK_ERR_OOM, "task output"); break; }
+            ca.scratch_e[i] = a.t[i].scratch_e; ca.scratch_p[i] = a.t[i].scratch_p; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt;
+            ca.entries[i] = outs[i].entries; ca.payoff[i] = outs[i].payoff;
+            any = true;
+        }
+    }
+    if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_ext_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
+        if (bt[i].n == 0 || done[i]) continue;
+        // the long way for this task: full-width passes (payload carried) from the current order, then the two-pass counter
+        c->stats.redone_tasks++;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); own_scratch[i] = false; }
+        const u64 payadd = pay_before[i];
+        free_task_out(c, outs[i]);
+        SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
+        u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
+        u64 *vcur = bt[i].out_v, *vother = (vcur == bt[i].vA) ? bt[i].vB : bt[i].vA;
+        rc = sort_task_device<1>(c, cur, other, vcur, vother, bt[i].n, K, sc1, &sk, &sv, false);
+        free_sort_scratch(c, sc1);
+        if (rc == HSK_OK) rc = count_task_device<1>(c, sk, sv, bt[i].n, payadd, d_histo, histo_len, outs[i]);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); }
+    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
+    return rc;
+}

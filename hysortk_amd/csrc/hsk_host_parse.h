@@ -1,0 +1,180 @@
+// hsk_host_parse.h -- host side of the parse stage: supermer store, parse_count / parse_place (kernels: hsk_parse.h).
+// Part of the single translation unit hsk_api.hip (included in this order; everything here is file-local).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// stage: parse (a4, a5, a6)
+// ------------------------------------------------------------------------------------------------
+struct SupermerStore {
+    u32 ntasks = 0, nblocks = 0;
+    u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
+    u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
+    std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
+    std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
+    std::vector<u32> order;       // storage order of tasks (grouped by owner rank, ascending id)
+};
+
+static void free_store(hsk_ctx *c, SupermerStore &s)
+{
+    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid);
+    s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr;
+}
+
+static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen,
+                                 u64 nreads, int64_t rid_base, u32 ntasks, u32 *nblocks_out)
+{
+    ParseArgs a; memset(&a, 0, sizeof a);
+    a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
+    a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks);
+    a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
+    u32 nblocks = (u32)std::min<u64>(a.ntiles, 1024);
+    a.tiles_per_block = (u32)((a.ntiles + nblocks - 1) / nblocks);
+    nblocks = (u32)((a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block);
+    a.rid_base = rid_base;
+    *nblocks_out = nblocks;
+    return a;
+}
+
+// The parse in two steps, so that a caller that needs the task sizes before it can fix the storage order
+// (multi-GPU: sizes -> all-reduce -> dispatcher -> owner-grouped order) hashes the reads only once:
+//   parse_count: minimizers + supermer boundaries of every tile; per-(workgroup, task) counts; task totals
+//   parse_place: exclusive scan of the counts in the storage order `order`, supermers to their slots
+// Fast path = scan_kernel + place_kernel (compact supermer records kept in between); the general path
+// (M > 25, or a tile with more supermers than the record capacity) = parse_kernel<COUNT> + emit_kernel.
+struct ParseJob {
+    ParseArgs a; u32 nblocks = 0, ntasks = 0; bool fast = false, empty = true;
+    const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
+    u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
+    u32 *d_tile_r0 = nullptr;     // EXTENSION: first read of every tile (hint for the (pos, rid) lookup)
+    std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
+};
+
+static void parse_release(hsk_ctx *c, ParseJob &j)
+{
+    c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
+    c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr;
+    j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
+}
+
+static bool parse_fast_enabled()
+{
+    static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
+    return on;
+}
+static u32 parse_rec_cap()
+{
+    static const u32 cap = getenv("HSK_PARSE_REC_CAP") ? (u32)std::min(std::max(atoi(getenv("HSK_PARSE_REC_CAP")), 1), (int)PLACE_MAX_REC) : SCAN_REC_CAP;
+    return cap;
+}
+
+static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                       int64_t rid_base, u32 ntasks, ParseJob &j)
+{
+    j = ParseJob();
+    j.ntasks = ntasks; j.d_roff = d_roff; j.nreads = nreads; j.rid_base = rid_base;
+    j.task_tot.assign((size_t)ntasks * 3, 0);
+    if (nreads == 0 || packed_bytes == 0) return HSK_OK;            // nothing to parse on this rank
+    j.empty = false;
+    j.a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
+    ParseArgs &a = j.a;
+    DALLOC(c, j.d_blk_cnt, u64 *, (size_t)j.nblocks * ntasks * 3 * 8);
+    a.blk_cnt = j.d_blk_cnt;
+    u64 *d_task_tot; DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8 + 64);
+    j.fast = parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
+    u32 *h_ovf = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
+    *h_ovf = 0;
+    if (j.fast) {
+        a.rec_cap = parse_rec_cap();
+        a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
+        DALLOC(c, j.d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+        DALLOC(c, j.d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+        DALLOC(c, j.d_overflow, u32 *, 256);
+        HIPCHK(c, hipMemsetAsync(j.d_overflow, 0, 4, c->stream));
+        a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec; a.overflow = j.d_overflow;
+        if (c->cfg.extension && nreads < (1ULL << 32)) { DALLOC(c, j.d_tile_r0, u32 *, (size_t)a.ntiles * 4 + 64); a.tile_r0 = j.d_tile_r0; }
+        hipLaunchKernelGGL(scan_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
+        HIPCHK(c, hipMemcpyAsync(h_ovf, j.d_overflow, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*h_ovf) {                                                // a tile with more supermers than the record capacity
+            j.fast = false; c->stats.parse_fallbacks++;
+            c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; a.tile_r0 = nullptr;
+            c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); j.d_tile_rec = j.d_tile_nrec = nullptr;
+            a.tile_rec = a.tile_nrec = nullptr;
+        }
+    }
+    if (!j.fast) {
+        // task id per base position, kept from COUNT to EMIT (2 B x 4 x packed_bytes); optional: without it EMIT re-hashes
+        j.d_dest_cache = (u16 *)c->pool.alloc((size_t)a.ntiles * PARSE_TILE * 2);
+        a.dest_cache = j.d_dest_cache;
+        hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
+        HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(d_task_tot);
+    return HSK_OK;
+}
+
+// `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
+// skip (optional, [ntasks]): tasks whose supermers are not stored (they take no room and report zero totals)
+static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st, const std::vector<u8> *skip = nullptr)
+{
+    const bool ext = c->cfg.extension != 0;
+    const u32 ntasks = j.ntasks;
+    st = SupermerStore();
+    st.ntasks = ntasks; st.nblocks = j.nblocks; st.order = order;
+    st.task_tot = j.task_tot;
+    if (skip) for (u32 t = 0; t < ntasks; ++t) if ((*skip)[t]) st.task_tot[3 * t] = st.task_tot[3 * t + 1] = st.task_tot[3 * t + 2] = 0;
+    st.task_base.assign((size_t)ntasks * 3, 0);
+    { u64 s = 0, b = 0, k = 0;
+      for (u32 i = 0; i < ntasks; ++i) { const u32 t = order[i]; st.task_base[3 * t] = s; st.task_base[3 * t + 1] = b; st.task_base[3 * t + 2] = k;
+                                          s += st.task_tot[3 * t]; b += st.task_tot[3 * t + 1]; k += st.task_tot[3 * t + 2]; }
+      st.tot_sup = s; st.tot_bytes = b; st.tot_kmers = k; }
+    if (j.empty) return HSK_OK;
+    ParseArgs &a = j.a;
+    u64 *d_blk_base, *d_task_tot, *d_task_base; u32 *d_order;
+    DALLOC(c, d_blk_base, u64 *, (size_t)j.nblocks * ntasks * 2 * 8);
+    DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8);
+    DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
+    DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
+    HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
+    u8 *d_skip = nullptr;
+    if (skip) {
+        DALLOC(c, d_skip, u8 *, ntasks);
+        HIPCHK(c, hipMemcpyAsync(d_skip, skip->data(), ntasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // the mask is host memory of the caller
+    }
+    a.task_skip = d_skip;
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base);
+    DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
+    DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);          // reference mode: bases stay in the packed reads
+    if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
+    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos;
+    if (st.tot_sup) {
+        if (j.fast) hipLaunchKernelGGL(place_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, c->stream, a);
+        else if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                                    st.sm_gpos, st.tot_sup, j.d_roff, j.nreads, j.rid_base, st.sm_pos, st.sm_rid, (const u32 *)j.d_tile_r0, a.ntiles);
+    }
+    HIPCHK(c, hipGetLastError());
+    // the small matrices are released after the stream has consumed them (pool reuse is stream-ordered:
+    // every later user of these blocks is enqueued on the same stream)
+    c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order); c->pool.release(d_skip);
+    a.task_skip = nullptr;
+    return HSK_OK;
+}
+
+// count + place with a known storage order
+static int parse_phase(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                       int64_t rid_base, u32 ntasks, const std::vector<u32> &order, SupermerStore &st)
+{
+    ParseJob j;
+    int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, j);
+    if (rc == HSK_OK) rc = parse_place(c, j, order, st);
+    parse_release(c, j);
+    return rc;
+}

@@ -1,0 +1,843 @@
+// hsk_host_pipeline.h -- the whole path: exchange feeder, heavy-hitter lists, per-rank task loop, single-GPU / RCCL / virtual-rank drivers.
+// Part of the single translation unit hsk_api.hip (included in this order; everything here is file-local).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Exchange / sort overlap (multi-GPU).  The owned tasks of every rank are cut into groups of
+// XCD_BATCH consecutive tasks; group g+1 travels on `comm_stream` (RCCL send/recv, or device copies
+// between the virtual ranks of the loopback driver) while group g is expanded, sorted and counted on
+// the main stream.  The reference overlaps the same way with BATCH-sized MPI_Ialltoallv rounds
+// (src/kmerops.cpp:130-196, exchange_supermer's stage loop); here the unit is a task group so that a
+// sort batch never waits for bytes it does not need.  HSK_OVERLAP=0 selects one exchange up front.
+// ------------------------------------------------------------------------------------------------
+struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; };
+
+struct GroupFeeder {
+    hsk_ctx *c = nullptr;
+    int nranks = 1, rank = 0, ngroups = 0;
+    bool ext = false;
+    std::vector<int32_t> group_of;                     // task -> group inside its owner's task list
+    std::vector<ExchangePlan> pl;                      // [group] this rank's plan
+    std::vector<ExchangeBuffers> xb;                   // [group] receive arrays, alive from post to release
+    std::vector<hipEvent_t> arrived;                   // [group] recorded on comm_stream after the transfer
+    int posted = 0, released = 0;
+    // transport: RCCL (store of this rank) or loopback (stores and plans of all virtual ranks)
+    const SupermerStore *st = nullptr;
+    const std::vector<SupermerStore> *st_all = nullptr;
+    const std::vector<std::vector<ExchangePlan>> *pl_all = nullptr;     // [rank][group]
+    u64 bytes_moved = 0;
+
+    int plan(hsk_ctx *c_, int nranks_, int rank_, u32 ntasks, const std::vector<int32_t> &owner, const std::vector<u32> &order,
+             const std::vector<u64> &M, const std::vector<u64> &task_base, std::vector<TaskSegs> &segs)
+    {
+        c = c_; nranks = nranks_; rank = rank_; ext = c->cfg.extension != 0;
+        assign_task_groups(nranks, ntasks, owner, XCD_BATCH, group_of, ngroups);
+        pl.resize(ngroups); xb.resize(ngroups); arrived.assign(ngroups, nullptr);
+        segs.assign(ntasks, TaskSegs());
+        for (int g = 0; g < ngroups; ++g) plan_exchange(nranks, rank, ntasks, owner, order, M, task_base, pl[g], segs, &group_of, g);
+        return HSK_OK;
+    }
+    int post(int g)
+    {
+        ExchangeBuffers &b = xb[g]; const ExchangePlan &p = pl[g];
+        b.len = (u8 *)c->pool.alloc(p.recv_tot_sup + 64); b.bytes = (u8 *)c->pool.alloc(p.recv_tot_bytes + 64); b.nbytes = p.recv_tot_bytes;
+        if (ext) { b.pos = (u32 *)c->pool.alloc(p.recv_tot_sup * 4 + 64); b.rid = (int32_t *)c->pool.alloc(p.recv_tot_sup * 4 + 64); }
+        if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid))) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
+        // the pool hands out blocks whose previous user may still be running on the main stream: order the
+        // transfer after everything launched there so far (that is the work of group g-2 and earlier)
+        hipEvent_t fence = ev_get(c);
+        HIPCHK(c, hipEventRecord(fence, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, fence, 0));
+        ev_put(c, fence);
+        hipStream_t s = c->comm_stream;
+        if (st_all) {
+            for (int src = 0; src < nranks; ++src) {
+                const ExchangePlan &sp = (*pl_all)[src][g]; const SupermerStore &ss = (*st_all)[src];
+                const u64 n = sp.send_sup[rank], nb = sp.send_bytes[rank];
+                if (n != p.recv_sup[src] || nb != p.recv_bytes[src]) return fail(c, HSK_ERR_INTERNAL, "exchange plan mismatch %d->%d (group %d)", src, rank, g);
+                if (!n) continue;
+                HIPCHK(c, hipMemcpyAsync(b.len + p.recv_sup_off[src], ss.sm_len + sp.send_sup_off[rank], n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(b.bytes + p.recv_byte_off[src], ss.sm_bytes + sp.send_byte_off[rank], nb, hipMemcpyDeviceToDevice, s));
+                if (ext) {
+                    HIPCHK(c, hipMemcpyAsync(b.pos + p.recv_sup_off[src], ss.sm_pos + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
+                    HIPCHK(c, hipMemcpyAsync(b.rid + p.recv_sup_off[src], ss.sm_rid + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
+                }
+            }
+        } else {
+            int rc = post_exchange(c->comm, s, ext, p, st->sm_len, st->sm_bytes, st->sm_pos, st->sm_rid, b);
+            if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange (group %d) failed: %d (%s)", g, rc, c->comm.last_error.c_str());
+        }
+        bytes_moved += p.recv_tot_bytes + p.recv_tot_sup * (ext ? 9 : 1);
+        arrived[g] = ev_get(c);
+        HIPCHK(c, hipEventRecord(arrived[g], s));
+        return HSK_OK;
+    }
+    // the main stream is about to read group g: make sure g and g+1 are on their way, wait for g
+    int need(int g)
+    {
+        const int upto = std::min(g + 1, ngroups - 1);
+        while (posted <= upto) { int rc = post(posted); if (rc) return rc; ++posted; }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, arrived[g], 0));
+        return HSK_OK;
+    }
+    // the main stream has launched its last reader of every group below g
+    void release_below(int g)
+    {
+        for (; released < g && released < posted; ++released) {
+            xb[released].release(c->pool);         // next user is ordered after the readers by post()'s fence (or is on the main stream)
+            if (arrived[released]) { ev_put(c, arrived[released]); arrived[released] = nullptr; }
+        }
+    }
+    // every rank must take part in every group even when it owns no task of it
+    int finish()
+    {
+        while (posted < ngroups) { int rc = post(posted); if (rc) return rc; ++posted; }
+        HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+        release_below(ngroups);
+        return HSK_OK;
+    }
+    TaskInput input(u32 t) const
+    {
+        const ExchangeBuffers &b = xb[group_of[t]];
+        TaskInput in; in.len = b.len; in.src = source_from_bytes(b.bytes, b.nbytes); in.pos = b.pos; in.rid = b.rid;
+        return in;
+    }
+};
+
+static bool overlap_enabled()
+{
+    static const bool on = !(getenv("HSK_OVERLAP") && atoi(getenv("HSK_OVERLAP")) == 0);
+    return on;
+}
+
+// ---- heavy-hitter tasks (a8): the owner's side --------------------------------------------------------------
+// d_entries: the {k-mer, count} lists of all ranks for one task, concatenated (n entries, each list key-ordered,
+// a key at most once per list).  Orders them by key with the count as payload, sums equal keys, filters [L, U].
+static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_histo, u32 histo_len, TaskOut &out)
+{
+    out = TaskOut();
+    if (n == 0) return HSK_OK;
+    u64 *kA, *kB, *vA, *vB;
+    DALLOC(c, kA, u64 *, n * 8 + 64); DALLOC(c, kB, u64 *, n * 8 + 64); DALLOC(c, vA, u64 *, n * 8 + 64); DALLOC(c, vB, u64 *, n * 8 + 64);
+    hipLaunchKernelGGL(heavy_split_kernel, dim3((u32)std::min<u64>((n + HV_THREADS - 1) / HV_THREADS, 4096)), dim3(HV_THREADS), 0, c->stream, d_entries, n, kA, vA);
+    SortScratch sc; int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    u64 *sk, *sv;
+    rc = sort_task_device<1>(c, kA, kB, vA, vB, n, c->cfg.kmer_size, sc, &sk, &sv);
+    free_sort_scratch(c, sc);
+    if (rc) return rc;
+    const u64 ntiles = (n + HV_THREADS - 1) / HV_THREADS;
+    u64 *d_tile, *d_total;
+    DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
+    HeavyMergeArgs a; memset(&a, 0, sizeof a);
+    a.keys = sk; a.cnts = sv; a.n = n; a.lower = (u64)c->cfg.lower_freq; a.upper = (u64)c->cfg.upper_freq; a.tile_cnt = d_tile; a.histo = d_histo; a.histo_len = histo_len;
+    hipLaunchKernelGGL(heavy_merge_kernel<false>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out.n = tot[0];
+    if (out.n) {
+        DALLOC(c, out.entries, u64 *, out.n * 16);
+        a.entries = out.entries;
+        hipLaunchKernelGGL(heavy_merge_kernel<true>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pool.release(kA); c->pool.release(kB); c->pool.release(vA); c->pool.release(vB); c->pool.release(d_tile); c->pool.release(d_total);
+    return HSK_OK;
+}
+
+struct HeavyIn { u32 task; u64 *d_entries; u64 n; };       // a heavy task this rank owns: concatenated lists of all ranks
+struct ProcExtra {
+    bool force_batch = false;                              // every task through the batch kernels (partial batches padded)
+    const std::vector<HeavyIn> *heavy_in = nullptr;        // merged and filtered here (they have no supermers)
+};
+
+// Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
+// result of this rank.  `segs[t]` lists where the supermers of task t live (x_len / x_src / x_pos / x_rid).
+template <int NW>
+static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owner, int rank, std::vector<TaskSegs> &segs,
+                        const u8 *x_len, const BaseSource &x_src, const u32 *x_pos, const int32_t *x_rid,
+                        hsk_result *out, ResultPriv *rp, PhaseTimer &pt, bool pt_total_open, GroupFeeder *feeder = nullptr,
+                        const ProcExtra *ex = nullptr)
+{
+    const bool ext = c->cfg.extension != 0;
+    const int K = c->cfg.kmer_size;
+    u64 max_task = 0, total_kmers = 0;
+    for (u32 t = 0; t < ntasks; ++t) { finalize_segs(segs[t]); max_task = std::max(max_task, segs[t].nkmers); total_kmers += segs[t].nkmers; }
+    out->total_kmers = total_kmers;
+
+    // ---- per task: expand, sort, count ---------------------------------------------------------------
+    const u32 histo_len = (u32)std::min<int64_t>((int64_t)c->cfg.upper_freq + 1, 65536);    // (U <= 65535 except in the unfiltered pre-aggregation)
+    u64 *d_histo; DALLOC(c, d_histo, u64 *, (size_t)histo_len * 8);
+    HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
+    // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
+    // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
+    static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    std::vector<u32> mine;
+    for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
+    // A remainder of three or more tasks is padded to a full batch with empty slots (an XCD without a task idles, which
+    // still beats eight full-width passes per task on the single-task path); ex->force_batch pads any remainder.
+    const u32 EMPTY_TASK = ~0u;
+    TaskSegs empty_segs;
+    std::vector<TaskOut> touts(ntasks);
+    std::vector<u32> mine_done;                          // tasks finished by the one-pass loop below
+    // ---- the one-pass plan (HSK_ONEPASS=1): batches of up to 64 small tasks -------------------------------------
+    // expand (8 tasks per launch, digit histogram of the top 8 bits) -> ONE scatter pass over all tasks of the batch in
+    // one launch -> aggregation over 8-bit prefix bins (8 tasks per launch); tasks whose bins overflow the LDS table are
+    // ordered on the next 8 bits too and finished over 16-bit bins.  Single GPU only (the exchange feeds groups of 8).
+    if constexpr (NW == 1) {
+        const bool op = !ext && !feeder && batch_enabled && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled() &&
+                        max_task <= ONEPASS_MAX_TASK && !mine.empty() && !(ex && ex->heavy_in && !ex->heavy_in->empty());
+        if (op) {
+            const int nbmax = (int)std::min<size_t>(MANY_MAX, (mine.size() + 7) / 8 * 8);
+            std::vector<u64 *> kAm(nbmax, nullptr), kBm(nbmax, nullptr);
+            for (int i = 0; i < nbmax; ++i) { DALLOC(c, kAm[i], u64 *, max_task * 8 + 64); DALLOC(c, kBm[i], u64 *, max_task * 8 + 64); }
+            u64 *d_gh; DALLOC(c, d_gh, u64 *, (size_t)nbmax * MAX_PASSES * 256 * 8);
+            PassDesc plan1[MAX_PASSES];
+            const int np1 = make_hybrid_plan(plan1, 8, 0);
+            TaskInput dflt1; dflt1.len = x_len; dflt1.src = x_src; dflt1.pos = x_pos; dflt1.rid = x_rid;
+            for (size_t mb = 0; mb < mine.size(); mb += MANY_MAX) {
+                const int nreal = (int)std::min<size_t>(MANY_MAX, mine.size() - mb);
+                const int nb = (nreal + 7) / 8 * 8;
+                BatchTask bt[MANY_MAX];
+                pt.begin(PH_EXTRACT);
+                HIPCHK(c, hipMemsetAsync(d_gh, 0, (size_t)nb * MAX_PASSES * 256 * 8, c->stream));
+                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
+                    ExpandJob jobs[XCD_BATCH];
+                    for (int i = 0; i < XCD_BATCH; ++i) {
+                        BatchTask &b = bt[c0 + i]; b = BatchTask(); b.kA = kAm[c0 + i]; b.kB = kBm[c0 + i];
+                        jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs;
+                        if (c0 + i >= nreal) continue;
+                        const u32 t = mine[mb + c0 + i];
+                        b.n = segs[t].nkmers;
+                        jobs[i].ts = &segs[t]; jobs[i].sm_len = dflt1.len; jobs[i].src = dflt1.src; jobs[i].sm_pos = dflt1.pos; jobs[i].sm_rid = dflt1.rid;
+                        jobs[i].keys = b.kA; jobs[i].vals = nullptr; jobs[i].ghist = d_gh + (size_t)(c0 + i) * MAX_PASSES * 256;
+                    }
+                    int rc = expand_batch<NW>(c, jobs, XCD_BATCH, np1, plan1); if (rc) return rc;
+                }
+                pt.end(PH_EXTRACT);
+                pt.begin(PH_SORT);
+                { int rc = sort_many_onepass<NW>(c, bt, nb, d_gh); if (rc) return rc; }
+                pt.end(PH_SORT);
+                pt.begin(PH_COUNT);
+                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
+                    TaskOut fo[XCD_BATCH];
+                    int rc = agg_finish_batch_device<1>(c, bt + c0, K, max_task, d_histo, histo_len, fo, 8); if (rc) return rc;
+                    BatchTask b2[XCD_BATCH]; bool any_miss = false;
+                    for (int i = 0; i < XCD_BATCH; ++i) {
+                        b2[i] = BatchTask();
+                        if (!fo[i].failed) continue;
+                        any_miss = true; c->stats.onepass_misses++;
+                        b2[i].n = bt[c0 + i].n; b2[i].kA = bt[c0 + i].out_k; b2[i].kB = (bt[c0 + i].out_k == bt[c0 + i].kA) ? bt[c0 + i].kB : bt[c0 + i].kA;
+                    }
+                    if (any_miss) {
+                        rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
+                        TaskOut f2[XCD_BATCH];
+                        rc = agg_finish_batch_device<1>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
+                        for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
+                    }
+                    for (int i = 0; i < XCD_BATCH; ++i) if (c0 + i < nreal) touts[mine[mb + c0 + i]] = fo[i];
+                }
+                pt.end(PH_COUNT);
+            }
+            for (int i = 0; i < nbmax; ++i) { c->pool.release(kAm[i]); c->pool.release(kBm[i]); }
+            c->pool.release(d_gh);
+            mine_done.swap(mine);                            // nothing left for the two-pass loops
+        }
+    }
+    const bool forced = ex && ex->force_batch && batch_enabled;
+    if ((batch_enabled && mine.size() >= (size_t)XCD_BATCH && mine.size() % XCD_BATCH >= 3) || (forced && !mine.empty()))
+        while (mine.size() % XCD_BATCH) mine.push_back(EMPTY_TASK);
+    const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
+    const int nsets = batch ? XCD_BATCH : 1;
+    // Two batches in flight (single GPU): batch b+1 is expanded on the second stream while batch b is sorted and
+    // counted on the main stream.  The expand kernel waits on memory latency for most of its life, the radix passes
+    // are bandwidth-bound and the aggregation is issue-bound: side by side they fill each other's gaps.  Every
+    // buffer the second stream touches is allocated up front (the pool's reuse rule is per stream).
+    // (off unless HSK_PIPELINE=1: the gain is ~1.5 % and every per-kernel duration, hence the reported roofline of the
+    // scatter pass, is inflated by whatever runs beside it)
+    static const bool pipe_enabled = getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) != 0;
+    const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
+    const int nslot = piped ? 2 : 1;
+    u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
+    u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
+    SortScratch sc;
+    if (max_task) {
+        for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
+            DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kBs[sl][i], u64 *, max_task * NW * 8 + 64);
+            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, max_task * 8 + 64); }
+        }
+        int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+    }
+    u64 *d_ghist_slot[2] = {nullptr, nullptr};
+    ExpandScratch xpre[2][XCD_BATCH];
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
+    hipStream_t xstream = piped ? c->comm_stream : c->stream;
+    if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    if (piped) {
+        u64 max_tiles = 0; size_t max_seg = 1;
+        for (u32 t : mine) { if (t == EMPTY_TASK) continue; max_tiles = std::max(max_tiles, segs[t].ntiles); max_seg = std::max(max_seg, segs[t].segs.size()); }
+        for (int sl = 0; sl < 2; ++sl) {
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                DALLOC(c, xpre[sl][i].d_segs, ExpSeg *, sizeof(ExpSeg) * max_seg);
+                DALLOC(c, xpre[sl][i].d_tile_sum, u64 *, max_tiles * 16 + 64);
+                DALLOC(c, xpre[sl][i].d_tile_off, u64 *, max_tiles * 16 + 64);
+            }
+            ev_ready[sl] = ev_get(c); ev_done[sl] = ev_get(c);
+        }
+        // everything the pool handed out above may still be in use by earlier main-stream work
+        hipEvent_t fence = ev_get(c);
+        HIPCHK(c, hipEventRecord(fence, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(xstream, fence, 0));
+        ev_put(c, fence);
+    }
+    u64 n_total = 0, pay_total = 0;
+    // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
+    std::vector<u64> pay_before(ntasks, 0);
+    { u64 acc = 0; for (u32 t : mine) { if (t == EMPTY_TASK) continue; pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
+    TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
+    // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
+    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
+    const bool agg = fused && agg_enabled();
+    // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
+    const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
+    int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
+    BatchTask bts[2][XCD_BATCH];
+    // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
+    auto issue_expand = [&](size_t bpos, int sl) -> int {
+        const int prefix_bits = (agg || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        slot_prefix[sl] = prefix_bits;
+        PassDesc plan[MAX_PASSES];
+        const int npass = batch_pass_plan<NW>(c, K, fused || fused_ext, prefix_bits, plan);
+        if (piped && done_valid[sl]) HIPCHK(c, hipStreamWaitEvent(xstream, ev_done[sl], 0));     // the slot's previous batch is counted
+        pt.begin(PH_EXTRACT, xstream);
+        HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, xstream));
+        ExpandJob jobs[XCD_BATCH];
+        for (int i = 0; i < XCD_BATCH; ++i) {
+            const u32 t = mine[bpos + i];
+            BatchTask &b = bts[sl][i];
+            b = BatchTask();
+            b.kA = kAs[sl][i]; b.kB = kBs[sl][i]; b.vA = vAs[sl][i]; b.vB = vBs[sl][i];
+            if (t == EMPTY_TASK) { jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs; continue; }
+            b.n = segs[t].nkmers;
+            const TaskInput in = feeder ? feeder->input(t) : dflt;
+            jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
+            jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
+        }
+        int rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc;
+        pt.end(PH_EXTRACT, xstream);
+        if (piped) HIPCHK(c, hipEventRecord(ev_ready[sl], xstream));
+        return HSK_OK;
+    };
+    size_t pos = 0;
+    const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
+    if (piped) { int rc = issue_expand(0, 0); if (rc) return rc; }
+    for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
+        const int sl = piped ? (int)(b & 1) : 0;
+        if (feeder) {                                   // exposed (not overlapped) part of the exchange
+            pt.begin(PH_EXCH);
+            for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK) continue; int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
+            pt.end(PH_EXCH);
+        }
+        if (!piped) { int rc = issue_expand(pos, 0); if (rc) return rc; }
+        else {
+            if (b + 1 < nbatch) { int rc = issue_expand(pos + XCD_BATCH, (int)((b + 1) & 1)); if (rc) return rc; }
+            HIPCHK(c, hipStreamWaitEvent(c->stream, ev_ready[sl], 0));
+        }
+        BatchTask *bt = bts[sl];
+        if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
+        const int prefix_bits = slot_prefix[sl];
+        pt.begin(PH_SORT);
+        { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        if (fused_ext) {
+            if constexpr (NW == 1) {
+                TaskOut fo[XCD_BATCH]; u64 pb[XCD_BATCH];
+                for (int i = 0; i < XCD_BATCH; ++i) pb[i] = mine[pos + i] != EMPTY_TASK ? pay_before[mine[pos + i]] : 0;
+                int rc = agg_ext_finish_batch_device(c, bt, K, pb, d_histo, histo_len, fo); if (rc) return rc;
+                for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
+            }
+        } else if (fused) {
+            if constexpr (NW <= 2) {
+                TaskOut fo[XCD_BATCH];
+                int rc;
+                if constexpr (NW == 1) rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits)
+                                                : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
+                else rc = agg_finish_batch_device<NW>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits);
+                if (rc) return rc;
+                for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
+            }
+        } else {
+            for (int i = 0; i < XCD_BATCH; ++i) {
+                const u32 t = mine[pos + i];
+                if (t == EMPTY_TASK) continue;
+                int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+            }
+        }
+        pt.end(PH_COUNT);
+        if (piped) { HIPCHK(c, hipEventRecord(ev_done[sl], c->stream)); done_valid[sl] = true; }
+    }
+    if (piped) {
+        HIPCHK(c, hipStreamSynchronize(xstream));
+        for (int sl = 0; sl < 2; ++sl) {
+            for (int i = 0; i < XCD_BATCH; ++i) expand_release(c, xpre[sl][i]);
+            ev_put(c, ev_ready[sl]); ev_put(c, ev_done[sl]);
+        }
+    }
+    for (; pos < mine.size(); ++pos) {
+        const u32 t = mine[pos];
+        const u64 n = segs[t].nkmers;
+        int rc;
+        if (feeder) { pt.begin(PH_EXCH); rc = feeder->need(feeder->group_of[t]); pt.end(PH_EXCH); if (rc) return rc; }
+        pt.begin(PH_EXTRACT);
+        const TaskInput in = feeder ? feeder->input(t) : dflt;
+        rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[0], vA[0]); if (rc) return rc;
+        pt.end(PH_EXTRACT);
+        if (feeder) feeder->release_below(pos + 1 < mine.size() ? feeder->group_of[mine[pos + 1]] : feeder->ngroups);
+        pt.begin(PH_SORT);
+        u64 *sk, *sv;
+        rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
+        pt.end(PH_SORT);
+        pt.begin(PH_COUNT);
+        rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
+        pt.end(PH_COUNT);
+    }
+    // heavy-hitter tasks this rank owns arrive as k-mer lists: order, sum, filter
+    if (ex && ex->heavy_in) {
+        pt.begin(PH_COUNT);
+        for (const HeavyIn &hv : *ex->heavy_in) {
+            if constexpr (NW == 1) { int rc = heavy_merge_task(c, hv.d_entries, hv.n, d_histo, histo_len, touts[hv.task]); if (rc) return rc; }
+            mine.push_back(hv.task);
+        }
+        pt.end(PH_COUNT);
+    }
+    for (u32 t : mine) { if (t == EMPTY_TASK) continue; touts[t].pay_base = pay_before[t]; n_total += touts[t].n; pay_total += touts[t].npay; }
+    for (u32 t : mine_done) { n_total += touts[t].n; pay_total += touts[t].npay; }
+    if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
+    {
+        int rc = check_device_error(c); if (rc) return rc;
+    }
+    for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
+    free_sort_scratch(c, sc);
+    c->pool.release(d_ghist_slot[0]); c->pool.release(d_ghist_slot[1]);
+
+    // ---- result ----------------------------------------------------------------------------------------
+    pt.begin(PH_D2H);
+    out->n = n_total;
+    out->task_off = (uint64_t *)host_alloc(rp, (size_t)(ntasks + 1) * 8);
+    out->histo = (uint64_t *)host_alloc(rp, (size_t)histo_len * 8);
+    out->histo_len = histo_len;
+    if (!out->task_off || !out->histo) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+    HIPCHK(c, hipMemcpyAsync(out->histo, d_histo, (size_t)histo_len * 8, hipMemcpyDeviceToHost, c->stream));
+    const bool keep = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
+    if (!keep) {
+        out->entries = (uint64_t *)host_alloc(rp, n_total * (NW + 1) * 8);
+        if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
+        if (ext) {
+            out->payload_off = (uint64_t *)host_alloc(rp, (n_total + 1) * 8);
+            out->pos = (uint32_t *)host_alloc(rp, pay_total * 4);
+            out->rid = (int32_t *)host_alloc(rp, pay_total * 4);
+            if (!out->payload_off || !out->pos || !out->rid) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
+        }
+    }
+    u64 o = 0, po = 0;
+    for (u32 t = 0; t < ntasks; ++t) {
+        out->task_off[t] = o;
+        TaskOut &to = touts[t];
+        if (!keep) {
+            if (to.n) HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.n) HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
+            if (ext && to.npay) {
+                HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(out->rid + po, to.rid, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
+        o += to.n; po += to.npay;
+    }
+    out->task_off[ntasks] = o;
+    pt.end(PH_D2H);
+    if (pt_total_open) pt.end(PH_TOTAL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ext && !keep) out->payload_off[n_total] = pay_total;
+    if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
+    else for (auto &to : touts) free_task_out(c, to);
+    c->pool.release(d_histo);
+    if (pt_total_open) out->ms_total = pt.collect(PH_TOTAL);
+    out->ms_parse = pt.collect(PH_PARSE); out->ms_exchange = pt.collect(PH_EXCH);
+    out->ms_extract = pt.collect(PH_EXTRACT); out->ms_sort = pt.collect(PH_SORT); out->ms_count = pt.collect(PH_COUNT);
+    out->ms_d2h = pt.collect(PH_D2H);
+    return HSK_OK;
+}
+
+// ---- heavy-hitter tasks (a8): the sending side ----------------------------------------------------------------
+// HeavyHitterClassifier (reference src/kmerops.cpp:1157-1199) on the GLOBAL k-mer counts; forced plain with
+// EXTENSION or PLAIN_CLASSIFIER (kmerops.cpp:109-113) and, here, for keys of more than one word.
+static bool heavy_enabled(hsk_ctx *c, int nw, int nranks)
+{
+    static const bool env_on = !(getenv("HSK_HEAVY") && atoi(getenv("HSK_HEAVY")) == 0);
+    return env_on && nranks > 1 && nw == 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0 &&
+           hybrid_enabled() && finish_enabled() && agg_enabled();
+}
+static double heavy_ratio() { static const double r = getenv("HSK_UNBALANCED_RATIO") ? atof(getenv("HSK_UNBALANCED_RATIO")) : 2.3; return r; }
+
+// Every rank turns its OWN supermers of the heavy tasks into unfiltered {k-mer, count} lists (ScatteredKmerList,
+// kmerops.cpp:363-398): only the heavy tasks are placed, then the ordinary expand / sort / aggregate kernels run with
+// L = 1, U = max.  lists[t] stays in HBM; failed[t] = the aggregating finish could not handle the task (it is then
+// sent as supermers like any other task -- on every rank, the flags are combined by the caller).
+template <int NW>
+static int heavy_preaggregate(hsk_ctx *c, ParseJob &job, const u8 *d_packed, u64 packed_bytes, const std::vector<u8> &is_heavy,
+                              std::vector<TaskOut> &lists, std::vector<u8> &failed)
+{
+    const u32 ntasks = job.ntasks;
+    lists.assign(ntasks, TaskOut()); failed.assign(ntasks, 0);
+    std::vector<u32> order; std::vector<u8> skip(ntasks, 0);
+    for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t]) order.push_back(t);
+    for (u32 t = 0; t < ntasks; ++t) if (!is_heavy[t]) { order.push_back(t); skip[t] = 1; }
+    SupermerStore sth;
+    int rc = parse_place(c, job, order, sth, &skip); if (rc) return rc;
+    std::vector<TaskSegs> segs(ntasks);
+    std::vector<int32_t> own(ntasks, -1);
+    for (u32 t = 0; t < ntasks; ++t) {
+        if (!is_heavy[t]) continue;
+        own[t] = 0;
+        if (sth.task_tot[3 * t] == 0) continue;
+        ExpSeg sg; sg.sup_off = sth.task_base[3 * t]; sg.n_sup = sth.task_tot[3 * t]; sg.byte_off = sth.task_base[3 * t + 1]; sg.kmer_off = 0; sg.tile_start = 0;
+        segs[t].segs.push_back(sg); segs[t].nkmers = sth.task_tot[3 * t + 2];
+    }
+    const hsk_config keep = c->cfg;
+    c->cfg.lower_freq = 1; c->cfg.upper_freq = INT32_MAX; c->cfg.flags |= HSK_FLAG_KEEP_DEVICE;
+    c->forbid_long_way = true;
+    hsk_result tmp; memset(&tmp, 0, sizeof tmp);
+    ResultPriv *rp = new ResultPriv(); tmp.priv = rp; tmp.nw = NW;
+    PhaseTimer pt(c);
+    ProcExtra ex; ex.force_batch = true;
+    rc = process_rank<NW>(c, ntasks, own, 0, segs, sth.sm_len, source_from_packed(d_packed, packed_bytes, sth.sm_gpos), nullptr, nullptr, &tmp, rp, pt, false, nullptr, &ex);
+    c->cfg = keep; c->forbid_long_way = false;
+    if (rc == HSK_OK) {
+        for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t] && t < rp->dev_tasks.size()) { lists[t] = rp->dev_tasks[t]; failed[t] = lists[t].failed ? 1 : 0; }
+        rp->dev_tasks.clear();                              // the lists are ours now
+    }
+    hsk_result_free(c, &tmp);
+    free_store(c, sth);
+    return rc;
+}
+
+template <int NW>
+static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                        int64_t rid_base, hsk_result *out)
+{
+    const bool ext = c->cfg.extension != 0;
+    const int K = c->cfg.kmer_size;
+    const int nranks = c->comm.active() ? c->comm.nranks : 1;
+    const int rank = c->comm.active() ? c->comm.rank : 0;
+    memset(out, 0, sizeof *out);
+    ResultPriv *rp = new ResultPriv();
+    out->priv = rp; out->nw = NW;
+    PhaseTimer pt(c);
+    pt.begin(PH_TOTAL);
+
+    u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : auto_ntasks(c, packed_bytes, nranks);
+    if (c->comm.active() && !c->cfg.ntasks) {
+        // every rank must use the same task count: take the maximum of the local proposals
+        u64 v = ntasks; int rc = c->comm.allreduce_max_u64(&v, 1, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks) failed: %d", rc);
+        ntasks = (u32)v;
+    }
+    out->ntasks = (int32_t)ntasks;
+    std::vector<int32_t> owner(ntasks, 0);
+    std::vector<u32> order(ntasks);
+    for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+
+    // ---- parse ------------------------------------------------------------------------------------
+    SupermerStore st;
+    std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<TaskOut> hlists;                         // this rank's {k-mer, count} lists of the heavy tasks
+    std::vector<HeavyIn> hin;                            // heavy tasks this rank owns: the lists of all ranks
+    bool any_heavy = false;
+    pt.begin(PH_PARSE);
+    {
+        // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
+        // before the storage order (tasks grouped by owner rank) is known, then parse_place lays the supermers out
+        ParseJob job;
+        int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, job);
+        if (rc) { parse_release(c, job); return rc; }
+        if (nranks > 1) {
+            std::vector<u64> bytes(ntasks);
+            for (u32 t = 0; t < ntasks; ++t) bytes[t] = job.task_tot[3 * t + 1] + job.task_tot[3 * t] * (ext ? 9 : 1);
+            // heavy-hitter tasks (a8): classified on the global k-mer counts; every rank pre-aggregates its own share
+            if (heavy_enabled(c, NW, nranks)) {
+                std::vector<u64> kg(ntasks); std::vector<int32_t> types(ntasks, 0);
+                for (u32 t = 0; t < ntasks; ++t) kg[t] = job.task_tot[3 * t + 2];
+                rc = c->comm.allreduce_sum_u64(kg.data(), ntasks, c->stream, c->pool);
+                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task k-mers) failed: %d", rc); }
+                plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+                for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+            }
+            if (any_heavy) {
+                std::vector<u8> failed;
+                rc = heavy_preaggregate<NW>(c, job, d_packed, packed_bytes, is_heavy, hlists, failed);
+                if (rc) { parse_release(c, job); return rc; }
+                std::vector<u64> bad(ntasks);
+                for (u32 t = 0; t < ntasks; ++t) bad[t] = failed[t];
+                rc = c->comm.allreduce_max_u64(bad.data(), ntasks, c->stream, c->pool);     // a task one rank could not aggregate travels as supermers everywhere
+                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(heavy flags) failed: %d", rc); }
+                any_heavy = false;
+                for (u32 t = 0; t < ntasks; ++t) {
+                    if (!is_heavy[t]) continue;
+                    if (bad[t]) { is_heavy[t] = 0; free_task_out(c, hlists[t]); continue; }
+                    any_heavy = true; c->stats.heavy_tasks++;
+                    bytes[t] = hlists[t].n * (u64)(NW + 1) * 8;                               // ScatteredKmerList::get_size_bytes
+                }
+            }
+            rc = c->comm.allreduce_sum_u64(bytes.data(), ntasks, c->stream, c->pool);
+            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc); }
+            rc = plan_dispatch(bytes.data(), (int)ntasks, nranks, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data());
+            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }
+            std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
+        }
+        rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr);
+        parse_release(c, job);
+        if (rc) return rc;
+    }
+    pt.end(PH_PARSE);
+    out->total_supermers = st.tot_sup; out->total_supermer_bytes = st.tot_bytes + st.tot_sup * (ext ? 9 : 1);
+
+    // ---- exchange (multi-GPU) ---------------------------------------------------------------------
+    // After this block `segs[t]` lists where the supermers of owned task t live.
+    std::vector<TaskSegs> segs(ntasks);
+    const u8 *x_len = st.sm_len; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
+    BaseSource x_src = source_from_packed(d_packed, packed_bytes, st.sm_gpos);
+    ExchangeBuffers xb;
+    GroupFeeder feeder; bool fed = false;
+    pt.begin(PH_EXCH);
+    if (nranks > 1) {
+        int rc = pack_store_bytes(c, st, x_src); if (rc) return rc;
+        if (overlap_enabled()) {
+            // size matrix: every rank contributes its row, the sum is the full matrix
+            std::vector<u64> M((size_t)nranks * ntasks * 3, 0);
+            for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)rank * ntasks * 3 + i] = st.task_tot[i];
+            rc = c->comm.allreduce_sum_u64(M.data(), M.size(), c->stream, c->pool);
+            if (rc) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", rc, c->comm.last_error.c_str());
+            rc = feeder.plan(c, nranks, rank, ntasks, owner, order, M, st.task_base, segs); if (rc) return rc;
+            feeder.st = &st; fed = true;
+        } else {
+            rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
+                                    st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
+            if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
+            x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
+            x_src = source_from_bytes(xb.bytes, xb.nbytes);
+            free_store(c, st);
+        }
+    } else {
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (st.task_tot[3 * t] == 0) continue;
+            ExpSeg s; s.sup_off = st.task_base[3 * t]; s.n_sup = st.task_tot[3 * t]; s.byte_off = st.task_base[3 * t + 1]; s.kmer_off = 0; s.tile_start = 0;
+            segs[t].segs.push_back(s); segs[t].nkmers = st.task_tot[3 * t + 2];
+        }
+    }
+    if (any_heavy) {
+        // the k-mer lists of the heavy tasks go to their owners: counts by all-reduce, one grouped send/recv
+        std::vector<u32> hv_tasks; for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t]) hv_tasks.push_back(t);
+        const size_t nh = hv_tasks.size();
+        std::vector<u64> Hn((size_t)nranks * nh, 0);
+        for (size_t i = 0; i < nh; ++i) Hn[(size_t)rank * nh + i] = hlists[hv_tasks[i]].n;
+        int rc = c->comm.allreduce_sum_u64(Hn.data(), Hn.size(), c->stream, c->pool);
+        if (rc) return fail(c, HSK_ERR_COMM, "allreduce(heavy list sizes) failed: %d (%s)", rc, c->comm.last_error.c_str());
+        const size_t ew = (size_t)(NW + 1) * 8;
+        for (size_t i = 0; i < nh; ++i) {
+            const u32 t = hv_tasks[i];
+            if (owner[t] != rank) continue;
+            HeavyIn hv; hv.task = t; hv.n = 0; hv.d_entries = nullptr;
+            for (int p = 0; p < nranks; ++p) hv.n += Hn[(size_t)p * nh + i];
+            if (hv.n) DALLOC(c, hv.d_entries, u64 *, hv.n * ew);
+            hin.push_back(hv);
+        }
+        Comm &cm = c->comm;
+        if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str());
+        size_t hi = 0;
+        for (size_t i = 0; i < nh && rc == 0; ++i) {
+            const u32 t = hv_tasks[i];
+            if (owner[t] == rank) {
+                HeavyIn &hv = hin[hi++];
+                u64 o = 0;
+                for (int p = 0; p < nranks && rc == 0; ++p) {
+                    const u64 n = Hn[(size_t)p * nh + i];
+                    if (n && p != rank) rc = cm.check(cm.api->Recv((char *)hv.d_entries + o * ew, n * ew, RCCL_UINT8, p, cm.comm, c->stream), "ncclRecv(heavy list)");
+                    o += n;
+                }
+            } else if (hlists[t].n) {
+                rc = cm.check(cm.api->Send(hlists[t].entries, hlists[t].n * ew, RCCL_UINT8, owner[t], cm.comm, c->stream), "ncclSend(heavy list)");
+            }
+        }
+        const int rc2 = cm.check(cm.api->GroupEnd(), "ncclGroupEnd");
+        if (rc || rc2) return fail(c, HSK_ERR_COMM, "heavy-hitter list exchange failed: %s", cm.last_error.c_str());
+        hi = 0;
+        for (size_t i = 0; i < nh; ++i) {                                   // own share: device copy
+            const u32 t = hv_tasks[i];
+            if (owner[t] != rank) continue;
+            HeavyIn &hv = hin[hi++];
+            u64 o = 0; for (int p = 0; p < rank; ++p) o += Hn[(size_t)p * nh + i];
+            if (hlists[t].n) HIPCHK(c, hipMemcpyAsync((char *)hv.d_entries + o * ew, hlists[t].entries, hlists[t].n * ew, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &to : hlists) free_task_out(c, to);
+    }
+    pt.end(PH_EXCH);
+    ProcExtra ex; ex.heavy_in = &hin;
+    int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
+    for (auto &hv : hin) c->pool.release(hv.d_entries);
+    if (nranks > 1 && !fed) xb.release(c->pool); else free_store(c, st);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// virtual ranks on one GPU: the multi-GPU data path (probe, dispatch, owner-grouped parse, pack,
+// all-to-all-v plan, multi-segment expand) with device-to-device copies in place of RCCL send/recv.
+// This is how the exchange logic is exercised on a single-GPU box (tests/test_gpu_multirank.py).
+// ------------------------------------------------------------------------------------------------
+struct DevInput { u8 *packed = nullptr; u64 *roff = nullptr; u32 *rlen = nullptr; };
+
+template <int NW>
+static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed_bytes, const u64 *nreads, hsk_result *outs, int32_t *owner_out, u32 *ntasks_out)
+{
+    const bool ext = c->cfg.extension != 0;
+    u64 tot_bytes = 0; for (int r = 0; r < R; ++r) tot_bytes += packed_bytes[r];
+    const u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : auto_ntasks(c, tot_bytes / (u64)R + 1, R);
+    *ntasks_out = ntasks;
+    std::vector<int64_t> rid_base(R, 0);
+    for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
+    std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    // 1. hash every rank's reads once (parse_count), sum the task sizes, dispatch
+    std::vector<u64> bytes(ntasks, 0);
+    std::vector<ParseJob> jobs(R);
+    auto release_jobs = [&]() { for (auto &j : jobs) parse_release(c, j); };
+    for (int r = 0; r < R; ++r) {
+        int rc = parse_count(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, jobs[r]);
+        if (rc) { release_jobs(); return rc; }
+        for (u32 t = 0; t < ntasks; ++t) bytes[t] += jobs[r].task_tot[3 * t + 1] + jobs[r].task_tot[3 * t] * (ext ? 9 : 1);
+    }
+    // 1b. heavy-hitter tasks: classify on the global k-mer counts, every rank pre-aggregates its share
+    std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<std::vector<TaskOut>> hlists(R);
+    auto free_hlists = [&]() { for (auto &v : hlists) for (auto &to : v) free_task_out(c, to); };
+    bool any_heavy = false;
+    if (heavy_enabled(c, NW, R)) {
+        std::vector<u64> kg(ntasks, 0); std::vector<int32_t> types(ntasks, 0);
+        for (int r = 0; r < R; ++r) for (u32 t = 0; t < ntasks; ++t) kg[t] += jobs[r].task_tot[3 * t + 2];
+        plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+        for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+    }
+    if (any_heavy) {
+        std::vector<u8> bad(ntasks, 0);
+        for (int r = 0; r < R; ++r) {
+            std::vector<u8> failed;
+            int rc = heavy_preaggregate<NW>(c, jobs[r], in[r].packed, packed_bytes[r], is_heavy, hlists[r], failed);
+            if (rc) { release_jobs(); free_hlists(); return rc; }
+            for (u32 t = 0; t < ntasks; ++t) bad[t] |= failed[t];
+        }
+        any_heavy = false;
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (!is_heavy[t]) continue;
+            if (bad[t]) { is_heavy[t] = 0; for (int r = 0; r < R; ++r) free_task_out(c, hlists[r][t]); continue; }   // travels as supermers after all
+            any_heavy = true; c->stats.heavy_tasks++;
+            bytes[t] = 0;
+            for (int r = 0; r < R; ++r) bytes[t] += hlists[r][t].n * (u64)(NW + 1) * 8;       // ScatteredKmerList::get_size_bytes
+        }
+    }
+    std::vector<int32_t> owner(ntasks, 0);
+    if (plan_dispatch(bytes.data(), (int)ntasks, R, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data())) {
+        release_jobs(); free_hlists();
+        return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH));
+    }
+    if (owner_out) memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks);
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
+    // 2. owner-grouped placement + byte materialisation on every rank
+    std::vector<SupermerStore> st(R);
+    std::vector<u64> M((size_t)R * ntasks * 3, 0);
+    for (int r = 0; r < R; ++r) {
+        int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr);
+        parse_release(c, jobs[r]);
+        if (rc) { release_jobs(); return rc; }
+        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) { release_jobs(); return rc; }
+        for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
+    }
+    // 2b. the k-mer lists of the heavy tasks go to their owners (device copies here, send/recv in run_pipeline)
+    std::vector<std::vector<HeavyIn>> hin(R);
+    if (any_heavy) {
+        for (u32 t = 0; t < ntasks; ++t) {
+            if (!is_heavy[t]) continue;
+            HeavyIn hv; hv.task = t; hv.n = 0; hv.d_entries = nullptr;
+            for (int r = 0; r < R; ++r) hv.n += hlists[r][t].n;
+            if (hv.n) {
+                DALLOC(c, hv.d_entries, u64 *, hv.n * (NW + 1) * 8);
+                u64 o = 0;
+                for (int r = 0; r < R; ++r) {
+                    if (hlists[r][t].n) HIPCHK(c, hipMemcpyAsync(hv.d_entries + o * (NW + 1), hlists[r][t].entries, hlists[r][t].n * (NW + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+                    o += hlists[r][t].n;
+                }
+            }
+            hin[owner[t]].push_back(hv);
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_hlists();
+    }
+    auto free_hin = [&]() { for (auto &v : hin) for (auto &hv : v) c->pool.release(hv.d_entries); };
+    // 3. the exchange: same plans as the RCCL path (hsk_comm.h), device copies instead of send/recv
+    if (overlap_enabled()) {
+        // grouped exchange overlapped with the sort, exactly as run_pipeline drives it
+        std::vector<GroupFeeder> fd(R);
+        std::vector<std::vector<ExchangePlan>> pl_all(R);
+        std::vector<std::vector<TaskSegs>> segs(R);
+        for (int d = 0; d < R; ++d) { int rc = fd[d].plan(c, R, d, ntasks, owner, order, M, st[d].task_base, segs[d]); if (rc) return rc; pl_all[d] = fd[d].pl; }
+        int rc_all = HSK_OK;
+        for (int r = 0; r < R && rc_all == HSK_OK; ++r) {
+            fd[r].st_all = &st; fd[r].pl_all = &pl_all;
+            memset(&outs[r], 0, sizeof(hsk_result));
+            ResultPriv *rp = new ResultPriv();
+            outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
+            PhaseTimer pt(c);
+            ProcExtra ex; ex.heavy_in = &hin[r];
+            rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r], &ex);
+        }
+        for (int r = 0; r < R; ++r) free_store(c, st[r]);
+        free_hin();
+        return rc_all;
+    }
+    std::vector<ExchangePlan> pl(R);
+    std::vector<std::vector<TaskSegs>> segs(R);
+    std::vector<ExchangeBuffers> xb(R);
+    for (int d = 0; d < R; ++d) {
+        plan_exchange(R, d, ntasks, owner, order, M, st[d].task_base, pl[d], segs[d]);
+        xb[d].len = (u8 *)c->pool.alloc(pl[d].recv_tot_sup + 64); xb[d].bytes = (u8 *)c->pool.alloc(pl[d].recv_tot_bytes + 64); xb[d].nbytes = pl[d].recv_tot_bytes;
+        if (ext) { xb[d].pos = (u32 *)c->pool.alloc(pl[d].recv_tot_sup * 4 + 64); xb[d].rid = (int32_t *)c->pool.alloc(pl[d].recv_tot_sup * 4 + 64); }
+        if (!xb[d].len || !xb[d].bytes || (ext && (!xb[d].pos || !xb[d].rid))) return fail(c, HSK_ERR_OOM, "exchange buffers");
+    }
+    for (int d = 0; d < R; ++d) for (int sidx = 0; sidx < R; ++sidx) {
+        const u64 n = pl[sidx].send_sup[d], nb = pl[sidx].send_bytes[d];
+        if (n != pl[d].recv_sup[sidx] || nb != pl[d].recv_bytes[sidx]) return fail(c, HSK_ERR_INTERNAL, "exchange plan mismatch %d->%d", sidx, d);
+        if (!n) continue;
+        HIPCHK(c, hipMemcpyAsync(xb[d].len + pl[d].recv_sup_off[sidx], st[sidx].sm_len + pl[sidx].send_sup_off[d], n, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(xb[d].bytes + pl[d].recv_byte_off[sidx], st[sidx].sm_bytes + pl[sidx].send_byte_off[d], nb, hipMemcpyDeviceToDevice, c->stream));
+        if (ext) {
+            HIPCHK(c, hipMemcpyAsync(xb[d].pos + pl[d].recv_sup_off[sidx], st[sidx].sm_pos + pl[sidx].send_sup_off[d], n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(xb[d].rid + pl[d].recv_sup_off[sidx], st[sidx].sm_rid + pl[sidx].send_sup_off[d], n * 4, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < R; ++r) free_store(c, st[r]);
+    // 4. every rank finishes its own tasks
+    for (int r = 0; r < R; ++r) {
+        memset(&outs[r], 0, sizeof(hsk_result));
+        ResultPriv *rp = new ResultPriv();
+        outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
+        PhaseTimer pt(c);
+        ProcExtra ex; ex.heavy_in = &hin[r];
+        int rc = process_rank<NW>(c, ntasks, owner, r, segs[r], xb[r].len, source_from_bytes(xb[r].bytes, xb[r].nbytes), xb[r].pos, xb[r].rid, &outs[r], rp, pt, false, nullptr, &ex);
+        xb[r].release(c->pool);
+        if (rc) { free_hin(); return rc; }
+    }
+    free_hin();
+    return HSK_OK;
+}
