@@ -12,23 +12,6 @@ static void finalize_segs(TaskSegs &ts)
     ts.ntiles = tile;
 }
 
-// where the bases of a task's supermers live
-struct BaseSource {
-    const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
-    const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
-};
-static BaseSource source_from_packed(const u8 *d_packed, u64 packed_bytes, const u64 *gpos)
-{
-    BaseSource b; const uintptr_t p = (uintptr_t)d_packed;
-    b.src8 = (const u64 *)(p & ~(uintptr_t)7); b.bit0 = 8 * (u64)(p & 7); b.nwords = ((p & 7) + packed_bytes + 7) / 8; b.gpos = gpos;
-    return b;
-}
-static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
-{
-    BaseSource b; b.src8 = (const u64 *)bytes; b.bit0 = 0; b.nwords = (nbytes + 7) / 8 + 1; b.gpos = nullptr;   // pool blocks are padded
-    return b;
-}
-
 struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr; };
 
 // tile sums + scans of n <= EXP_PREP_BATCH tasks with two launches
@@ -130,10 +113,13 @@ static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const B
 }
 
 // multi-GPU: bytes of all supermers of the store, in storage order (what the exchange sends)
-static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src)
+// run_kernel = false: only the byte array is allocated; the bytes of a task group are produced right before the group
+// travels (pack_group, on the communication stream, overlapped with the sort of the previous group)
+static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src, bool run_kernel = true)
 {
     DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
-    if (st.tot_sup == 0) return HSK_OK;
+    st.base = src;
+    if (st.tot_sup == 0 || !run_kernel) return HSK_OK;
     TaskSegs all; ExpSeg s; s.sup_off = 0; s.n_sup = st.tot_sup; s.byte_off = 0; s.kmer_off = 0; s.tile_start = 0;
     all.segs.push_back(s);
     all.ntiles = (st.tot_sup + EXP_TILE - 1) / EXP_TILE;
@@ -144,5 +130,39 @@ static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));          // `all` lives on this stack frame
     expand_release(c, x);
+    return HSK_OK;
+}
+
+// The bytes of the supermer ranges one task group sends (one contiguous range per destination rank), packed on `stream`.
+// The scratch of the job must have been allocated (pack_group_alloc) before the caller fenced `stream` against the main
+// stream; the job (host-side segment list included) stays alive until the group has been released.
+struct PackJob { TaskSegs ts; ExpandScratch x; };
+
+static int pack_group_alloc(hsk_ctx *c, const ExchangePlan &sp, int nranks, PackJob &job)
+{
+    job = PackJob();
+    u64 tile = 0;
+    for (int q = 0; q < nranks; ++q) {
+        if (!sp.send_sup[q]) continue;
+        ExpSeg sg; sg.sup_off = sp.send_sup_off[q]; sg.n_sup = sp.send_sup[q]; sg.byte_off = sp.send_byte_off[q]; sg.kmer_off = 0; sg.tile_start = tile;
+        tile += (sg.n_sup + EXP_TILE - 1) / EXP_TILE;
+        job.ts.segs.push_back(sg);
+    }
+    job.ts.ntiles = tile;
+    if (!tile) return HSK_OK;
+    DALLOC(c, job.x.d_segs, ExpSeg *, sizeof(ExpSeg) * job.ts.segs.size());
+    DALLOC(c, job.x.d_tile_sum, u64 *, tile * 16 + 64);
+    DALLOC(c, job.x.d_tile_off, u64 *, tile * 16 + 64);
+    return HSK_OK;
+}
+
+static int pack_group_launch(hsk_ctx *c, const SupermerStore &st, PackJob &job, hipStream_t stream)
+{
+    if (!job.ts.ntiles) return HSK_OK;
+    const TaskSegs *tp = &job.ts; const u8 *lens = st.sm_len;
+    int rc = expand_prepare_batch(c, 1, &tp, &lens, &job.x, stream, true); if (rc) return rc;
+    hipLaunchKernelGGL(pack_kernel, dim3((u32)job.ts.ntiles), dim3(EXP_THREADS), 0, stream, job.x.d_segs, (int)job.ts.segs.size(), st.sm_len,
+                       st.base.src8, st.base.bit0, st.base.nwords, st.sm_gpos, job.x.d_tile_off, st.sm_bytes);
+    HIPCHK(c, hipGetLastError());
     return HSK_OK;
 }

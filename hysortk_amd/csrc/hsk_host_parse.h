@@ -5,6 +5,23 @@
 // ------------------------------------------------------------------------------------------------
 // stage: parse (a4, a5, a6)
 // ------------------------------------------------------------------------------------------------
+// where the bases of a task's supermers live
+struct BaseSource {
+    const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
+    const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
+};
+static BaseSource source_from_packed(const u8 *d_packed, u64 packed_bytes, const u64 *gpos)
+{
+    BaseSource b; const uintptr_t p = (uintptr_t)d_packed;
+    b.src8 = (const u64 *)(p & ~(uintptr_t)7); b.bit0 = 8 * (u64)(p & 7); b.nwords = ((p & 7) + packed_bytes + 7) / 8; b.gpos = gpos;
+    return b;
+}
+static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
+{
+    BaseSource b; b.src8 = (const u64 *)bytes; b.bit0 = 0; b.nwords = (nbytes + 7) / 8 + 1; b.gpos = nullptr;   // pool blocks are padded
+    return b;
+}
+
 struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
@@ -12,6 +29,8 @@ struct SupermerStore {
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
     std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
     std::vector<u32> order;       // storage order of tasks (grouped by owner rank, ascending id)
+    BaseSource base;              // multi-GPU: where pack_kernel reads the bases from (the rank's packed reads)
+    std::vector<char> group_packed;  // multi-GPU, grouped exchange: sm_bytes of task group g have been produced
 };
 
 static void free_store(hsk_ctx *c, SupermerStore &s)

@@ -22,8 +22,10 @@ struct GroupFeeder {
     std::vector<hipEvent_t> arrived;                   // [group] recorded on comm_stream after the transfer
     int posted = 0, released = 0;
     // transport: RCCL (store of this rank) or loopback (stores and plans of all virtual ranks)
-    const SupermerStore *st = nullptr;
-    const std::vector<SupermerStore> *st_all = nullptr;
+    SupermerStore *st = nullptr;
+    std::vector<SupermerStore> *st_all = nullptr;
+    std::vector<std::vector<PackJob>> packs;           // [group] byte-packing jobs issued with the group (scratch released with it)
+    bool lazy_pack = false;                            // the stores' bytes are produced group by group (pack_group_*)
     const std::vector<std::vector<ExchangePlan>> *pl_all = nullptr;     // [rank][group]
     u64 bytes_moved = 0;
 
@@ -32,7 +34,7 @@ struct GroupFeeder {
     {
         c = c_; nranks = nranks_; rank = rank_; ext = c->cfg.extension != 0;
         assign_task_groups(nranks, ntasks, owner, XCD_BATCH, group_of, ngroups);
-        pl.resize(ngroups); xb.resize(ngroups); arrived.assign(ngroups, nullptr);
+        pl.resize(ngroups); xb.resize(ngroups); arrived.assign(ngroups, nullptr); packs.assign(ngroups, std::vector<PackJob>());
         segs.assign(ntasks, TaskSegs());
         for (int g = 0; g < ngroups; ++g) plan_exchange(nranks, rank, ntasks, owner, order, M, task_base, pl[g], segs, &group_of, g);
         return HSK_OK;
@@ -43,6 +45,18 @@ struct GroupFeeder {
         b.len = (u8 *)c->pool.alloc(p.recv_tot_sup + 64); b.bytes = (u8 *)c->pool.alloc(p.recv_tot_bytes + 64); b.nbytes = p.recv_tot_bytes;
         if (ext) { b.pos = (u32 *)c->pool.alloc(p.recv_tot_sup * 4 + 64); b.rid = (int32_t *)c->pool.alloc(p.recv_tot_sup * 4 + 64); }
         if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid))) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
+        // the bytes this group sends are packed now, on the communication stream (RCCL: this rank's store; virtual ranks:
+        // the store of every source that has not produced group g yet)
+        std::vector<SupermerStore *> to_pack;
+        if (lazy_pack) {
+            if (st_all) { for (int src = 0; src < nranks; ++src) { SupermerStore &ss = (*st_all)[src]; if (ss.group_packed.size() <= (size_t)g) ss.group_packed.resize(ngroups, 0); if (!ss.group_packed[g]) to_pack.push_back(&ss); } }
+            else { if (st->group_packed.size() <= (size_t)g) st->group_packed.resize(ngroups, 0); if (!st->group_packed[g]) to_pack.push_back(st); }
+            packs[g].resize(to_pack.size());
+            for (size_t i = 0; i < to_pack.size(); ++i) {
+                const ExchangePlan &sp = st_all ? (*pl_all)[(int)(to_pack[i] - &(*st_all)[0])][g] : p;
+                int rc = pack_group_alloc(c, sp, nranks, packs[g][i]); if (rc) return rc;
+            }
+        }
         // the pool hands out blocks whose previous user may still be running on the main stream: order the
         // transfer after everything launched there so far (that is the work of group g-2 and earlier)
         hipEvent_t fence = ev_get(c);
@@ -50,6 +64,7 @@ struct GroupFeeder {
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, fence, 0));
         ev_put(c, fence);
         hipStream_t s = c->comm_stream;
+        for (size_t i = 0; i < to_pack.size(); ++i) { int rc = pack_group_launch(c, *to_pack[i], packs[g][i], s); if (rc) return rc; to_pack[i]->group_packed[g] = 1; }
         if (st_all) {
             for (int src = 0; src < nranks; ++src) {
                 const ExchangePlan &sp = (*pl_all)[src][g]; const SupermerStore &ss = (*st_all)[src];
@@ -85,6 +100,8 @@ struct GroupFeeder {
     {
         for (; released < g && released < posted; ++released) {
             xb[released].release(c->pool);         // next user is ordered after the readers by post()'s fence (or is on the main stream)
+            for (auto &pj : packs[released]) expand_release(c, pj.x);
+            packs[released].clear();
             if (arrived[released]) { ev_put(c, arrived[released]); arrived[released] = nullptr; }
         }
     }
@@ -613,7 +630,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     GroupFeeder feeder; bool fed = false;
     pt.begin(PH_EXCH);
     if (nranks > 1) {
-        int rc = pack_store_bytes(c, st, x_src); if (rc) return rc;
+        int rc = pack_store_bytes(c, st, x_src, !overlap_enabled()); if (rc) return rc;
         if (overlap_enabled()) {
             // size matrix: every rank contributes its row, the sum is the full matrix
             std::vector<u64> M((size_t)nranks * ntasks * 3, 0);
@@ -621,7 +638,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             rc = c->comm.allreduce_sum_u64(M.data(), M.size(), c->stream, c->pool);
             if (rc) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", rc, c->comm.last_error.c_str());
             rc = feeder.plan(c, nranks, rank, ntasks, owner, order, M, st.task_base, segs); if (rc) return rc;
-            feeder.st = &st; fed = true;
+            feeder.st = &st; feeder.lazy_pack = true; fed = true;
         } else {
             rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
                                     st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
@@ -760,7 +777,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr);
         parse_release(c, jobs[r]);
         if (rc) { release_jobs(); return rc; }
-        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos)); if (rc) { release_jobs(); return rc; }
+        rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos), !overlap_enabled()); if (rc) { release_jobs(); return rc; }
         for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
     }
     // 2b. the k-mer lists of the heavy tasks go to their owners (device copies here, send/recv in run_pipeline)
@@ -793,7 +810,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         for (int d = 0; d < R; ++d) { int rc = fd[d].plan(c, R, d, ntasks, owner, order, M, st[d].task_base, segs[d]); if (rc) return rc; pl_all[d] = fd[d].pl; }
         int rc_all = HSK_OK;
         for (int r = 0; r < R && rc_all == HSK_OK; ++r) {
-            fd[r].st_all = &st; fd[r].pl_all = &pl_all;
+            fd[r].st_all = &st; fd[r].pl_all = &pl_all; fd[r].lazy_pack = true;
             memset(&outs[r], 0, sizeof(hsk_result));
             ResultPriv *rp = new ResultPriv();
             outs[r].priv = rp; outs[r].nw = NW; outs[r].ntasks = (int32_t)ntasks;
