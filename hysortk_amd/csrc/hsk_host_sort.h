@@ -42,6 +42,13 @@ template <int NW> static bool prefix_plan_ok(int K, bool finish_follows)
     return hybrid_enabled() && (NW == 1 || (NW == 2 && finish_follows && K - 32 >= 8));
 }
 
+// tasks of 2^30 keys and more use 64-bit look-back words; HSK_WIDE_LOOKBACK=1 forces them (tests: such tasks do not fit a test)
+static bool force_wide_lookback()
+{
+    static const bool on = getenv("HSK_WIDE_LOOKBACK") && atoi(getenv("HSK_WIDE_LOOKBACK")) != 0;
+    return on;
+}
+
 struct SortScratch {
     u64 *ghist = nullptr;      // [MAX_PASSES][256]
     u64 *gbase = nullptr;      // [MAX_PASSES][256]
@@ -90,7 +97,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
     HIPCHK(c, hipMemcpyAsync(sc.gbase, hb, (size_t)h.npass * 256 * 8, hipMemcpyHostToDevice, c->stream));
     constexpr int TILE = SortTile<NW>::TILE;
     const u32 ntiles = (u32)((n + TILE - 1) / TILE);
-    const bool wide = n >= (1ULL << 30);
+    const bool wide = n >= (1ULL << 30) || force_wide_lookback();
     const size_t lbw = wide ? 8 : 4;
     const size_t need = (size_t)todo.size() * ntiles * 256 * lbw;
     if (need > sc.lookback_bytes) {
@@ -179,7 +186,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     PassDesc plan[MAX_PASSES];
     const bool hybrid = prefix_plan_ok<NW>(K, finish_follows);
     const int npass = batch_pass_plan<NW>(c, K, finish_follows, prefix_bits, plan);
-    u64 ntot = 0; bool wide = false;
+    u64 ntot = 0; bool wide = force_wide_lookback();
     for (int i = 0; i < XCD_BATCH; ++i) {
         bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
         ntot += bt[i].n; if (bt[i].n >= (1ULL << 30)) wide = true;
