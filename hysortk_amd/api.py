@@ -397,6 +397,19 @@ class Context:
     def synth_free(self, dp, do, dl):
         self.lib.hsk_synth_free(self.h, dp, do, dl)
 
+    def format_entries(self, kmers, cnt):
+        """The "KMER\\tcount\\n" lines of the entries, formatted on the GPU (hsk_format_entries); returns bytes."""
+        n = len(cnt)
+        if n == 0:
+            return b""
+        nw = kmers.shape[1]
+        e = np.ascontiguousarray(np.concatenate([kmers.astype(np.uint64), np.asarray(cnt, dtype=np.uint64)[:, None]], axis=1))
+        need = C.c_uint64()
+        self._check(self.lib.hsk_format_entries(self.h, _p(e), n, nw, 0, None, 0, C.byref(need)))
+        buf = np.zeros(int(need.value), dtype=np.uint8)
+        self._check(self.lib.hsk_format_entries(self.h, _p(e), n, nw, 0, _p(buf), buf.size, C.byref(need)))
+        return buf.tobytes()
+
     def d2h(self, dptr, nbytes):
         out = np.zeros(nbytes, dtype=np.uint8)
         self._check(self.lib.hsk_memcpy_d2h(self.h, _p(out), dptr, nbytes))
@@ -581,14 +594,18 @@ def print_kmer_histogram(kmerlist, comm=None, file=None):
         comm.barrier()
 
 
-def write_output_file(kmerlist, output_dir, comm=None):
-    """<output_dir>/<rank>.out with lines "KMER\\tcount" (reference src/hysortk.cpp:138-164)."""
+def write_output_file(kmerlist, output_dir, comm=None, ctx=None):
+    """<output_dir>/<rank>.out with lines "KMER\\tcount" (reference src/hysortk.cpp:138-164).  With a Context the text is
+    formatted on the GPU (hsk_format_entries): spelling 10^8 k-mers on the host takes longer than counting them."""
     rank = 0 if comm is None else comm.rank
     fname = os.path.join(output_dir, "%d.out" % rank)
     try:
-        f = open(fname, "w")
+        f = open(fname, "wb")
     except OSError:
         raise HskError(1, "cannot open output file " + fname)
     with f:
-        strs = kmerlist.strings()
-        f.write("".join("%s\t%d\n" % (s, int(c)) for s, c in zip(strs, kmerlist.cnt)))
+        if ctx is not None:
+            f.write(ctx.format_entries(kmerlist.kmers, kmerlist.cnt))
+        else:
+            strs = kmerlist.strings()
+            f.write("".join("%s\t%d\n" % (s, int(c)) for s, c in zip(strs, kmerlist.cnt)).encode())

@@ -644,6 +644,37 @@ extern "C" int hsk_pack_fasta(hsk_ctx *c, const char *text, uint64_t text_bytes,
     return HSK_OK;
 }
 
+extern "C" int hsk_format_entries(hsk_ctx *c, const void *entries, uint64_t n, int32_t nw, int32_t on_device, char *text, uint64_t capacity, uint64_t *nbytes)
+{
+    if (!c || !nbytes || (n && !entries) || nw < 1 || nw > 3 || nw != c->nw) return HSK_ERR_INVALID_ARG;
+    *nbytes = 0;
+    if (n == 0) return HSK_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t eb = (size_t)n * (nw + 1) * 8;
+    u64 *d_e = (u64 *)entries, *d_own = nullptr;
+    if (!on_device) { DALLOC(c, d_own, u64 *, eb); HIPCHK(c, hipMemcpyAsync(d_own, entries, eb, hipMemcpyHostToDevice, c->stream)); d_e = d_own; }
+    const u64 ntiles = (n + FMT_THREADS - 1) / FMT_THREADS;
+    u64 *d_tile, *d_total;
+    DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
+    hipLaunchKernelGGL(format_entries_kernel<false>, dim3((u32)ntiles), dim3(FMT_THREADS), 0, c->stream, d_e, n, nw, c->cfg.kmer_size, d_tile, (char *)nullptr);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nbytes = tot[0];
+    int rc = HSK_OK;
+    if (text && capacity >= tot[0]) {
+        char *d_text; DALLOC(c, d_text, char *, tot[0] + 64);
+        hipLaunchKernelGGL(format_entries_kernel<true>, dim3((u32)ntiles), dim3(FMT_THREADS), 0, c->stream, d_e, n, nw, c->cfg.kmer_size, d_tile, d_text);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(text, d_text, tot[0], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->pool.release(d_text);
+    } else if (text || capacity) rc = fail(c, HSK_ERR_INVALID_ARG, "text capacity %llu < %llu", (unsigned long long)capacity, (unsigned long long)tot[0]);
+    c->pool.release(d_tile); c->pool.release(d_total); c->pool.release(d_own);
+    return rc;
+}
+
 extern "C" int hsk_synth_free(hsk_ctx *c, void *d_packed, void *d_off, void *d_len)
 {
     if (!c) return HSK_ERR_INVALID_ARG;

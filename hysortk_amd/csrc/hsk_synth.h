@@ -102,4 +102,35 @@ __global__ void pack_fasta_offsets_kernel(const u32 *rec_len, u64 nrec, u64 *rof
     if (threadIdx.x == 0) roff[nrec] = s_carry;
 }
 
+// ---- result egress: entries -> the lines write_output_file prints (reference src/hysortk.cpp:138-164: "KMERSTRING\tcount\n",
+//      the k-mer spelled by Kmer::GetString, include/kmer.hpp:76).  Two launches around a scan of the tile sizes:
+//      line lengths (K + 2 + decimal digits of the count), then every lane writes its own line. --------------------------------
+constexpr int FMT_THREADS = 256;
+
+__device__ __forceinline__ u32 dec_digits(u64 v) { u32 d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+
+// tile_bytes[tile] = text bytes of the tile's entries (COUNT) / exclusive offsets (EMIT, after the scan)
+template <bool EMIT>
+__global__ __launch_bounds__(FMT_THREADS) void format_entries_kernel(const u64 *entries, u64 n, int nw, int k, u64 *tile_bytes, char *text)
+{
+    __shared__ u64 s_scr[8];
+    const u64 e = (u64)blockIdx.x * FMT_THREADS + threadIdx.x;
+    u64 cnt = 0; u32 len = 0;
+    if (e < n) { cnt = entries[e * (nw + 1) + nw]; len = (u32)k + 2 + dec_digits(cnt); }
+    u64 tot;
+    const u64 off = block_excl_scan_256<u64>((u64)len, s_scr, &tot);
+    if (!EMIT) { if (threadIdx.x == 0) tile_bytes[blockIdx.x] = tot; return; }
+    if (e >= n) return;
+    char *o = text + tile_bytes[blockIdx.x] + off;
+    for (int j = 0; j < k; ++j) {
+        const u64 w = entries[e * (nw + 1) + (j >> 5)];
+        o[j] = "ACGT"[(w >> (2 * (31 - (j & 31)))) & 3];
+    }
+    o[k] = '\t';
+    const u32 nd = len - (u32)k - 2;
+    u64 v = cnt;
+    for (u32 d = 0; d < nd; ++d) { o[k + nd - d] = (char)('0' + (int)(v % 10)); v /= 10; }
+    o[k + 1 + nd] = '\n';
+}
+
 } // namespace hsk

@@ -165,6 +165,11 @@ void hsk_result_free(hsk_ctx *ctx, hsk_result *res);
  * them in place; the memory belongs to the result. */
 int hsk_result_device_task(const hsk_result *res, int32_t task, const void **entries, uint64_t *n,
                            const void **payload_off, const void **pos, const void **rid, uint64_t *npay, uint64_t *payload_base);
+/* Result egress (write_output_file, reference src/hysortk.cpp:138-164): the lines "KMERSTRING\tcount\n" of `n` entries
+ * ((nw + 1)-word records: host memory, or device memory when `on_device`), formatted on the GPU into `text` (host, capacity
+ * bytes); *nbytes = bytes needed (call with capacity 0 to size the buffer: K + 2 + up to 20 digits per entry). */
+int hsk_format_entries(hsk_ctx *ctx, const void *entries, uint64_t n, int32_t nw, int32_t on_device,
+                       char *text, uint64_t capacity, uint64_t *nbytes);
 int  hsk_get_stats(hsk_ctx *ctx, hsk_stats *out, int reset);
 
 /* ---- stage entry points (each one is a reference function of SURVEY 8a; used by the parity

@@ -575,3 +575,22 @@ def test_random_configurations_vs_oracle(H, O, seed):
             pos, rid = res.payload(i)
             a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
             assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
+
+
+@pytest.mark.parametrize("K", [31, 51, 77])
+def test_output_text_formatted_on_device(H, O, K, tmp_path):
+    """hsk_format_entries: the "KMER\\tcount" lines of write_output_file (reference src/hysortk.cpp:138-164) formatted on the GPU
+    equal the host formatter byte for byte (one, two and three key words; counts of one to five digits)."""
+    from hysortk_amd import synth
+    seqs = list(synth.reads(60000, 150, 3000, 41)) + ["ACGT" * 40] * 1200 + [("ACGGTCATTGCA" * 13)[:150]] * 2000
+    dna = H.DnaBuffer.from_sequences(seqs)
+    with H.Context(K=K, M=17, L=1, U=65535, ntasks=5) as c:
+        kl = c.count(dna)
+        assert int(kl.cnt.max()) >= 10000 and int(kl.cnt.min()) == 1
+        (tmp_path / "g").mkdir(); (tmp_path / "h").mkdir()
+        H.write_output_file(kl, str(tmp_path / "g"), ctx=c)
+        H.write_output_file(kl, str(tmp_path / "h"))
+        assert c.format_entries(kl.kmers[:0], kl.cnt[:0]) == b""
+    g = open(tmp_path / "g" / "0.out", "rb").read()
+    h = open(tmp_path / "h" / "0.out", "rb").read()
+    assert g == h and g.count(b"\n") == len(kl)
