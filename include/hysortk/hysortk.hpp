@@ -186,9 +186,21 @@ inline void print_kmer_histogram(const KmerListS &kmerlist, MPI_Comm comm)
 inline void write_output_file(const KmerListS &kmerlist, const std::string &output_dir, MPI_Comm comm)
 {
     const std::string fname = output_dir + "/" + std::to_string(detail::ranks_of(comm).rank) + ".out";
-    std::ofstream ofs(fname);
+    std::ofstream ofs(fname, std::ios::binary);
     if (!ofs) throw std::runtime_error("Error: cannot open output file " + fname);
+#if EXTENSION == 0
+    // {TKmer, uint64_t} records are the C ABI's entry layout: the lines are spelled on the GPU (hsk_format_entries)
+    if (!kmerlist.empty()) {
+        hsk_ctx *ctx = detail::context(comm);
+        uint64_t need = 0;
+        detail::check(hsk_format_entries(ctx, kmerlist.data(), kmerlist.size(), (KMER_SIZE + 31) / 32, 0, nullptr, 0, &need), ctx, "hsk_format_entries");
+        std::string text(static_cast<size_t>(need), '\0');
+        detail::check(hsk_format_entries(ctx, kmerlist.data(), kmerlist.size(), (KMER_SIZE + 31) / 32, 0, &text[0], need, &need), ctx, "hsk_format_entries");
+        ofs.write(text.data(), static_cast<std::streamsize>(text.size()));
+    }
+#else
     for (const auto &e : kmerlist) ofs << e.kmer << "\t" << e.cnt << "\n";
+#endif
 }
 
 } // namespace hysortk
