@@ -697,6 +697,7 @@ extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
     memset(out, 0, sizeof(unsigned long long) * n);
 #ifdef HSK_DIAG
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_diag), sizeof(unsigned long long) * n) != hipSuccess) return HSK_ERR_HIP;
+    if (n >= 32) { if (hipMemcpyFromSymbol(out + 20, HIP_SYMBOL(hsk::g_scan_diag), sizeof(unsigned long long) * 10) != hipSuccess) return HSK_ERR_HIP; }
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hsk::g_diag), z, sizeof z) != hipSuccess) return HSK_ERR_HIP; }
 #else
     (void)reset;

@@ -458,6 +458,9 @@ constexpr u32 PLACE_MAX_REC = 8192;                   // records of one placemen
 constexpr int SCAN_HSTRIDE = PARSE_THREADS + 16;      // 256 lanes + 12 lanes' worth of positions behind the tile
 __device__ __forceinline__ int scan_hidx(int p) { return (p & 7) * SCAN_HSTRIDE + (p >> 3); }
 
+#ifdef HSK_DIAG
+__device__ unsigned long long g_scan_diag[16];
+#endif
 __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
@@ -482,11 +485,18 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     const u64 RINF = ~0ULL >> 2;
     const int p0 = tid * PARSE_PPT;
 
+#ifdef HSK_DIAG
+    unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
         const u64 tile = tile0 + ti;
         if (tile >= a.ntiles) break;
         const u64 gbase = tile * PARSE_TILE;
         const u64 bbase = gbase >> 2;
+#ifdef HSK_DIAG
+        unsigned long long sd[6];
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[0] = t_; }
+#endif
 
         // ---- 1. stage bytes (big-endian words), read index window (as parse_kernel) -----------------------
         {
@@ -523,6 +533,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
         }
         __syncthreads();
+#ifdef HSK_DIAG
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[1] = t_; }
+#endif
 
         // ---- 2. canonical m-mer hashes of this lane's 8 positions (rolled), kept in registers -------------
         u64 h[PARSE_PPT];
@@ -547,6 +560,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
         }
         __syncthreads();
+#ifdef HSK_DIAG
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[2] = t_; }
+#endif
 
         // ---- 3. window minima (shared middle), validity --------------------------------------------------
         u64 mn[PARSE_PPT];
@@ -605,6 +621,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         s_last[tid] = mn[PARSE_PPT - 1];
         s_v8[tid] = (u8)vmask;
         __syncthreads();
+#ifdef HSK_DIAG
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[3] = t_; }
+#endif
 
         // ---- 4. boundaries, supermer starts, compaction ---------------------------------------------------
         u32 start8 = 0;
@@ -629,6 +648,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         for (int i = 0; i < PARSE_PPT; ++i)
             if ((start8 >> i) & 1) { s_hash[off] = mn[i]; s_plist[off] = (u16)(p0 + i); ++off; }
         __syncthreads();
+#ifdef HSK_DIAG
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[4] = t_; }
+#endif
 
         // ---- 5. one lane per supermer: task, run length, counters, record ----------------------------------
         {
@@ -653,7 +675,16 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
         }
         __syncthreads();
+#ifdef HSK_DIAG
+        if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[5] = t_; }
+#endif
+#ifdef HSK_DIAG
+        if (tid == 0) { for (int q = 0; q < 5; ++q) dacc[q] += sd[q + 1] - sd[q]; dacc[5] += 1; }
+#endif
     }
+#ifdef HSK_DIAG
+    if (tid == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_scan_diag[q], dacc[q]); atomicAdd(&g_scan_diag[8], dacc[5]); }
+#endif
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
         u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
         const u64 pk = s_cur[2 * t];

@@ -21,3 +21,9 @@ with H.Context(K=31, M=17, L=15, U=40, keep_device=True) as c:
     for i, nm in enumerate(names):
         print("  %-24s %8.0f cyc  %5.1f%%" % (nm, out[i] / max(out[16], 1), 100.0 * out[i] / tot))
     print("  look-back per tile (digit 0): window steps %.2f, not-ready retries %.2f, depth %.1f tiles" % (out[10] / out[16], out[11] / out[16], out[12] / out[16]))
+    sn = ["stage + index probe", "hash", "window min + validity", "boundaries + compaction", "dense (task, run, record)"]
+    st = sum(out[20 + i] for i in range(5))
+    if out[28]:
+        print("scan_kernel tiles", out[28], "avg clocks per tile", st / out[28])
+        for i, nm in enumerate(sn):
+            print("  %-28s %8.0f  %5.1f%%" % (nm, out[20 + i] / out[28], 100.0 * out[20 + i] / st))
