@@ -124,7 +124,7 @@ def test_rccl_binding_selftest():
         c.comm_selftest()
 
 
-@pytest.mark.parametrize("R,ntasks", [(2, 24), (3, 24), (4, 32)])
+@pytest.mark.parametrize("R,ntasks", [(2, 24), (3, 24), (4, 32), (2, 56), (8, 128)])
 def test_loopback_heavy_hitter_tasks(R, ntasks):
     """A tandem repeat makes a few tasks several times larger than the mean: they are classified as heavy hitters
     (reference HeavyHitterClassifier, kmerops.cpp:1157), every rank pre-aggregates its share into (k-mer, count) lists, the
