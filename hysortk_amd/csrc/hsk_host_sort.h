@@ -49,6 +49,14 @@ static bool force_wide_lookback()
     return on;
 }
 
+// The first of several prefix passes need not be stable when an aggregation (which only needs the records GROUPED by the
+// prefix) follows: its ranking is then a single LDS atomic per key.  HSK_UNSTABLE_FIRST=0 keeps it stable.
+static bool unstable_first_pass()
+{
+    static const bool on = !(getenv("HSK_UNSTABLE_FIRST") && atoi(getenv("HSK_UNSTABLE_FIRST")) == 0);
+    return on;
+}
+
 struct SortScratch {
     u64 *ghist = nullptr;      // [MAX_PASSES][256]
     u64 *gbase = nullptr;      // [MAX_PASSES][256]
@@ -239,6 +247,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
                 SortArgs &a = m.t[i];
                 a.keys_in = kin[i]; a.keys_out = kout[i]; a.vals_in = vin[i]; a.vals_out = vout[i]; a.n = bt[i].n; a.ntiles = ntiles[i];
                 a.word = plan[p].word; a.shift = plan[p].shift; a.bits = plan[p].bits;
+                a.unstable = (hybrid && finish_follows && j == 0 && todo.size() > 1 && unstable_first_pass()) ? 1 : 0;
                 a.gbase = d_gbase + ((size_t)i * MAX_PASSES + p) * 256;
                 a.lookback = (char *)d_lookback + j * per_pass + lb_off[i];
                 a.ticket = d_tickets + (size_t)i * MAX_PASSES + j; a.err = c->d_err;

@@ -74,6 +74,7 @@ struct SortArgs {
     u64 n;
     u64 ntiles;           // tiles of this task and pass
     int word, shift, bits;
+    int unstable;         // 1: equal digits may leave in any order (first pass of a prefix plan that ends in an aggregation)
     const u64 *gbase;     // [256] exclusive digit offsets of this pass
     void *lookback;       // [ntiles][256] LB words, zeroed
     u32 *ticket;          // zeroed
@@ -156,6 +157,10 @@ __device__ __forceinline__ void onesweep_tile(const SortArgs &a)
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const u32 d = dig[j];
+        if (a.unstable) {                            // (uniform) one LDS atomic: the rank is the arrival order inside the wave
+            rank[j] = __hip_atomic_fetch_add(&wh[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            continue;
+        }
         __hip_atomic_fetch_or(&wm[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const u64 peers = __hip_atomic_load(&wm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
