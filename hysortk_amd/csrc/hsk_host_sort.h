@@ -341,7 +341,7 @@ static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
     for (int i = 0; i < nb; ++i) {
         SortArgs &a = ta[i]; memset(&a, 0, sizeof a);
         a.keys_in = bt[i].kA; a.keys_out = bt[i].kB; a.vals_in = nullptr; a.vals_out = nullptr; a.n = bt[i].n; a.ntiles = ntiles[i];
-        a.word = NW - 1; a.shift = 56; a.bits = 8;
+        a.word = NW - 1; a.shift = 56; a.bits = 8; a.unstable = unstable_first_pass() ? 1 : 0;      // a single pass before an aggregation
         a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lb + lb_off[i]; a.ticket = d_tk + i; a.err = c->d_err;
     }
     HIPCHK(c, hipMemcpyAsync(d_tasks, ta.data(), sizeof(SortArgs) * nb, hipMemcpyHostToDevice, c->stream));
