@@ -157,6 +157,8 @@ struct ExpandTask {
     const u64 *tile_off; u64 ntiles;
     u64 *keys_out, *vals_out;
     u64 *ghist;                    // [npass][256] digit histograms of this task (null: none)
+    u64 *kcursor;                  // tile_off == null (bases read in place, one segment): next free record of the task's key array;
+                                   // a tile reserves its range with one atomic (the order of the k-mers inside a task is free)
 };
 struct ExpandArgs { ExpandTask t[EXP_BATCH]; int ntask, k; u32 row_workers; int npass; u64 nrows; PassDesc pass[MAX_PASSES]; };
 
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
     __shared__ u16 s_isup[EXP_MAX_ITEMS];
     __shared__ u64 s_gpos[EXP_TILE];                                  // first base of every supermer of the tile (reference mode)
     __shared__ u32 s_scr[8];
+    __shared__ u64 s_kb;
     extern __shared__ __attribute__((aligned(16))) u32 s_hist[];       // [npass][256]
     const int tid = threadIdx.x;
     const u32 xcd = blockIdx.x & 7u, wk = blockIdx.x >> 3;
@@ -217,8 +220,13 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
         if (tid == EXP_THREADS - 1) { s_boff[EXP_TILE] = eb; s_koff[EXP_TILE] = ek; s_ioff[EXP_TILE] = ei; }
         __syncthreads();
 
-        const u64 byte_abs = t.tile_off[2 * tile];
-        const u64 kbase = t.tile_off[2 * tile + 1];
+        u64 byte_abs = 0, kbase;
+        if (t.tile_off) { byte_abs = t.tile_off[2 * tile]; kbase = t.tile_off[2 * tile + 1]; }
+        else {
+            if (tid == 0) s_kb = atomicAdd((unsigned long long *)t.kcursor, (unsigned long long)totk);
+            __syncthreads();
+            kbase = s_kb;
+        }
 
         // The window of step s+1 is requested before step s is computed (two dependent memory latencies per step
         // -- item -> position -> bases -- would otherwise sit in front of every 8 rounds of arithmetic).

@@ -12,11 +12,12 @@ static void finalize_segs(TaskSegs &ts)
     ts.ntiles = tile;
 }
 
-struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr; };
+struct ExpandScratch { ExpSeg *d_segs = nullptr; u64 *d_tile_sum = nullptr, *d_tile_off = nullptr, *d_cursor = nullptr; };
 
 // tile sums + scans of n <= EXP_PREP_BATCH tasks with two launches
+// offsets = false: only the segment lists are uploaded (tiles then reserve their output ranges themselves)
 static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, const u8 *const *sm_len, ExpandScratch *x,
-                                hipStream_t stream = nullptr, bool prealloc = false)
+                                hipStream_t stream = nullptr, bool prealloc = false, bool offsets = true)
 {
     if (!stream) stream = c->stream;
     ExpandPrepArgs pa; memset(&pa, 0, sizeof pa);
@@ -26,15 +27,14 @@ static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, co
         const int nseg = (int)ts[i]->segs.size();
         if (!prealloc) {
             DALLOC(c, x[i].d_segs, ExpSeg *, sizeof(ExpSeg) * nseg);
-            DALLOC(c, x[i].d_tile_sum, u64 *, ts[i]->ntiles * 16);
-            DALLOC(c, x[i].d_tile_off, u64 *, ts[i]->ntiles * 16);
+            if (offsets) { DALLOC(c, x[i].d_tile_sum, u64 *, ts[i]->ntiles * 16); DALLOC(c, x[i].d_tile_off, u64 *, ts[i]->ntiles * 16); }
         }
         HIPCHK(c, hipMemcpyAsync(x[i].d_segs, ts[i]->segs.data(), sizeof(ExpSeg) * nseg, hipMemcpyHostToDevice, stream));
         pa.segs[i] = x[i].d_segs; pa.nseg[i] = nseg; pa.sm_len[i] = sm_len[i]; pa.ntiles[i] = ts[i]->ntiles;
         pa.tile_sum[i] = x[i].d_tile_sum; pa.tile_off[i] = x[i].d_tile_off;
         max_tiles = std::max(max_tiles, ts[i]->ntiles); max_seg = std::max(max_seg, nseg);
     }
-    if (max_tiles == 0) return HSK_OK;
+    if (max_tiles == 0 || !offsets) return HSK_OK;
     hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)max_tiles, n), dim3(EXP_THREADS), 0, stream, pa);
     hipLaunchKernelGGL(expand_scan_kernel, dim3(max_seg, n), dim3(EXP_THREADS), 0, stream, pa);
     return HSK_OK;
@@ -44,7 +44,7 @@ static int expand_prepare(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, Expa
     const TaskSegs *tp = &ts;
     return expand_prepare_batch(c, 1, &tp, &sm_len, &x);
 }
-static void expand_release(hsk_ctx *c, ExpandScratch &x) { c->pool.release(x.d_segs); c->pool.release(x.d_tile_sum); c->pool.release(x.d_tile_off); x = ExpandScratch(); }
+static void expand_release(hsk_ctx *c, ExpandScratch &x) { c->pool.release(x.d_segs); c->pool.release(x.d_tile_sum); c->pool.release(x.d_tile_off); c->pool.release(x.d_cursor); x = ExpandScratch(); }
 
 // One launch for up to EXP_BATCH tasks (hsk_expand.h).  ghist[i] (optional) receives the digit histograms of
 // the `npass` radix passes in `plan` for task i.
@@ -60,11 +60,22 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
     ExpandScratch xown[EXP_BATCH];
     ExpandScratch *x = pre ? pre : xown;
     int nt = 0; u64 max_tiles = 0;
+    static const bool reserve_enabled = !(getenv("HSK_EXPAND_RESERVE") && atoi(getenv("HSK_EXPAND_RESERVE")) == 0);
+    bool reserve = true;
     {
         const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH]; int m = 0;
         for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles) { tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; ++m; }
         // (ts.segs is host memory owned by the caller and stays alive until the next sync)
-        int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, pre != nullptr); if (rc) return rc;
+        // bases read in place (one GPU, one segment per task): no tile sums, a tile takes its output range with an atomic
+        for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles && (!jobs[i].src.gpos || jobs[i].ts->segs.size() != 1)) reserve = false;
+        if (!reserve_enabled) reserve = false;
+        int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, pre != nullptr, !reserve); if (rc) return rc;
+    }
+    u64 *d_kcur = nullptr;
+    if (reserve) {
+        d_kcur = pre ? pre[0].d_cursor : (u64 *)c->pool.alloc(256);
+        if (!d_kcur) return fail(c, HSK_ERR_OOM, "expand cursors");
+        HIPCHK(c, hipMemsetAsync(d_kcur, 0, EXP_BATCH * 8, stream));
     }
     for (int i = 0; i < njobs; ++i) {
         const ExpandJob &j = jobs[i];
@@ -72,7 +83,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
         ExpandTask &t = a.t[nt];
         t.segs = x[nt].d_segs; t.nseg = (int)j.ts->segs.size(); t.sm_len = j.sm_len;
         t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos; t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid;
-        t.tile_off = x[nt].d_tile_off; t.ntiles = j.ts->ntiles; t.keys_out = j.keys; t.vals_out = j.vals; t.ghist = npass ? j.ghist : nullptr;
+        t.tile_off = reserve ? nullptr : x[nt].d_tile_off; t.kcursor = reserve ? d_kcur + nt : nullptr; t.ntiles = j.ts->ntiles; t.keys_out = j.keys; t.vals_out = j.vals; t.ghist = npass ? j.ghist : nullptr;
         max_tiles = std::max(max_tiles, t.ntiles);
         ++nt;
     }
@@ -100,7 +111,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
     if (ext) hipLaunchKernelGGL((expand_kernel<NW, true>), dim3(grid), dim3(EXP_THREADS), dyn, stream, a);
     else hipLaunchKernelGGL((expand_kernel<NW, false>), dim3(grid), dim3(EXP_THREADS), dyn, stream, a);
     HIPCHK(c, hipGetLastError());
-    if (!pre) for (int i = 0; i < nt; ++i) expand_release(c, x[i]);
+    if (!pre) { for (int i = 0; i < nt; ++i) expand_release(c, x[i]); c->pool.release(d_kcur); }
     return HSK_OK;
 }
 

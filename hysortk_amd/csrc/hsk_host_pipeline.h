@@ -301,6 +301,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 DALLOC(c, xpre[sl][i].d_segs, ExpSeg *, sizeof(ExpSeg) * max_seg);
                 DALLOC(c, xpre[sl][i].d_tile_sum, u64 *, max_tiles * 16 + 64);
                 DALLOC(c, xpre[sl][i].d_tile_off, u64 *, max_tiles * 16 + 64);
+                if (i == 0) DALLOC(c, xpre[sl][i].d_cursor, u64 *, 256);
             }
             ev_ready[sl] = ev_get(c); ev_done[sl] = ev_get(c);
         }
