@@ -28,6 +28,7 @@
 #include "hsk_parse.h"
 #include "hsk_expand.h"
 #include "hsk_sort.h"
+#include "hsk_scatter.h"
 #include "hsk_count.h"
 #include "hsk_finish.h"
 #include "hsk_agg.h"
@@ -83,8 +84,23 @@ static int validate_cfg(const hsk_config *cfg)
     return 1;
 }
 
+// HSK_BACKTRACE=1 (diagnostic): print the native stack when the process is aborted (a runtime that gives up on a queue
+// error calls abort() without saying where from)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void backtrace_on_abort(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
 {
+    if (getenv("HSK_BACKTRACE") && atoi(getenv("HSK_BACKTRACE")) != 0) { signal(SIGABRT, backtrace_on_abort); signal(SIGSEGV, backtrace_on_abort); }
     if (!cfg || !out) return HSK_ERR_INVALID_ARG;
     *out = nullptr;
     if (!validate_cfg(cfg)) return HSK_ERR_INVALID_ARG;
@@ -154,6 +170,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 #include "hsk_host_parse.h"
 #include "hsk_host_expand.h"
 #include "hsk_host_sort.h"
+#include "hsk_host_scatter.h"
 #include "hsk_host_finish.h"
 #include "hsk_host_pipeline.h"
 
@@ -698,6 +715,12 @@ extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
 #ifdef HSK_DIAG
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_diag), sizeof(unsigned long long) * n) != hipSuccess) return HSK_ERR_HIP;
     if (n >= 32) { if (hipMemcpyFromSymbol(out + 20, HIP_SYMBOL(hsk::g_scan_diag), sizeof(unsigned long long) * 10) != hipSuccess) return HSK_ERR_HIP; }
+    if (reset & 2) {                                            // the fused expand + scatter kernel's stamps instead
+        unsigned long long z[16] = {0};
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_xs_diag), sizeof(unsigned long long) * (n < 16 ? n : 16)) != hipSuccess) return HSK_ERR_HIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hsk::g_xs_diag), z, sizeof z) != hipSuccess) return HSK_ERR_HIP;
+        return HSK_OK;
+    }
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hsk::g_diag), z, sizeof z) != hipSuccess) return HSK_ERR_HIP; }
 #else
     (void)reset;

@@ -277,12 +277,17 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     static const bool pipe_enabled = getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) != 0;
     const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = piped ? 2 : 1;
+    // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
+    const bool xs = batch && !piped && !ext && NW == 1 && scatter_enabled() && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    ScatterBatch sbatch;
+    PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
     u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
     SortScratch sc;
     if (max_task) {
         for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
-            DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64); DALLOC(c, kBs[sl][i], u64 *, max_task * NW * 8 + 64);
+            DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
+            DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task) : max_task * NW) * 8 + 64);   // xs: the chunk store of the first pass
             if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, max_task * 8 + 64); }
         }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
@@ -344,7 +349,14 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             jobs[i].ts = &segs[t]; jobs[i].sm_len = in.len; jobs[i].src = in.src; jobs[i].sm_pos = in.pos; jobs[i].sm_rid = in.rid;
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
         }
-        int rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc;
+        int rc;
+        if (xs && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
+            if constexpr (NW == 1) {
+                for (int i = 0; i < XCD_BATCH; ++i) jobs[i].keys = bts[sl][i].kB;
+                memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
+                rc = scatter_expand_batch(c, jobs, bts[sl], plan, sbatch, xstream); if (rc) return rc;
+            }
+        } else { rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc; }
         pt.end(PH_EXTRACT, xstream);
         if (piped) HIPCHK(c, hipEventRecord(ev_ready[sl], xstream));
         return HSK_OK;
@@ -368,7 +380,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
-        { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
+        if (sbatch.active) { if constexpr (NW == 1) { int rc = sort_batch_prescattered(c, bt, xs_plan, d_ghist_slot[sl], sbatch); if (rc) return rc; } }
+        else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         if (fused_ext) {

@@ -1,0 +1,154 @@
+// hsk_host_scatter.h -- host side of the expand fused with the first scatter pass (kernels: hsk_scatter.h).
+// Part of the single translation unit hsk_api.hip (included in this order; everything here is file-local).
+#pragma once
+
+// device state of one batch between expand_scatter_kernel and the second pass
+struct ScatterBatch {
+    ScatterArgs args;
+    u64 *d_cursor = nullptr;                     // [XCD_BATCH][256]
+    u32 *d_ctl = nullptr;                        // [XCD_BATCH][4]
+    u32 *d_map[XCD_BATCH] = {nullptr};
+    u64 *d_tile_src[XCD_BATCH] = {nullptr};
+    bool active = false;
+};
+
+#define XS_TRACE(msg) do { if (getenv("HSK_TRACE")) { fprintf(stderr, "[xs] %s\n", msg); fflush(stderr); } } while (0)
+static bool scatter_enabled()
+{
+    static const bool on = !(getenv("HSK_FUSED_SCATTER") && atoi(getenv("HSK_FUSED_SCATTER")) == 0);
+    return on;
+}
+// keys the chunk store of a task of n k-mers must hold (less than one chunk is wasted per digit)
+static size_t scatter_store_keys(u64 n) { return (size_t)(n / XS_CHUNK + 257) * XS_CHUNK; }
+
+static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
+{
+    c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl);
+    for (int i = 0; i < XCD_BATCH; ++i) { c->pool.release(sb.d_map[i]); c->pool.release(sb.d_tile_src[i]); }
+    sb = ScatterBatch();
+}
+
+// jobs[i] is the task XCD i expands (ts->ntiles == 0: none); its keys go to the chunk store jobs[i].keys, the histogram
+// of the second pass's digit to jobs[i].ghist + 256.  plan: the two 8-bit passes of the prefix plan.
+static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTask *bt, const PassDesc *plan, ScatterBatch &sb, hipStream_t stream)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    sb = ScatterBatch();
+    ScatterArgs &a = sb.args; memset(&a, 0, sizeof a);
+    ExpandScratch x[EXP_BATCH]; int xi[EXP_BATCH]; int m = 0;
+    const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH];
+    bool offsets = false;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        xi[i] = -1;
+        if (!jobs[i].ts->ntiles) continue;
+        tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; xi[i] = m++;
+        if (!jobs[i].src.gpos) offsets = true;           // byte streams: a tile's input offset is a prefix over the tiles before it
+    }
+    if (m == 0) return HSK_OK;
+    XS_TRACE("prepare");
+    int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, false, offsets); if (rc) return rc;
+    XS_TRACE("prepared");
+    DALLOC(c, sb.d_cursor, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    DALLOC(c, sb.d_ctl, u32 *, (size_t)XCD_BATCH * 16);
+    HIPCHK(c, hipMemsetAsync(sb.d_cursor, 0, (size_t)XCD_BATCH * 256 * 8, stream));
+    HIPCHK(c, hipMemsetAsync(sb.d_ctl, 0, (size_t)XCD_BATCH * 16, stream));
+    u64 ntot = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        if (xi[i] < 0) continue;
+        const ExpandJob &j = jobs[i];
+        ScatterTask &t = a.t[i];
+        const u64 n = bt[i].n;
+        t.vmax = (u32)(n / XS_CHUNK + 1);
+        DALLOC(c, sb.d_map[i], u32 *, (size_t)256 * t.vmax * 4);
+        DALLOC(c, sb.d_tile_src[i], u64 *, (size_t)(n / XS_CHUNK + 257) * 8);
+        HIPCHK(c, hipMemsetAsync(sb.d_map[i], 0, (size_t)256 * t.vmax * 4, stream));
+        t.segs = x[xi[i]].d_segs; t.nseg = (int)j.ts->segs.size(); t.sm_len = j.sm_len;
+        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos;
+        t.tile_off = offsets ? x[xi[i]].d_tile_off : nullptr; t.ntiles = j.ts->ntiles;
+        t.chunks = j.keys; t.cursor = sb.d_cursor + (size_t)i * 256; t.map = sb.d_map[i]; t.ctl = sb.d_ctl + (size_t)i * 4;
+        t.ghist = j.ghist + 256; t.tile_src = sb.d_tile_src[i];
+        ntot += n;
+    }
+    a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.err = c->d_err;
+    static int occ = 0;
+    if (!occ) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel, XS_THREADS, 0);
+        occ = (e == hipSuccess && nb > 0) ? nb : 2;
+    }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
+    XS_TRACE("launch");
+    hipLaunchKernelGGL(expand_scatter_kernel, dim3((u32)occ * 256u), dim3(XS_THREADS), 0, stream, a);
+    if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
+    HIPCHK(c, hipGetLastError());
+    if (getenv("HSK_TRACE")) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "[xs] kernel done: %d\n", (int)e); fflush(stderr); }
+    for (int i = 0; i < m; ++i) expand_release(c, x[i]);
+    sb.active = true;
+    return HSK_OK;
+}
+
+// Second (stable) pass over a batch whose first pass was done by expand_scatter_kernel: input = the chunk stores bt[i].kB,
+// output = bt[i].kA.  d_ghist: [XCD_BATCH][MAX_PASSES][256], row 1 = the histogram of this pass's digit.
+static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *plan, u64 *d_ghist, ScatterBatch &sb)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = bt[i].kA; bt[i].out_v = nullptr; }
+    if (!sb.active) return HSK_OK;
+    std::vector<u64> hh((size_t)XCD_BATCH * MAX_PASSES * 256), cur((size_t)XCD_BATCH * 256), hb((size_t)XCD_BATCH * 256, 0);
+    HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cur.data(), sb.d_cursor, cur.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    XS_TRACE("cursors read");
+    int rc = check_device_error(c); if (rc) { scatter_release(c, sb); return rc; }
+    u64 ntiles[XCD_BATCH], max_tiles = 0, ntot = 0; bool wide = force_wide_lookback();
+    size_t lb_off[XCD_BATCH + 1]; lb_off[0] = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        ntiles[i] = 0;
+        u64 placed = 0, run = 0;
+        for (int d = 0; d < 256; ++d) {
+            const u64 v = cur[(size_t)i * 256 + d];
+            placed += v; ntiles[i] += (v + XS_CHUNK - 1) / XS_CHUNK;
+            hb[(size_t)i * 256 + d] = run; run += hh[((size_t)i * MAX_PASSES + 1) * 256 + d];
+        }
+        // every XCD must have expanded its task (the kernel picks the task by the XCD it runs on)
+        if (placed != bt[i].n || run != bt[i].n) {
+            scatter_release(c, sb);
+            return fail(c, HSK_ERR_INTERNAL, "XCD %d did not expand its task (%llu of %llu k-mers placed)", i, (unsigned long long)placed, (unsigned long long)bt[i].n);
+        }
+        if (bt[i].n >= (1ULL << 30)) wide = true;
+        max_tiles = std::max(max_tiles, ntiles[i]); ntot += bt[i].n;
+    }
+    const size_t lbw = wide ? 8 : 4;
+    for (int i = 0; i < XCD_BATCH; ++i) lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * lbw;
+    u64 *d_gbase; u32 *d_tickets; void *d_lookback;
+    DALLOC(c, d_gbase, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    DALLOC(c, d_tickets, u32 *, 256);
+    DALLOC(c, d_lookback, void *, lb_off[XCD_BATCH] + 256);
+    HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_tickets, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_lookback, 0, lb_off[XCD_BATCH], c->stream));
+    hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, c->stream, sb.args);
+    MultiSortArgs ms; memset(&ms, 0, sizeof ms);
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        SortArgs &a = ms.t[i];
+        a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.n = bt[i].n; a.ntiles = ntiles[i];
+        a.word = plan[1].word; a.shift = plan[1].shift; a.bits = plan[1].bits; a.unstable = 0;
+        a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lookback + lb_off[i];
+        a.ticket = d_tickets + i; a.err = c->d_err; a.tile_src = sb.d_tile_src[i];
+    }
+    const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
+    if (max_tiles) { if (wide) launch_onesweep_multi<1, false, u64>(c, ms, grid); else launch_onesweep_multi<1, false, u32>(c, ms, grid); }
+    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    HIPCHK(c, hipGetLastError());
+    XS_TRACE("pass 2 launched");
+    u32 tk[XCD_BATCH];
+    HIPCHK(c, hipMemcpyAsync(tk, d_tickets, sizeof tk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    XS_TRACE("pass 2 done");
+    for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
+        if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (%u of %llu tiles)", i, tk[i], (unsigned long long)ntiles[i]);
+    c->pool.release(d_gbase); c->pool.release(d_tickets); c->pool.release(d_lookback);
+    scatter_release(c, sb);
+    return rc;
+}

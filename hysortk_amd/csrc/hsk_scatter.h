@@ -1,0 +1,276 @@
+// hsk_scatter.h -- expand fused with the first scatter pass (one-word keys, no payload, aggregating finish).
+//
+// The two-pass prefix plan (hsk_host_sort.h) orders a task by its top 16 key bits: a first pass on the lower 8 of them,
+// whose output order inside a digit is free, and a stable second pass on the upper 8.  The first pass needs nothing but
+// the keys, so it runs where the keys are born: expand_scatter_kernel rolls the k-mers of a tile exactly like
+// expand_kernel (hsk_expand.h; reference GatheredSupermer::receive_from_buffer_stage2 src/kmerops.cpp:484-521) and,
+// instead of writing them in input order for a radix pass to read back, ranks them by digit in LDS and writes them
+// straight into the digit's bin: 16 bytes of HBM traffic per k-mer less (the key array written by the expand and read
+// by the first pass is never materialised).
+//
+// The digit histogram of the keys is not known before they exist, so a bin is not a pre-sized range but a LIST OF CHUNKS
+// of XS_CHUNK keys (= one tile of the second pass).  cursor[d] counts the keys reserved for digit d; a flush takes its
+// range [p, p + c) with one atomic add; virtual chunk v = p / XS_CHUNK of digit d lives in physical chunk map[d][v],
+// allocated (bump counter) by the one reservation that contains the chunk's first slot and published through the map;
+// everybody else whose range touches the chunk polls the map entry.  The allocator publishes before it waits for
+// anything, so the wait is bounded by one L2 round trip (and by XS_SPIN_LIMIT: error word, HSK_ERR_INTERNAL).
+// A task wastes less than one chunk per digit: the chunk store holds n / XS_CHUNK + 257 chunks.
+//
+// One task per XCD (HW_REG_XCC_ID, like onesweep_multi_kernel): cursors, map and chunk counter of a task are only ever
+// touched from one XCD, so their atomics execute in that XCD's L2 (workgroup-scope RMW, L1-bypassing polls), and the
+// short runs that neighbouring reservations of a digit write into the same 128-byte line merge in that L2 before they
+// go to HBM.  The host checks afterwards that the cursors add up to the task's k-mer count.
+//
+// chunk_tiles_kernel then lists the chunks in (digit, virtual chunk) order as the tiles of the second pass
+// (SortArgs::tile_src): tile = {physical chunk, keys in it}.
+#pragma once
+#include "hsk_expand.h"
+#include "hsk_sort.h"
+
+namespace hsk {
+
+constexpr int XS_THREADS = 512;
+constexpr int XS_WAVES = XS_THREADS / WAVE;
+constexpr int XS_TILE = EXP_TILE;                     // supermers per tile: one per thread (the tile lists are shared with expand_kernel)
+constexpr int XS_RUN = 16;                            // k-mers per work item: nearly every supermer is one item (expand_kernel: 8)
+constexpr int XS_MAX_ITEMS = XS_TILE * (128 / XS_RUN);
+constexpr int XS_CHUNK = SortTile<1>::TILE;           // keys per chunk
+constexpr int XS_SPAN = 3;                            // chunks one reservation can touch
+constexpr u32 XS_SPIN_LIMIT = 1u << 22;
+static_assert(XS_THREADS == XS_TILE, "one supermer per thread in the tile prologue");
+static_assert(XS_THREADS * XS_RUN <= (XS_SPAN - 1) * XS_CHUNK, "a reservation touches at most XS_SPAN chunks of a digit");
+static_assert((XS_CHUNK & (XS_CHUNK - 1)) == 0, "chunk size is a power of two");
+
+struct ScatterTask {
+    const ExpSeg *segs; int nseg; u32 vmax;          // vmax: map entries per digit (n / XS_CHUNK + 1)
+    const u8 *sm_len; const u64 *src8; u64 src_bit0, src_words;
+    const u64 *sm_gpos; const u64 *tile_off; u64 ntiles;
+    u64 *chunks;                                     // chunk store
+    u64 *cursor;                                     // [256] keys reserved per digit (zeroed)
+    u32 *map;                                        // [256][vmax] physical chunk + 1 (zeroed)
+    u32 *ctl;                                        // [0] tile ticket, [1] chunks handed out (zeroed)
+    u64 *ghist;                                      // [256] histogram of the second pass's digit (zeroed)
+    u64 *tile_src;                                   // out (chunk_tiles_kernel): second-pass tiles
+};
+struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1; u32 *err; };
+
+__device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 */, u32 *total)
+{
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    u32 inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) scratch[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < XS_WAVES; ++i) { u32 s = scratch[i]; if (i < w) base += s; tot += s; }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
+// Diagnostic build only (-DHSK_DIAG): shader-clock sums per phase of a flush, stamped by thread 0 of every workgroup
+#ifdef HSK_DIAG
+__device__ unsigned long long g_xs_diag[16];
+#define XS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[i] += t_ - xs_last; xs_last = t_; } } while (0)
+#else
+#define XS_STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs a)
+{
+#ifdef HSK_DIAG
+    unsigned long long xs_acc[12] = {0}, xs_last = __builtin_amdgcn_s_memtime();
+#endif
+    __shared__ u32 s_boff[XS_TILE + 1];
+    __shared__ u32 s_koff[XS_TILE + 1];
+    __shared__ u32 s_ioff[XS_TILE + 1];
+    __shared__ u16 s_isup[XS_MAX_ITEMS];
+    __shared__ u64 s_gpos[XS_TILE];
+    __shared__ u64 s_stage[XS_CHUNK];
+    __shared__ u32 s_cnt[256], s_start[256], s_off0[256], s_hist[256];
+    __shared__ u32 s_ph[XS_SPAN][256];
+    __shared__ u32 s_scr[XS_WAVES];
+    __shared__ u32 s_tile;
+    typedef __attribute__((address_space(1))) u32 G32;
+    const int tid = threadIdx.x;
+    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
+    const ScatterTask &t = a.t[xcc];
+    if (t.ntiles == 0) return;
+    const int k = a.k;
+    const int low = 64 - 2 * k;
+    const u64 lastmask = ~0ULL << low;
+    if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
+
+    for (;;) {
+        if (tid == 0) s_tile = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        const u64 tile = s_tile;
+        if (tile >= t.ntiles) break;                                  // uniform
+        const int sg = seg_of_tile(t.segs, t.nseg, tile);
+        const ExpSeg seg = t.segs[sg];
+        const u64 first = (tile - seg.tile_start) * XS_TILE;
+        const u32 ns = (u32)((seg.n_sup - first) < (u64)XS_TILE ? (seg.n_sup - first) : (u64)XS_TILE);
+
+        // ---- prologue: thread s owns supermer s of the tile ---------------------------------------------------
+        const u32 len = ((u32)tid < ns) ? t.sm_len[seg.sup_off + first + tid] : 0;
+        const u32 nb = ((u32)tid < ns) ? ((len + 3) >> 2) : 0;
+        const u32 nk = ((u32)tid < ns) ? (len - k + 1) : 0;
+        const u32 ni = (nk + XS_RUN - 1) / XS_RUN;
+        u32 toti;
+        const u32 eb = block_excl_scan_512(nb, s_scr, nullptr);
+        const u32 ek = block_excl_scan_512(nk, s_scr, nullptr);
+        const u32 ei = block_excl_scan_512(ni, s_scr, &toti);
+        s_boff[tid] = eb; s_koff[tid] = ek; s_ioff[tid] = ei;
+        if (t.sm_gpos && (u32)tid < ns) s_gpos[tid] = t.sm_gpos[seg.sup_off + first + tid];
+        for (u32 j = 0; j < ni; ++j) s_isup[ei + j] = (u16)tid;
+        if (tid == XS_THREADS - 1) { s_boff[XS_TILE] = eb + nb; s_koff[XS_TILE] = ek + nk; s_ioff[XS_TILE] = ei + ni; }
+        const u64 byte_abs = t.tile_off ? t.tile_off[2 * tile] : 0;
+        __syncthreads();
+
+        u32 n_cnt = 0, n_sh = 0; u64 n_raw[3];
+        auto fetch = [&](u32 item) {
+            n_cnt = 0; n_sh = 0; n_raw[0] = n_raw[1] = n_raw[2] = 0;
+            if (item < toti) {
+                const u32 sidx = s_isup[item];
+                const u32 i0 = (item - s_ioff[sidx]) * XS_RUN;
+                const u32 nks = s_koff[sidx + 1] - s_koff[sidx];
+                n_cnt = nks - i0 < (u32)XS_RUN ? nks - i0 : (u32)XS_RUN;
+                const u64 bit = t.sm_gpos ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+                const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+            }
+        };
+        fetch(tid);
+        XS_STAMP(0);                                                  // tile claim + prologue
+        for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
+            const u32 cnt = n_cnt;
+            u64 win[2];
+            {
+                u64 aw[3];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) aw[x] = __builtin_bswap64(n_raw[x]);
+#pragma unroll
+                for (int x = 0; x < 2; ++x) win[x] = n_sh ? ((aw[x] << n_sh) | (aw[x + 1] >> (64 - n_sh))) : aw[x];
+            }
+            if (it0 + XS_THREADS < toti) fetch(it0 + XS_THREADS + tid);
+            // ---- roll the item's k-mers; rank every key inside its digit (arrival order: the pass is not stable) ----
+            u64 key[XS_RUN]; u32 rk[XS_RUN];
+            u64 fw = win[0] & lastmask;
+            Mer<1> f1; f1.w[0] = fw;
+            u64 rc = twin<1>(f1, k).w[0];
+#pragma unroll
+            for (int r = 0; r < XS_RUN; ++r) {
+                if (r > 0) {
+                    win[0] = (win[0] << 2) | (win[1] >> 62); win[1] <<= 2;
+                    fw = win[0] & lastmask;
+                    const u64 nbase = (fw >> low) & 3;
+                    rc = ((rc >> 2) | ((3 - nbase) << 62)) & lastmask;
+                }
+                key[r] = 0; rk[r] = 0;
+                if ((u32)r < cnt) {
+                    const u64 kk = rc < fw ? rc : fw;
+                    key[r] = kk;
+                    rk[r] = atomicAdd(&s_cnt[(u32)(kk >> a.shift0) & 255u], 1u);
+                    atomicAdd(&s_hist[(u32)(kk >> a.shift1) & 255u], 1u);
+                }
+            }
+            XS_STAMP(1);                                              // window + roll + rank
+            __syncthreads();                                          // digit counts of the flush complete
+            XS_STAMP(2);
+
+            // ---- flush: reserve the digits' ranges, permute through LDS, write runs ---------------------------
+            const u32 c = tid < 256 ? s_cnt[tid] : 0;
+            u32 tot;
+            const u32 st = block_excl_scan_512(c, s_scr, &tot);
+            u64 p = 0;
+            if (tid < 256) {
+                s_start[tid] = st; s_cnt[tid] = 0;
+                if (c) p = __hip_atomic_fetch_add(&t.cursor[tid], (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            XS_STAMP(3);                                              // scan + reservation issued
+            __syncthreads();
+            // the sorted order of the flush goes through the stage in windows of XS_CHUNK keys (one window unless the
+            // tile's supermers are longer than usual); the reservation is resolved while the first window is staged
+#pragma unroll
+            for (int r = 0; r < XS_RUN; ++r) {
+                if ((u32)r >= cnt) continue;
+                const u32 pos = s_start[(u32)(key[r] >> a.shift0) & 255u] + rk[r];
+                rk[r] = pos;                                           // position in the sorted order of the flush
+                if (pos < (u32)XS_CHUNK) s_stage[pos] = key[r];
+            }
+            XS_STAMP(4);                                              // sync + permute
+            if (tid < 256 && c) {
+                const u64 v0 = p / XS_CHUNK;
+                const u32 off0 = (u32)(p % XS_CHUNK);
+                const u32 nv = (off0 + c - 1) / XS_CHUNK + 1;          // chunks touched
+                G32 *mp = (G32 *)(t.map + (u64)tid * t.vmax);
+                u32 ph[XS_SPAN] = {0, 0, 0};
+                // the chunks whose first slot is mine are allocated and published before anything is waited for
+#pragma unroll
+                for (int j = 0; j < XS_SPAN; ++j) {
+                    if ((u32)j >= nv || (j == 0 && off0 != 0)) continue;
+                    ph[j] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    __hip_atomic_store(mp + v0 + j, ph[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (off0 != 0) {                                      // the chunk my range starts in was opened by another reservation
+                    u32 spins = 0;
+                    while ((ph[0] = __hip_atomic_load(mp + v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                        if (++spins > XS_SPIN_LIMIT) { atomicOr(a.err, 2u); ph[0] = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                s_off0[tid] = off0;
+#pragma unroll
+                for (int j = 0; j < XS_SPAN; ++j) s_ph[j][tid] = (ph[j] ? ph[j] : 1u) - 1;
+            }
+            XS_STAMP(5);                                              // reservation returned, chunk resolved
+            for (u32 w0 = 0; w0 < tot; w0 += XS_CHUNK) {
+                if (w0) {
+#pragma unroll
+                    for (int r = 0; r < XS_RUN; ++r)
+                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) s_stage[rk[r] - w0] = key[r];
+                }
+                __syncthreads();
+                const u32 wn = tot - w0 < (u32)XS_CHUNK ? tot - w0 : (u32)XS_CHUNK;
+                for (u32 i = tid; i < wn; i += XS_THREADS) {
+                    const u64 kk = s_stage[i];
+                    const u32 d = (u32)(kk >> a.shift0) & 255u;
+                    const u32 q = s_off0[d] + (w0 + i - s_start[d]);      // slot relative to the first chunk of the reservation
+                    t.chunks[(u64)s_ph[q / XS_CHUNK][d] * XS_CHUNK + (q & (XS_CHUNK - 1))] = kk;
+                }
+                __syncthreads();                                      // the stage is rewritten by the next window / flush
+            }
+            XS_STAMP(6);
+#ifdef HSK_DIAG
+            if (tid == 0) { xs_acc[10] += 1; xs_acc[11] += tot; }
+#endif
+        }
+    }
+    if (tid < 256) {
+        const u32 cv = s_hist[tid];
+        if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
+    }
+#ifdef HSK_DIAG
+    if (tid == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_xs_diag[i], xs_acc[i]);
+#endif
+}
+
+// tile_src[i] = (physical chunk << 32) | keys, chunks in (digit, virtual chunk) order; one workgroup per task
+__global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
+{
+    __shared__ u64 s_scr[8];
+    const ScatterTask &t = a.t[blockIdx.x];
+    if (t.ntiles == 0) return;
+    const int d = threadIdx.x;
+    const u64 cnt = t.cursor[d];
+    const u64 nch = (cnt + XS_CHUNK - 1) / XS_CHUNK;
+    u64 off = block_excl_scan_256<u64>(nch, s_scr, nullptr);
+    const u32 *mp = t.map + (u64)d * t.vmax;
+    for (u64 v = 0; v < nch; ++v) {
+        const u64 left = cnt - v * XS_CHUNK;
+        t.tile_src[off + v] = ((u64)(mp[v] - 1) << 32) | (left < (u64)XS_CHUNK ? left : (u64)XS_CHUNK);
+    }
+}
+
+} // namespace hsk

@@ -79,6 +79,7 @@ struct SortArgs {
     void *lookback;       // [ntiles][256] LB words, zeroed
     u32 *ticket;          // zeroed
     u32 *err;             // sticky error word
+    const u64 *tile_src;  // null: tile t is keys_in[t * TILE ...]; else tile t = (chunk << 32 | keys) of a chunked input (hsk_scatter.h)
 };
 
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
@@ -122,8 +123,9 @@ __device__ __forceinline__ void onesweep_tile(const SortArgs &a)
     DIAG_STAMP(1);
     const u64 tile = s_tile[0];
     if (tile >= a.ntiles) return;                 // uniform: the whole workgroup leaves (multi kernel: task exhausted)
-    const u64 base = tile * TILE;
-    const u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
+    u64 base = tile * TILE;
+    u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
+    if (a.tile_src) { const u64 ts = a.tile_src[tile]; base = (ts >> 32) * TILE; nvalid = (u32)ts; }
     const u32 dmask = (1u << a.bits) - 1;
 
     // ---- load (wave-striped) -----------------------------------------------------------------
@@ -157,6 +159,8 @@ __device__ __forceinline__ void onesweep_tile(const SortArgs &a)
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const u32 d = dig[j];
+        // padding of a partial tile is not counted (a chunked input has a partial tile per digit, not only at the end)
+        if ((u32)(wave * (WAVE * KPT) + j * WAVE + lane) >= nvalid) { rank[j] = 0; continue; }
         if (a.unstable) {                            // (uniform) one LDS atomic: the rank is the arrival order inside the wave
             rank[j] = __hip_atomic_fetch_add(&wh[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             continue;
@@ -203,6 +207,7 @@ __device__ __forceinline__ void onesweep_tile(const SortArgs &a)
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const u32 d = dig[j];
+        if ((u32)(wave * (WAVE * KPT) + j * WAVE + lane) >= nvalid) continue;
         const u32 lpos = s_dstart[d] + s_whist[wave * 256 + d] + rank[j];
 #pragma unroll
         for (int w = 0; w < NW; ++w) s_keys[lpos * NW + w] = key[j][w];
