@@ -278,7 +278,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = piped ? 2 : 1;
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
-    const bool xs = batch && !piped && !ext && NW == 1 && scatter_enabled() && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    const bool xs = batch && !piped && !ext && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
     ScatterBatch sbatch;
     PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};

@@ -35,6 +35,7 @@ constexpr int XS_TILE = EXP_TILE;                     // supermers per tile: one
 constexpr int XS_RUN = 16;                            // k-mers per work item: nearly every supermer is one item (expand_kernel: 8)
 constexpr int XS_MAX_ITEMS = XS_TILE * (128 / XS_RUN);
 constexpr int XS_CHUNK = SortTile<1>::TILE;           // keys per chunk
+constexpr int XS_CLAIM = 4;                          // tiles per claim
 constexpr int XS_SPAN = 3;                            // chunks one reservation can touch
 constexpr u32 XS_SPIN_LIMIT = 1u << 22;
 static_assert(XS_THREADS == XS_TILE, "one supermer per thread in the tile prologue");
@@ -52,18 +53,23 @@ struct ScatterTask {
     u64 *ghist;                                      // [256] histogram of the second pass's digit (zeroed)
     u64 *tile_src;                                   // out (chunk_tiles_kernel): second-pass tiles
 };
-struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1; u32 *err; };
+struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1; u32 *err; };     // shift0, shift1 >= 32 (the digits are in the top 16 bits)
+
+// Workgroup barrier for LDS traffic only: waits for the wave's LDS operations, not for its outstanding global loads, stores
+// and atomics (__syncthreads() drains those too, which would put every prefetch and the reservation round trip on the
+// critical path).  Everything the waves of this kernel hand to each other between barriers goes through LDS.
+__device__ __forceinline__ void xs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 */, u32 *total)
 {
     const int lane = lane_id(), w = threadIdx.x >> 6;
     u32 inc = wave_incl_scan(v);
     if (lane == WAVE - 1) scratch[w] = inc;
-    __syncthreads();
+    xs_barrier();
     u32 base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < XS_WAVES; ++i) { u32 s = scratch[i]; if (i < w) base += s; tot += s; }
-    __syncthreads();
+    xs_barrier();
     if (total) *total = tot;
     return base + inc - v;
 }
@@ -76,10 +82,10 @@ __device__ unsigned long long g_xs_diag[16];
 #define XS_STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs a)
+__global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
 {
 #ifdef HSK_DIAG
-    unsigned long long xs_acc[12] = {0}, xs_last = __builtin_amdgcn_s_memtime();
+    unsigned long long xs_acc[16] = {0}, xs_last = __builtin_amdgcn_s_memtime();
 #endif
     __shared__ u32 s_boff[XS_TILE + 1];
     __shared__ u32 s_koff[XS_TILE + 1];
@@ -87,10 +93,10 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
     __shared__ u16 s_isup[XS_MAX_ITEMS];
     __shared__ u64 s_gpos[XS_TILE];
     __shared__ u64 s_stage[XS_CHUNK];
-    __shared__ u32 s_cnt[256], s_start[256], s_off0[256], s_hist[256];
-    __shared__ u32 s_ph[XS_SPAN][256];
+    __shared__ u32 s_cnt[256], s_start[256], s_split[256], s_hist[256];
+    __shared__ u32 s_dl[XS_SPAN][256];                                  // staged slot + s_dl[j][d] = slot in the chunk store (j-th chunk of the reservation)
     __shared__ u32 s_scr[XS_WAVES];
-    __shared__ u32 s_tile;
+    __shared__ u32 s_blk[2];
     typedef __attribute__((address_space(1))) u32 G32;
     const int tid = threadIdx.x;
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
@@ -99,33 +105,77 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
     const int k = a.k;
     const int low = 64 - 2 * k;
     const u64 lastmask = ~0ULL << low;
+    const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u;
+    const bool single = t.nseg == 1;                       // one segment (always on one GPU): the next tile's inputs are prefetched
+    const bool inplace = t.sm_gpos != nullptr;
+    const ExpSeg seg0 = t.segs[0];
+    const u64 s0_sup = seg0.sup_off, s0_n = seg0.n_sup;
     if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
 
-    for (;;) {
-        if (tid == 0) s_tile = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
-        const u64 tile = s_tile;
-        if (tile >= t.ntiles) break;                                  // uniform
-        const int sg = seg_of_tile(t.segs, t.nseg, tile);
-        const ExpSeg seg = t.segs[sg];
-        const u64 first = (tile - seg.tile_start) * XS_TILE;
-        const u32 ns = (u32)((seg.n_sup - first) < (u64)XS_TILE ? (seg.n_sup - first) : (u64)XS_TILE);
+    // Tiles are claimed in blocks of XS_CLAIM, two blocks ahead: the tile that follows the current one is always known,
+    // so its supermer lengths and positions (and then its first windows) are requested while the current tile is worked on.
+    if (tid == 0) {
+        s_blk[0] = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s_blk[1] = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    xs_barrier();
+    u64 blk = s_blk[0], nblk = s_blk[1];
+    u32 p_len = 0; u64 p_gpos = 0, p_raw[3] = {0, 0, 0}; bool p_have = false, p_win = false;
+    auto prefetch_meta = [&](u64 tl) {
+        p_have = single && tl < t.ntiles; p_len = 0; p_gpos = 0;
+        if (p_have) {
+            const u64 sidx = tl * XS_TILE + tid;
+            if (sidx < s0_n) { p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx]; }
+        }
+    };
+    auto prefetch_win = [&]() {                            // speculation: item `tid` of the tile is the start of supermer `tid`
+        p_win = p_have && inplace;
+        if (p_win) {
+            const u64 wi = (t.src_bit0 + 2 * p_gpos) >> 6;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) p_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+        }
+    };
+    prefetch_meta(blk); prefetch_win();
+    xs_barrier();                                       // s_blk[1] is rewritten during the first tile
+
+    for (u32 j = 0;;) {
+        const u64 tile = blk + j;
+        if (tile >= t.ntiles) break;                                  // uniform; blocks come in ascending order
+        const u64 ntile = (j + 1 == (u32)XS_CLAIM) ? nblk : tile + 1;
+        u32 claim = 0;
+        if (j == 0 && tid == 0) claim = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        u64 sg_sup = seg0.sup_off, sg_n = seg0.n_sup, sg_t0 = seg0.tile_start;
+        if (!single) { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, t.nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; }
+        const u64 first = (tile - sg_t0) * XS_TILE;
+        const u32 ns = (u32)((sg_n - first) < (u64)XS_TILE ? (sg_n - first) : (u64)XS_TILE);
 
         // ---- prologue: thread s owns supermer s of the tile ---------------------------------------------------
-        const u32 len = ((u32)tid < ns) ? t.sm_len[seg.sup_off + first + tid] : 0;
+        u32 len = p_len; u64 gp = p_gpos;
+        const bool have_win = p_win;
+        const u64 raw0 = p_raw[0], raw1 = p_raw[1], raw2 = p_raw[2];
+        if (!p_have) {
+            len = ((u32)tid < ns) ? t.sm_len[sg_sup + first + tid] : 0;
+            gp = (inplace && (u32)tid < ns) ? t.sm_gpos[sg_sup + first + tid] : 0;
+        }
+        XS_STAMP(12);
         const u32 nb = ((u32)tid < ns) ? ((len + 3) >> 2) : 0;
         const u32 nk = ((u32)tid < ns) ? (len - k + 1) : 0;
         const u32 ni = (nk + XS_RUN - 1) / XS_RUN;
-        u32 toti;
-        const u32 eb = block_excl_scan_512(nb, s_scr, nullptr);
-        const u32 ek = block_excl_scan_512(nk, s_scr, nullptr);
-        const u32 ei = block_excl_scan_512(ni, s_scr, &toti);
+        u32 tot2;
+        const u32 e2 = block_excl_scan_512((nk << 13) | ni, s_scr, &tot2);   // sums: items <= 4096, k-mers <= 65536
+        const u32 ek = e2 >> 13, ei = e2 & 8191u, toti = tot2 & 8191u;
+        u32 eb = 0;
+        if (!inplace) eb = block_excl_scan_512(nb, s_scr, nullptr);
+        prefetch_meta(ntile);                                         // (after the last use of the values it replaces)
+        XS_STAMP(13);
         s_boff[tid] = eb; s_koff[tid] = ek; s_ioff[tid] = ei;
-        if (t.sm_gpos && (u32)tid < ns) s_gpos[tid] = t.sm_gpos[seg.sup_off + first + tid];
-        for (u32 j = 0; j < ni; ++j) s_isup[ei + j] = (u16)tid;
+        if (inplace) s_gpos[tid] = gp;
+        for (u32 q = 0; q < ni; ++q) s_isup[ei + q] = (u16)tid;
         if (tid == XS_THREADS - 1) { s_boff[XS_TILE] = eb + nb; s_koff[XS_TILE] = ek + nk; s_ioff[XS_TILE] = ei + ni; }
         const u64 byte_abs = t.tile_off ? t.tile_off[2 * tile] : 0;
-        __syncthreads();
+        xs_barrier();
+        XS_STAMP(14);
 
         u32 n_cnt = 0, n_sh = 0; u64 n_raw[3];
         auto fetch = [&](u32 item) {
@@ -135,13 +185,18 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
                 const u32 i0 = (item - s_ioff[sidx]) * XS_RUN;
                 const u32 nks = s_koff[sidx + 1] - s_koff[sidx];
                 n_cnt = nks - i0 < (u32)XS_RUN ? nks - i0 : (u32)XS_RUN;
-                const u64 bit = t.sm_gpos ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+                const u64 bit = inplace ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
                 const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
 #pragma unroll
                 for (int x = 0; x < 3; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
             }
         };
-        fetch(tid);
+        if (have_win && (ei == (u32)tid || (u32)tid >= toti)) {         // the speculation held for this lane (or it has no item)
+            n_cnt = (u32)tid < toti ? (nk < (u32)XS_RUN ? nk : (u32)XS_RUN) : 0;
+            n_sh = (u32)((t.src_bit0 + 2 * gp) & 63);
+            n_raw[0] = raw0; n_raw[1] = raw1; n_raw[2] = raw2;
+        } else fetch(tid);
+        bool win_sent = false;
         XS_STAMP(0);                                                  // tile claim + prologue
         for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
             const u32 cnt = n_cnt;
@@ -171,12 +226,13 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
                 if ((u32)r < cnt) {
                     const u64 kk = rc < fw ? rc : fw;
                     key[r] = kk;
-                    rk[r] = atomicAdd(&s_cnt[(u32)(kk >> a.shift0) & 255u], 1u);
-                    atomicAdd(&s_hist[(u32)(kk >> a.shift1) & 255u], 1u);
+                    rk[r] = atomicAdd(&s_cnt[((u32)(kk >> 32) >> sh0) & 255u], 1u);
+                    atomicAdd(&s_hist[((u32)(kk >> 32) >> sh1) & 255u], 1u);
                 }
             }
+            if (!win_sent) { prefetch_win(); win_sent = true; }       // the next tile's positions have arrived by now
             XS_STAMP(1);                                              // window + roll + rank
-            __syncthreads();                                          // digit counts of the flush complete
+            xs_barrier();                                          // digit counts of the flush complete
             XS_STAMP(2);
 
             // ---- flush: reserve the digits' ranges, permute through LDS, write runs ---------------------------
@@ -189,13 +245,13 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
                 if (c) p = __hip_atomic_fetch_add(&t.cursor[tid], (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             XS_STAMP(3);                                              // scan + reservation issued
-            __syncthreads();
+            xs_barrier();
             // the sorted order of the flush goes through the stage in windows of XS_CHUNK keys (one window unless the
             // tile's supermers are longer than usual); the reservation is resolved while the first window is staged
 #pragma unroll
             for (int r = 0; r < XS_RUN; ++r) {
                 if ((u32)r >= cnt) continue;
-                const u32 pos = s_start[(u32)(key[r] >> a.shift0) & 255u] + rk[r];
+                const u32 pos = s_start[((u32)(key[r] >> 32) >> sh0) & 255u] + rk[r];
                 rk[r] = pos;                                           // position in the sorted order of the flush
                 if (pos < (u32)XS_CHUNK) s_stage[pos] = key[r];
             }
@@ -220,9 +276,11 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                s_off0[tid] = off0;
-#pragma unroll
-                for (int j = 0; j < XS_SPAN; ++j) s_ph[j][tid] = (ph[j] ? ph[j] : 1u) - 1;
+                const u32 split = st + ((u32)XS_CHUNK - off0);         // first slot (in the sorted order of the flush) in the second chunk
+                s_split[tid] = split;
+                s_dl[0][tid] = (ph[0] - 1) * (u32)XS_CHUNK + off0 - st;
+                s_dl[1][tid] = ((ph[1] ? ph[1] : 1u) - 1) * (u32)XS_CHUNK - split;
+                s_dl[2][tid] = ((ph[2] ? ph[2] : 1u) - 1) * (u32)XS_CHUNK - (split + (u32)XS_CHUNK);
             }
             XS_STAMP(5);                                              // reservation returned, chunk resolved
             for (u32 w0 = 0; w0 < tot; w0 += XS_CHUNK) {
@@ -231,28 +289,32 @@ __global__ __launch_bounds__(XS_THREADS) void expand_scatter_kernel(ScatterArgs 
                     for (int r = 0; r < XS_RUN; ++r)
                         if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) s_stage[rk[r] - w0] = key[r];
                 }
-                __syncthreads();
+                xs_barrier();
                 const u32 wn = tot - w0 < (u32)XS_CHUNK ? tot - w0 : (u32)XS_CHUNK;
                 for (u32 i = tid; i < wn; i += XS_THREADS) {
                     const u64 kk = s_stage[i];
-                    const u32 d = (u32)(kk >> a.shift0) & 255u;
-                    const u32 q = s_off0[d] + (w0 + i - s_start[d]);      // slot relative to the first chunk of the reservation
-                    t.chunks[(u64)s_ph[q / XS_CHUNK][d] * XS_CHUNK + (q & (XS_CHUNK - 1))] = kk;
+                    const u32 d = ((u32)(kk >> 32) >> sh0) & 255u;
+                    const u32 g = w0 + i, sp = s_split[d];
+                    const u32 o = g + (g < sp ? s_dl[0][d] : (g < sp + (u32)XS_CHUNK ? s_dl[1][d] : s_dl[2][d]));   // (mod 2^32)
+                    t.chunks[o] = kk;
                 }
-                __syncthreads();                                      // the stage is rewritten by the next window / flush
+                xs_barrier();                                      // the stage is rewritten by the next window / flush
             }
             XS_STAMP(6);
 #ifdef HSK_DIAG
             if (tid == 0) { xs_acc[10] += 1; xs_acc[11] += tot; }
 #endif
         }
+        if (!win_sent) prefetch_win();                                // (tile without k-mers)
+        if (j == 0 && tid == 0) s_blk[1] = claim;                     // read at the next block switch, at least one barrier from here
+        if (++j == (u32)XS_CLAIM) { xs_barrier(); blk = nblk; nblk = s_blk[1]; j = 0; xs_barrier(); }
     }
     if (tid < 256) {
         const u32 cv = s_hist[tid];
         if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
     }
 #ifdef HSK_DIAG
-    if (tid == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_xs_diag[i], xs_acc[i]);
+    if (tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_xs_diag[i], xs_acc[i]);
 #endif
 }
 

@@ -20,5 +20,8 @@ with H.Context(K=31, M=17, L=15, U=40, keep_device=True) as c:
     nf = max(out[10], 1)
     tot = sum(out[i] for i in range(7))
     print("flushes", out[10], "keys per flush %.0f" % (out[11] / nf), "clocks per flush %.0f" % (tot / nf))
+    print("  prologue parts per flush: take prefetched + next meta %.0f, scan %.0f, tables + sync %.0f, first windows %.0f" % (out[12] / nf, out[13] / nf, out[14] / nf, out[0] / nf))
+    out[0] += out[12] + out[13] + out[14]
+    tot = sum(out[i] for i in range(7))
     for i, nm in enumerate(names):
         print("  %-30s %8.0f  %5.1f%%" % (nm, out[i] / nf, 100.0 * out[i] / tot))
