@@ -132,7 +132,8 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
     for (int i = 0; i < XCD_BATCH; ++i) {
         SortArgs &a = ms.t[i];
         a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.n = bt[i].n; a.ntiles = ntiles[i];
-        a.word = plan[1].word; a.shift = plan[1].shift; a.bits = plan[1].bits; a.unstable = 0;
+        a.word = plan[1].word; a.shift = plan[1].shift; a.bits = plan[1].bits;
+        a.unstable = unstable_first_pass() ? 1 : 0;     // a tile is a chunk of ONE first-pass digit: the order inside it is free, the look-back keeps the tiles in order
         a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lookback + lb_off[i];
         a.ticket = d_tickets + i; a.err = c->d_err; a.tile_src = sb.d_tile_src[i];
     }
