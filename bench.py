@@ -201,10 +201,13 @@ def main():
                 "K": KK, "M": M, "L": L, "U": U, "EXT": a.ext, "ntasks": info["ntasks"], "scale": a.scale,
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD; with the first pass fused into the expand this is the one remaining pass, over chunk tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": int(st["scatter_launches"]),
                          "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch,
-                         "hist_GBs": (st["hist_bytes"] / max(st["hist_ms"], 1e-9) / 1e6) if st["hist_ms"] else None,
+                         # kind-1 events: expand_scatter_kernel (expand + first scatter pass; bytes = keys written) when the fused
+                         # path runs, the histogram kernel otherwise
+                         "expand_scatter_avg_launch_ms": (st["hist_ms"] / max(int(st["hist_launches"]), 1)) if st["hist_ms"] else None,
+                         "expand_scatter_written_GBs": (st["hist_bytes"] / max(st["hist_ms"], 1e-9) / 1e6) if st["hist_ms"] else None,
                          "agg_GBs": (st["agg_bytes"] / max(st["agg_ms"], 1e-9) / 1e6) if st["agg_ms"] else None,
                          "agg_avg_launch_ms": (st["agg_ms"] / max(int(st["agg_launches"]), 1)) if st["agg_ms"] else None},
             "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks", "onepass_misses") if k_ in st},

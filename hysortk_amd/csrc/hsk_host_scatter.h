@@ -12,7 +12,6 @@ struct ScatterBatch {
     bool active = false;
 };
 
-#define XS_TRACE(msg) do { if (getenv("HSK_TRACE")) { fprintf(stderr, "[xs] %s\n", msg); fflush(stderr); } } while (0)
 static bool scatter_enabled()
 {
     static const bool on = !(getenv("HSK_FUSED_SCATTER") && atoi(getenv("HSK_FUSED_SCATTER")) == 0);
@@ -45,9 +44,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         if (!jobs[i].src.gpos) offsets = true;           // byte streams: a tile's input offset is a prefix over the tiles before it
     }
     if (m == 0) return HSK_OK;
-    XS_TRACE("prepare");
     int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, false, offsets); if (rc) return rc;
-    XS_TRACE("prepared");
     DALLOC(c, sb.d_cursor, u64 *, (size_t)XCD_BATCH * 256 * 8);
     DALLOC(c, sb.d_ctl, u32 *, (size_t)XCD_BATCH * 16);
     HIPCHK(c, hipMemsetAsync(sb.d_cursor, 0, (size_t)XCD_BATCH * 256 * 8, stream));
@@ -77,11 +74,9 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         occ = (e == hipSuccess && nb > 0) ? nb : 2;
     }
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
-    XS_TRACE("launch");
     hipLaunchKernelGGL(expand_scatter_kernel, dim3((u32)occ * 256u), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
-    if (getenv("HSK_TRACE")) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "[xs] kernel done: %d\n", (int)e); fflush(stderr); }
     for (int i = 0; i < m; ++i) expand_release(c, x[i]);
     sb.active = true;
     return HSK_OK;
@@ -98,7 +93,6 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
     HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cur.data(), sb.d_cursor, cur.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    XS_TRACE("cursors read");
     int rc = check_device_error(c); if (rc) { scatter_release(c, sb); return rc; }
     u64 ntiles[XCD_BATCH], max_tiles = 0, ntot = 0; bool wide = force_wide_lookback();
     size_t lb_off[XCD_BATCH + 1]; lb_off[0] = 0;
@@ -142,11 +136,9 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
     if (max_tiles) { if (wide) launch_onesweep_multi<1, false, u64>(c, ms, grid); else launch_onesweep_multi<1, false, u32>(c, ms, grid); }
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
-    XS_TRACE("pass 2 launched");
     u32 tk[XCD_BATCH];
     HIPCHK(c, hipMemcpyAsync(tk, d_tickets, sizeof tk, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    XS_TRACE("pass 2 done");
     for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
         if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (%u of %llu tiles)", i, tk[i], (unsigned long long)ntiles[i]);
     c->pool.release(d_gbase); c->pool.release(d_tickets); c->pool.release(d_lookback);

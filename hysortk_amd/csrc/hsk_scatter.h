@@ -77,7 +77,7 @@ __device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 *
 // Diagnostic build only (-DHSK_DIAG): shader-clock sums per phase of a flush, stamped by thread 0 of every workgroup
 #ifdef HSK_DIAG
 __device__ unsigned long long g_xs_diag[16];
-#define XS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[i] += t_ - xs_last; xs_last = t_; } } while (0)
+#define XS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[i] += t_ - xs_acc[15]; xs_acc[15] = t_; } } while (0)
 #else
 #define XS_STAMP(i) do { } while (0)
 #endif
@@ -85,7 +85,8 @@ __device__ unsigned long long g_xs_diag[16];
 __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
 {
 #ifdef HSK_DIAG
-    unsigned long long xs_acc[16] = {0}, xs_last = __builtin_amdgcn_s_memtime();
+    __shared__ unsigned long long xs_acc[16];                 // (LDS: sixteen 64-bit accumulators in registers would cost the kernel its occupancy)
+    if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) xs_acc[i] = 0; xs_acc[15] = __builtin_amdgcn_s_memtime(); }
 #endif
     __shared__ u32 s_boff[XS_TILE + 1];
     __shared__ u32 s_koff[XS_TILE + 1];
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
     }
 #ifdef HSK_DIAG
-    if (tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_xs_diag[i], xs_acc[i]);
+    if (tid == 0) for (int i = 0; i < 15; ++i) atomicAdd(&g_xs_diag[i], xs_acc[i]);
 #endif
 }
 

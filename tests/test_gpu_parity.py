@@ -357,6 +357,29 @@ def test_fused_finish_adversarial(H, O, L, U, wild):
         assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
 
 
+def test_fused_scatter_long_supermers_one_digit(H, O):
+    """Expand fused with the first scatter pass (hsk_scatter.h): supermers of up to 128 k-mers (eight work items each, a
+    flush of more than one stage window), a million copies of one k-mer (one digit's chunk list spans hundreds of chunks,
+    reservations that straddle three chunks) next to ordinary reads."""
+    rng = np.random.default_rng(5)
+    g = "".join(rng.choice(list("ACGT"), 40000))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 6000)]
+    reads += ["A" * 400] * 3000 + ["ACG" * 120] * 500 + ["T" * 31] * 100
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=31, m=17, L=1, U=65535, ntasks=8, fast=True)
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=8) as c:
+        res = c.count(dna)
+        st = c.stats()
+    assert st["fused_tasks"] + st["redone_tasks"] == 8, st
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert int(ores.cnt.max()) >= 3000 * 370
+
+
 @pytest.mark.parametrize("L,U", [(1, 65535), (2, 50)])
 def test_aggregating_finish_table_ladder(H, O, L, U):
     """Prefix bins with ~200 / ~500 / ~1000 distinct keys per task: rank-by-counting, bitonic, and the retry with the

@@ -1,8 +1,11 @@
 #!/bin/bash
-for nt in 38 128 256 512 1024; do
-timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu --ntasks $nt 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-r=d['roofline']
-print('ntasks %d: %.3f G k-mers/s' % (d['config']['ntasks'], d['value']/1e9), {k: round(v,1) for k,v in d['phases_ms_per_step'].items()}, 'onesweep %.0f GB/s avg %.3f ms' % (r['achieved'], r['avg_launch_ms']))"
+# bench at several task counts: tools/gpu_ntasks.sh 24 32 40 ...
+export TMPDIR=/tmp
+for nt in "$@"; do
+  python bench.py --steps 2 --warmup 1 --no-cpu --ntasks $nt 2>&1 | tail -1 > /tmp/ab.json
+  python - "$nt" <<'PY'
+import json, sys
+d = json.loads(open("/tmp/ab.json").read())
+print("ntasks %-4s %.3f G k-mers/s  %.1f ms/step  %s %s" % (sys.argv[1], d["value"] / 1e9, d["ms_per_step"], {k[3:]: round(v, 1) for k, v in d["phases_ms_per_step"].items() if k not in ("ms_d2h", "ms_exchange")}, d.get("path_stats")))
+PY
 done
