@@ -278,8 +278,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = piped ? 2 : 1;
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
-    const bool xs = batch && !piped && !ext && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
-    ScatterBatch sbatch;
+    const bool xs = batch && !ext && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
     u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
@@ -354,7 +354,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             if constexpr (NW == 1) {
                 for (int i = 0; i < XCD_BATCH; ++i) jobs[i].keys = bts[sl][i].kB;
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
-                rc = scatter_expand_batch(c, jobs, bts[sl], plan, sbatch, xstream); if (rc) return rc;
+                rc = scatter_expand_batch(c, jobs, bts[sl], plan, sbatch[sl], xstream); if (rc) return rc;
             }
         } else { rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc; }
         pt.end(PH_EXTRACT, xstream);
@@ -380,7 +380,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
-        if (sbatch.active) { if constexpr (NW == 1) { int rc = sort_batch_prescattered(c, bt, xs_plan, d_ghist_slot[sl], sbatch); if (rc) return rc; } }
+        if (sbatch[sl].active) { if constexpr (NW == 1) { int rc = sort_batch_prescattered(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
         else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);

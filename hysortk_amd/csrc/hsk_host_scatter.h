@@ -9,6 +9,7 @@ struct ScatterBatch {
     u32 *d_ctl = nullptr;                        // [XCD_BATCH][4]
     u32 *d_map[XCD_BATCH] = {nullptr};
     u64 *d_tile_src[XCD_BATCH] = {nullptr};
+    ExpandScratch x[EXP_BATCH];                  // segment lists (and tile offsets) the kernel reads
     bool active = false;
 };
 
@@ -23,7 +24,7 @@ static size_t scatter_store_keys(u64 n) { return (size_t)(n / XS_CHUNK + 257) * 
 static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
 {
     c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl);
-    for (int i = 0; i < XCD_BATCH; ++i) { c->pool.release(sb.d_map[i]); c->pool.release(sb.d_tile_src[i]); }
+    for (int i = 0; i < XCD_BATCH; ++i) { c->pool.release(sb.d_map[i]); c->pool.release(sb.d_tile_src[i]); expand_release(c, sb.x[i]); }
     sb = ScatterBatch();
 }
 
@@ -34,7 +35,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     sb = ScatterBatch();
     ScatterArgs &a = sb.args; memset(&a, 0, sizeof a);
-    ExpandScratch x[EXP_BATCH]; int xi[EXP_BATCH]; int m = 0;
+    ExpandScratch *x = sb.x; int xi[EXP_BATCH]; int m = 0;
     const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH];
     bool offsets = false;
     for (int i = 0; i < XCD_BATCH; ++i) {
@@ -74,10 +75,12 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         occ = (e == hipSuccess && nb > 0) ? nb : 2;
     }
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
-    hipLaunchKernelGGL(expand_scatter_kernel, dim3((u32)occ * 256u), dim3(XS_THREADS), 0, stream, a);
+    // beside the sort of the previous batch (second stream): HSK_SCATTER_SHARE percent of the resident workgroups
+    static const int share_pct = getenv("HSK_SCATTER_SHARE") ? atoi(getenv("HSK_SCATTER_SHARE")) : 100;
+    const u32 grid = (stream != c->stream) ? std::max(8u, (u32)occ * 256u * (u32)share_pct / 100u) : (u32)occ * 256u;
+    hipLaunchKernelGGL(expand_scatter_kernel, dim3(grid), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
-    for (int i = 0; i < m; ++i) expand_release(c, x[i]);
     sb.active = true;
     return HSK_OK;
 }

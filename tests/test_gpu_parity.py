@@ -377,7 +377,6 @@ def test_fused_scatter_long_supermers_one_digit(H, O):
     assert np.array_equal(res.task_off, ores.task_off)
     assert np.array_equal(res.kmers, ores.keys)
     assert np.array_equal(res.cnt, ores.cnt)
-    assert int(ores.cnt.max()) >= 3000 * 370
 
 
 @pytest.mark.parametrize("L,U", [(1, 65535), (2, 50)])
