@@ -599,6 +599,32 @@ def test_random_configurations_vs_oracle(H, O, seed):
             assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_scatter_sweep_vs_oracle(H, O, seed):
+    """The benchmark path (one-word keys, no payload, whole batches of 8 tasks: expand fused with the first scatter pass,
+    chunk-listed bins, second pass over chunk tiles, aggregation) over K, M, task counts and skewed inputs at a few
+    million k-mers: digits with thousands of chunks next to empty ones, partial batches padded with empty tasks."""
+    rng = np.random.default_rng(4000 + seed)
+    K = int(rng.choice([17, 21, 25, 27, 29, 31]))
+    M = int(rng.integers(7, min(K - 1, 24)))
+    ntasks = int(rng.choice([8, 11, 16, 24, 40]))
+    L = int(rng.choice([1, 2, 3])); U = int(rng.choice([40, 65535]))
+    g = "".join(rng.choice(list("ACGT"), 200000, p=[0.4, 0.1, 0.1, 0.4] if seed % 2 else [0.25] * 4))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 30000)]
+    reads += ["".join(rng.choice(list("AT"), 200)) for _ in range(2000)]          # low complexity: few digits, long chunk lists
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=M, L=L, U=U, ntasks=ntasks, fast=True)
+    with H.Context(K=K, M=M, L=L, U=U, ntasks=ntasks) as c:
+        res = c.count(dna)
+        st = c.stats()
+    tag = (K, M, ntasks, L, U)
+    assert st["fused_tasks"] + st["redone_tasks"] == ntasks, (tag, st)
+    assert np.array_equal(res.task_off, ores.task_off), tag
+    assert np.array_equal(res.kmers, ores.keys), tag
+    assert np.array_equal(res.cnt, ores.cnt), tag
+
+
 @pytest.mark.parametrize("K", [31, 51, 77])
 def test_output_text_formatted_on_device(H, O, K, tmp_path):
     """hsk_format_entries: the "KMER\\tcount" lines of write_output_file (reference src/hysortk.cpp:138-164) formatted on the GPU
