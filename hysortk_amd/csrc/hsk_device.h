@@ -189,6 +189,26 @@ __device__ __forceinline__ T block_excl_scan_256(T v, T *scratch, T *total)
     return base + inc - v;
 }
 
+// Workgroup barrier for LDS traffic only: waits for the wave's LDS operations, not for its outstanding global loads, stores
+// and atomics.  __syncthreads() drains those too, which puts every prefetch issued before it (and the acknowledgement of
+// every store) on the critical path.  Use where the waves hand data to each other through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_256_lds(T v, T *scratch, T *total)      // block_excl_scan_256 with lds_barrier()
+{
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    T inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) scratch[w] = inc;
+    lds_barrier();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T s = scratch[i]; if (i < w) base += s; tot += s; }
+    lds_barrier();
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
 // ---- radix digit plan (hsk_sort.h; hsk_expand.h builds the digit histograms while it writes the keys) ----
 constexpr int MAX_PASSES = 24;
 struct PassDesc { int word; int shift; int bits; };

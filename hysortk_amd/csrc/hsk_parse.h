@@ -37,6 +37,7 @@ constexpr int HSK_MAX_TASKS = 1024;
 constexpr int PARSE_WORDS = PARSE_TILE / 16 + 12;     // 128 tile words + halo (K-1 <= 94 bases = 6 words) + overread
 constexpr int PARSE_HMAX = PARSE_TILE + 96;           // hashes for TILE + (K-M) positions
 constexpr int PARSE_RWIN = 64;                        // reads looked at per tile by the wave-parallel index search
+static_assert(PARSE_RWIN + PARSE_WORDS <= PARSE_THREADS, "scan_kernel prefetches the next tile with one lane per read-index entry and per word");
 
 struct ParseArgs {
     const u8 *packed;          // 4-byte aligned; nothing beyond packed_bytes is read
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     __syncthreads();
     const u64 RINF = ~0ULL >> 2;
     const int p0 = tid * PARSE_PPT;
+    u32 pf0 = 0, pf1 = 0, pf2 = 0; bool pf_have = false;      // prefetched: lanes < PARSE_RWIN {read offset, length}, the next PARSE_WORDS lanes one tile word each
 
 #ifdef HSK_DIAG
     unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0};
@@ -499,7 +501,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 #endif
 
         // ---- 1. stage bytes (big-endian words), read index window (as parse_kernel) -----------------------
-        {
+        if (pf_have) { if (tid >= PARSE_RWIN && tid < PARSE_RWIN + PARSE_WORDS) s_words[tid - PARSE_RWIN] = __builtin_bswap32(pf0); }
+        else {
             const u32 *src = reinterpret_cast<const u32 *>(a.packed + bbase);
             const u64 left = a.packed_bytes - bbase;
             for (int i = tid; i < PARSE_WORDS; i += PARSE_THREADS) {
@@ -516,9 +519,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             u64 blast = bbase + PARSE_TILE / 4 - 1;
             if (blast >= a.packed_bytes) blast = a.packed_bytes - 1;
             const u64 idx = rb + tid;
-            const u64 off = (idx <= a.nreads) ? a.roff[idx] : RINF;
+            const u64 off = pf_have ? ((u64)pf0 | ((u64)pf1 << 32)) : ((idx <= a.nreads) ? a.roff[idx] : RINF);
             s_roff[tid] = off;
-            s_rlen[tid] = (idx < a.nreads) ? a.rlen[idx] : 0;
+            s_rlen[tid] = pf_have ? pf2 : ((idx < a.nreads) ? a.rlen[idx] : 0);
             const u32 c0 = (u32)__popcll(__ballot(idx < a.nreads && off <= bbase));
             const u32 c1 = (u32)__popcll(__ballot(idx < a.nreads && off <= blast));
             if (tid == 0) {
@@ -532,7 +535,21 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 if (a.tile_r0) a.tile_r0[tile] = (u32)r0;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        // the next tile's word and read-index entries are requested now and land in LDS at the top of the next round (every
+        // barrier of the loop is an LDS-only barrier: none of them waits for these loads or for the record stores)
+        {
+            const u64 nb = bbase + PARSE_TILE / 4;
+            pf_have = (ti + 1 < a.tiles_per_block) && (tile + 1 < a.ntiles) && (nb + (u64)PARSE_WORDS * 4 <= a.packed_bytes);
+            if (pf_have) {
+                if (tid < PARSE_RWIN) {
+                    const u64 idx = s_rng[1] + tid;                   // the read holding this tile's last byte is the next tile's first
+                    const u64 o_ = (idx <= a.nreads) ? a.roff[idx] : RINF;
+                    pf0 = (u32)o_; pf1 = (u32)(o_ >> 32);
+                    pf2 = (idx < a.nreads) ? a.rlen[idx] : 0;
+                } else if (tid < PARSE_RWIN + PARSE_WORDS) pf0 = reinterpret_cast<const u32 *>(a.packed + nb)[tid - PARSE_RWIN];
+            }
+        }
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[1] = t_; }
 #endif
@@ -559,7 +576,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 s_hash[scan_hidx(p)] = murmur64_8(tw < fw ? tw : fw);
             }
         }
-        __syncthreads();
+        lds_barrier();
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[2] = t_; }
 #endif
@@ -620,7 +637,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         }
         s_last[tid] = mn[PARSE_PPT - 1];
         s_v8[tid] = (u8)vmask;
-        __syncthreads();
+        lds_barrier();
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[3] = t_; }
 #endif
@@ -643,11 +660,11 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             s_bnd8[tid] = (u8)bnd8;
         }
         u32 nrec;
-        u32 off = block_excl_scan_256<u32>((u32)__popc(start8), s_scan, &nrec);   // (barriers inside: s_hash is free from here on)
+        u32 off = block_excl_scan_256_lds<u32>((u32)__popc(start8), s_scan, &nrec);   // (barriers inside: s_hash is free from here on)
 #pragma unroll
         for (int i = 0; i < PARSE_PPT; ++i)
             if ((start8 >> i) & 1) { s_hash[off] = mn[i]; s_plist[off] = (u16)(p0 + i); ++off; }
-        __syncthreads();
+        lds_barrier();
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[4] = t_; }
 #endif
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 if (nrec > a.rec_cap) atomicOr(a.overflow, 1u);
             }
         }
-        __syncthreads();
+        lds_barrier();
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[5] = t_; }
 #endif
