@@ -35,6 +35,7 @@ constexpr int XS_TILE = EXP_TILE;                     // supermers per tile: one
 constexpr int XS_RUN = 16;                            // k-mers per work item: nearly every supermer is one item (expand_kernel: 8)
 constexpr int XS_MAX_ITEMS = XS_TILE * (128 / XS_RUN);
 constexpr int XS_CHUNK = SortTile<1>::TILE;           // keys per chunk
+constexpr int XS_MAXSEG = 64;                        // segments (source ranks) whose tiles are looked up in LDS; more: no prefetch
 constexpr int XS_CLAIM = 4;                          // tiles per claim
 constexpr int XS_SPAN = 3;                            // chunks one reservation can touch
 constexpr u32 XS_SPIN_LIMIT = 1u << 22;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     __shared__ u32 s_dl[XS_SPAN][256];                                  // staged slot + s_dl[j][d] = slot in the chunk store (j-th chunk of the reservation)
     __shared__ u32 s_scr[XS_WAVES];
     __shared__ u32 s_blk[2];
+    __shared__ u64 s_seg[3][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile} of the task's segments
     typedef __attribute__((address_space(1))) u32 G32;
     const int tid = threadIdx.x;
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
@@ -107,10 +109,10 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     const int low = 64 - 2 * k;
     const u64 lastmask = ~0ULL << low;
     const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u;
-    const bool single = t.nseg == 1;                       // one segment (always on one GPU): the next tile's inputs are prefetched
+    const int nseg = t.nseg;
+    const bool segs_lds = nseg <= XS_MAXSEG;               // the next tile's inputs are prefetched (always on one GPU: one segment)
     const bool inplace = t.sm_gpos != nullptr;
-    const ExpSeg seg0 = t.segs[0];
-    const u64 s0_sup = seg0.sup_off, s0_n = seg0.n_sup;
+    if (segs_lds && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
     if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
 
     // Tiles are claimed in blocks of XS_CLAIM, two blocks ahead: the tile that follows the current one is always known,
@@ -122,11 +124,15 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     xs_barrier();
     u64 blk = s_blk[0], nblk = s_blk[1];
     u32 p_len = 0; u64 p_gpos = 0, p_raw[3] = {0, 0, 0}; bool p_have = false, p_win = false;
+    // lengths and positions of the tile's supermers (byte streams: the tile's input offset instead of the positions)
     auto prefetch_meta = [&](u64 tl) {
-        p_have = single && tl < t.ntiles; p_len = 0; p_gpos = 0;
+        p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0;
         if (p_have) {
-            const u64 sidx = tl * XS_TILE + tid;
-            if (sidx < s0_n) { p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx]; }
+            int sg = 0;
+            while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
+            const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
+            if (sidx < s_seg[1][sg]) { p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx]; }
+            if (!inplace) p_gpos = t.tile_off[2 * tl];
         }
     };
     auto prefetch_win = [&]() {                            // speculation: item `tid` of the tile is the start of supermer `tid`
@@ -146,14 +152,18 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         const u64 ntile = (j + 1 == (u32)XS_CLAIM) ? nblk : tile + 1;
         u32 claim = 0;
         if (j == 0 && tid == 0) claim = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        u64 sg_sup = seg0.sup_off, sg_n = seg0.n_sup, sg_t0 = seg0.tile_start;
-        if (!single) { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, t.nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; }
+        u64 sg_sup, sg_n, sg_t0;
+        if (segs_lds) {
+            int sg = 0;
+            while (sg + 1 < nseg && s_seg[2][sg + 1] <= tile) ++sg;
+            sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg];
+        } else { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; }
         const u64 first = (tile - sg_t0) * XS_TILE;
         const u32 ns = (u32)((sg_n - first) < (u64)XS_TILE ? (sg_n - first) : (u64)XS_TILE);
 
         // ---- prologue: thread s owns supermer s of the tile ---------------------------------------------------
         u32 len = p_len; u64 gp = p_gpos;
-        const bool have_win = p_win;
+        const bool have_win = p_win, had_meta = p_have;
         const u64 raw0 = p_raw[0], raw1 = p_raw[1], raw2 = p_raw[2];
         if (!p_have) {
             len = ((u32)tid < ns) ? t.sm_len[sg_sup + first + tid] : 0;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         if (inplace) s_gpos[tid] = gp;
         for (u32 q = 0; q < ni; ++q) s_isup[ei + q] = (u16)tid;
         if (tid == XS_THREADS - 1) { s_boff[XS_TILE] = eb + nb; s_koff[XS_TILE] = ek + nk; s_ioff[XS_TILE] = ei + ni; }
-        const u64 byte_abs = t.tile_off ? t.tile_off[2 * tile] : 0;
+        const u64 byte_abs = inplace ? 0 : (had_meta ? gp : t.tile_off[2 * tile]);
         xs_barrier();
         XS_STAMP(14);
 
