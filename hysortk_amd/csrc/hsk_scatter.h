@@ -110,9 +110,11 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     const u64 lastmask = ~0ULL << low;
     const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u;
     const int nseg = t.nseg;
-    const bool segs_lds = nseg <= XS_MAXSEG;               // the next tile's inputs are prefetched (always on one GPU: one segment)
+    const bool single = nseg == 1;                         // one GPU: one segment, kept in scalar registers
+    const bool segs_lds = nseg <= XS_MAXSEG;               // the next tile's inputs are prefetched
     const bool inplace = t.sm_gpos != nullptr;
-    if (segs_lds && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
+    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup;
+    if (!single && segs_lds && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
     if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
 
     // Tiles are claimed in blocks of XS_CLAIM, two blocks ahead: the tile that follows the current one is always known,
@@ -128,10 +130,15 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     auto prefetch_meta = [&](u64 tl) {
         p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0;
         if (p_have) {
-            int sg = 0;
-            while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
-            const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
-            if (sidx < s_seg[1][sg]) { p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx]; }
+            if (single) {
+                const u64 sidx = tl * XS_TILE + tid;
+                if (sidx < s0_n) { p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx]; }
+            } else {
+                int sg = 0;
+                while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
+                const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
+                if (sidx < s_seg[1][sg]) { p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx]; }
+            }
             if (!inplace) p_gpos = t.tile_off[2 * tl];
         }
     };
@@ -152,8 +159,9 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         const u64 ntile = (j + 1 == (u32)XS_CLAIM) ? nblk : tile + 1;
         u32 claim = 0;
         if (j == 0 && tid == 0) claim = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        u64 sg_sup, sg_n, sg_t0;
-        if (segs_lds) {
+        u64 sg_sup = s0_sup, sg_n = s0_n, sg_t0 = 0;
+        if (single) { }
+        else if (segs_lds) {
             int sg = 0;
             while (sg + 1 < nseg && s_seg[2][sg + 1] <= tile) ++sg;
             sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg];
