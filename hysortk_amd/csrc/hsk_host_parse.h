@@ -80,9 +80,16 @@ static bool parse_fast_enabled()
     static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
     return on;
 }
-static u32 parse_rec_cap()
+// Record slots per 2048-position tile.  A window of W k-mers starts a supermer every (W + 1) / 2 positions on random
+// sequence (+ one per 128 positions and per read): 40 % head room, a power of two from SCAN_REC_CAP (W >= 12) to 2048
+// (tiny windows); a tile that still overflows sends the parse through the general kernels.
+static u32 parse_rec_cap(int W)
 {
-    static const u32 cap = getenv("HSK_PARSE_REC_CAP") ? (u32)std::min(std::max(atoi(getenv("HSK_PARSE_REC_CAP")), 1), (int)PLACE_MAX_REC) : SCAN_REC_CAP;
+    static const int forced = getenv("HSK_PARSE_REC_CAP") ? std::min(std::max(atoi(getenv("HSK_PARSE_REC_CAP")), 1), (int)PLACE_MAX_REC) : 0;
+    if (forced) return (u32)forced;
+    const u32 need = (u32)(1.4 * (2.0 * PARSE_TILE / (W + 1) + 40));
+    u32 cap = SCAN_REC_CAP;
+    while (cap < need && cap < 2048) cap <<= 1;
     return cap;
 }
 
@@ -103,7 +110,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     u32 *h_ovf = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
     *h_ovf = 0;
     if (j.fast) {
-        a.rec_cap = parse_rec_cap();
+        a.rec_cap = parse_rec_cap(c->cfg.kmer_size - c->cfg.minimizer_size + 1);
         a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
         DALLOC(c, j.d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
         DALLOC(c, j.d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
