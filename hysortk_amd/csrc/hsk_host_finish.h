@@ -251,11 +251,14 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
     };
     memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
+    // bins of 6144 records and more on average (tasks far above 2^28 k-mers) rarely fit the small table: start with the large one
+    u64 nmax = 0; for (int i = 0; i < AG_BATCH; ++i) nmax = std::max(nmax, bt[i].n);
+    const bool large_first = !big && nmax / nbins >= 6144;
+    int rc = run(large_first ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL); if (rc) return rc;
     bool retry = false, done[AG_BATCH];
     u64 total[AG_BATCH];
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
-    if (retry && !big) {
+    if (retry && !big && !large_first) {
         // second chance with the large table for the tasks that overflowed
         AggArgs keep = a;
         for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
