@@ -315,6 +315,33 @@ def test_large_properties(H):
     assert np.array_equal(res.kmers, res2.kmers) and np.array_equal(res.cnt, res2.cnt)
 
 
+def test_full_size_properties_both_expand_paths():
+    """BASELINE.json configs[1] at full size (10 Gbp, 8.0e9 31-mers, 40 tasks of 2e8 k-mers): size-independent properties of the
+    unfiltered list -- checksum of counts = number of k-mers, histogram consistent, every task strictly ascending, low bits
+    clear -- and a checksum of checksums that must be identical with the expand fused into the first scatter pass (default)
+    and with expand + two passes (HSK_FUSED_SCATTER=0).  Subprocesses: the switch is read once, and each run holds 5 GB."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "G, RL = 312500000, 150; NR = G * 32 // RL\n"
+            "c = H.Context(K=31, M=17, L=1, U=65535, ntasks=0)\n"
+            "dp, nb, do, dl = c.synth_reads(G, RL, NR, 20251003)\n"
+            "r = c.count_device(dp, nb, do, dl, NR)\n"
+            "total = NR * (RL - 31 + 1)\n"
+            "assert r.info['total_kmers'] == total\n"
+            "k = r.kmers[:, 0]; cnt = r.cnt\n"
+            "assert int(cnt.sum(dtype=np.uint64)) == total\n"
+            "assert int((r.histo * np.arange(r.histo.size, dtype=np.uint64)).sum()) == total and int(r.histo.sum()) == len(k)\n"
+            "assert not np.any(k & np.uint64(3))\n"
+            "d = k[1:] > k[:-1]; starts = r.task_off[1:-1].astype(np.int64)\n"
+            "d[starts[(starts > 0) & (starts < len(k))] - 1] = True\n"
+            "assert bool(d.all())\n"
+            "h = int(np.bitwise_xor.reduce(k * np.uint64(0x9E3779B97F4A7C15) + cnt.astype(np.uint64)))\n"
+            "print(len(k), h, int(k.sum(dtype=np.uint64)), r.info['ntasks'], c.stats()['fused_tasks'])\n") % util.ROOT
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split() for env in ({}, {"HSK_FUSED_SCATTER": "0"})]
+    assert outs[0] == outs[1], outs
+    assert int(outs[0][0]) > 300_000_000 and int(outs[0][3]) == 40 and int(outs[0][4]) == 40
+
+
 # ---------------------------------------------------------------------------------------------------
 # hybrid sort + fused finish (8 tasks per launch): bins with one key, several keys, giant bins
 # ---------------------------------------------------------------------------------------------------
