@@ -278,7 +278,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = piped ? 2 : 1;
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
-    const bool xs = batch && !ext && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    // (EXTENSION: payload chunks beside the key chunks, HSK_FUSED_SCATTER_EXT=0 turns that variant off)
+    static const bool xs_ext_enabled = !(getenv("HSK_FUSED_SCATTER_EXT") && atoi(getenv("HSK_FUSED_SCATTER_EXT")) == 0);
+    const bool xs = batch && (!ext || xs_ext_enabled) && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
     ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
@@ -288,7 +290,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
             DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
             DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task) : max_task * NW) * 8 + 64);   // xs: the chunk store of the first pass
-            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, max_task * 8 + 64); }
+            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task) : max_task) * 8 + 64); }
         }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
@@ -352,7 +354,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         int rc;
         if (xs && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
             if constexpr (NW == 1) {
-                for (int i = 0; i < XCD_BATCH; ++i) jobs[i].keys = bts[sl][i].kB;
+                for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
                 rc = scatter_expand_batch(c, jobs, bts[sl], plan, sbatch[sl], xstream); if (rc) return rc;
             }

@@ -65,20 +65,25 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         t.tile_off = offsets ? x[xi[i]].d_tile_off : nullptr; t.ntiles = j.ts->ntiles;
         t.chunks = j.keys; t.cursor = sb.d_cursor + (size_t)i * 256; t.map = sb.d_map[i]; t.ctl = sb.d_ctl + (size_t)i * 4;
         t.ghist = j.ghist + 256; t.tile_src = sb.d_tile_src[i];
+        t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid; t.vchunks = j.vals;
         ntot += n;
     }
     a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.err = c->d_err;
-    static int occ = 0;
+    const bool ext = c->cfg.extension != 0;
+    static int occ_c[2] = {0, 0};
+    int &occ = occ_c[ext ? 1 : 0];
     if (!occ) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel, XS_THREADS, 0);
+        hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<true>, XS_THREADS, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<false>, XS_THREADS, 0);
         occ = (e == hipSuccess && nb > 0) ? nb : 2;
     }
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * (ext ? 16 : 8); (void)hipEventRecord(ep.a, stream); }
     // beside the sort of the previous batch (second stream): HSK_SCATTER_SHARE percent of the resident workgroups
     static const int share_pct = getenv("HSK_SCATTER_SHARE") ? atoi(getenv("HSK_SCATTER_SHARE")) : 100;
     const u32 grid = (stream != c->stream) ? std::max(8u, (u32)occ * 256u * (u32)share_pct / 100u) : (u32)occ * 256u;
-    hipLaunchKernelGGL(expand_scatter_kernel, dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    if (ext) hipLaunchKernelGGL(expand_scatter_kernel<true>, dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(expand_scatter_kernel<false>, dim3(grid), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     sb.active = true;
@@ -90,7 +95,8 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
 static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *plan, u64 *d_ghist, ScatterBatch &sb)
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
-    for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = bt[i].kA; bt[i].out_v = nullptr; }
+    const bool has_val = bt[0].vA != nullptr;
+    for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = bt[i].kA; bt[i].out_v = has_val ? bt[i].vA : nullptr; }
     if (!sb.active) return HSK_OK;
     std::vector<u64> hh((size_t)XCD_BATCH * MAX_PASSES * 256), cur((size_t)XCD_BATCH * 256), hb((size_t)XCD_BATCH * 256, 0);
     HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -128,15 +134,18 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
     MultiSortArgs ms; memset(&ms, 0, sizeof ms);
     for (int i = 0; i < XCD_BATCH; ++i) {
         SortArgs &a = ms.t[i];
-        a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.n = bt[i].n; a.ntiles = ntiles[i];
+        a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.vals_in = has_val ? bt[i].vB : nullptr; a.vals_out = has_val ? bt[i].vA : nullptr; a.n = bt[i].n; a.ntiles = ntiles[i];
         a.word = plan[1].word; a.shift = plan[1].shift; a.bits = plan[1].bits;
         a.unstable = unstable_first_pass() ? 1 : 0;     // a tile is a chunk of ONE first-pass digit: the order inside it is free, the look-back keeps the tiles in order
         a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lookback + lb_off[i];
         a.ticket = d_tickets + i; a.err = c->d_err; a.tile_src = sb.d_tile_src[i];
     }
     const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * 8; (void)hipEventRecord(ep.a, c->stream); }
-    if (max_tiles) { if (wide) launch_onesweep_multi<1, false, u64>(c, ms, grid); else launch_onesweep_multi<1, false, u32>(c, ms, grid); }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * (has_val ? 16 : 8); (void)hipEventRecord(ep.a, c->stream); }
+    if (max_tiles) {
+        if (has_val) { if (wide) launch_onesweep_multi<1, true, u64>(c, ms, grid); else launch_onesweep_multi<1, true, u32>(c, ms, grid); }
+        else { if (wide) launch_onesweep_multi<1, false, u64>(c, ms, grid); else launch_onesweep_multi<1, false, u32>(c, ms, grid); }
+    }
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     u32 tk[XCD_BATCH];

@@ -53,6 +53,8 @@ struct ScatterTask {
     u32 *ctl;                                        // [0] tile ticket, [1] chunks handed out (zeroed)
     u64 *ghist;                                      // [256] histogram of the second pass's digit (zeroed)
     u64 *tile_src;                                   // out (chunk_tiles_kernel): second-pass tiles
+    const u32 *sm_pos; const int32_t *sm_rid;        // EXTENSION: position in read and read id of every supermer
+    u64 *vchunks;                                    // EXTENSION: payload chunk store (same slots as `chunks`)
 };
 struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1; u32 *err; };     // shift0, shift1 >= 32 (the digits are in the top 16 bits)
 
@@ -83,6 +85,9 @@ __device__ unsigned long long g_xs_diag[16];
 #define XS_STAMP(i) do { } while (0)
 #endif
 
+// EXT: every k-mer carries pos | rid << 32 (reference include/kmer.hpp:350-360) = its item's base value + the round; the stage
+// keeps (lane, round) per slot and the lanes' base values sit in LDS, so the payload is rebuilt when the run is written.
+template <bool EXT>
 __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
 {
 #ifdef HSK_DIAG
@@ -95,6 +100,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     __shared__ u16 s_isup[XS_MAX_ITEMS];
     __shared__ u64 s_gpos[XS_TILE];
     __shared__ u64 s_stage[XS_CHUNK];
+    __shared__ u64 s_vb[EXT ? XS_THREADS : 1];
+    __shared__ u16 s_src[EXT ? XS_CHUNK : 1];
     __shared__ u32 s_cnt[256], s_start[256], s_split[256], s_hist[256];
     __shared__ u32 s_dl[XS_SPAN][256];                                  // staged slot + s_dl[j][d] = slot in the chunk store (j-th chunk of the reservation)
     __shared__ u32 s_scr[XS_WAVES];
@@ -125,19 +132,25 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     }
     xs_barrier();
     u64 blk = s_blk[0], nblk = s_blk[1];
-    u32 p_len = 0; u64 p_gpos = 0, p_raw[3] = {0, 0, 0}; bool p_have = false, p_win = false;
+    u32 p_len = 0; u64 p_gpos = 0, p_raw[3] = {0, 0, 0}, p_vb = 0; bool p_have = false, p_win = false;
     // lengths and positions of the tile's supermers (byte streams: the tile's input offset instead of the positions)
     auto prefetch_meta = [&](u64 tl) {
-        p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0;
+        p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0; p_vb = 0;
         if (p_have) {
             if (single) {
                 const u64 sidx = tl * XS_TILE + tid;
-                if (sidx < s0_n) { p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx]; }
+                if (sidx < s0_n) {
+                    p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx];
+                    if (EXT) p_vb = (u64)t.sm_pos[s0_sup + sidx] | ((u64)(u32)t.sm_rid[s0_sup + sidx] << 32);
+                }
             } else {
                 int sg = 0;
                 while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
                 const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
-                if (sidx < s_seg[1][sg]) { p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx]; }
+                if (sidx < s_seg[1][sg]) {
+                    p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx];
+                    if (EXT) p_vb = (u64)t.sm_pos[s_seg[0][sg] + sidx] | ((u64)(u32)t.sm_rid[s_seg[0][sg] + sidx] << 32);
+                }
             }
             if (!inplace) p_gpos = t.tile_off[2 * tl];
         }
@@ -172,6 +185,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         // ---- prologue: thread s owns supermer s of the tile ---------------------------------------------------
         u32 len = p_len; u64 gp = p_gpos;
         const bool have_win = p_win, had_meta = p_have;
+        u64 svb = p_vb;                                               // EXTENSION: base value of supermer `tid`
+        if (EXT && !p_have && (u32)tid < ns) svb = (u64)t.sm_pos[sg_sup + first + tid] | ((u64)(u32)t.sm_rid[sg_sup + first + tid] << 32);
         const u64 raw0 = p_raw[0], raw1 = p_raw[1], raw2 = p_raw[2];
         if (!p_have) {
             len = ((u32)tid < ns) ? t.sm_len[sg_sup + first + tid] : 0;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         xs_barrier();
         XS_STAMP(14);
 
-        u32 n_cnt = 0, n_sh = 0; u64 n_raw[3];
+        u32 n_cnt = 0, n_sh = 0; u64 n_raw[3], n_vb = 0;
         auto fetch = [&](u32 item) {
             n_cnt = 0; n_sh = 0; n_raw[0] = n_raw[1] = n_raw[2] = 0;
             if (item < toti) {
@@ -208,17 +223,19 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
 #pragma unroll
                 for (int x = 0; x < 3; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+                if (EXT) { const u64 sabs = sg_sup + first + sidx; n_vb = (u64)(t.sm_pos[sabs] + i0) | ((u64)(u32)t.sm_rid[sabs] << 32); }
             }
         };
         if (have_win && (ei == (u32)tid || (u32)tid >= toti)) {         // the speculation held for this lane (or it has no item)
             n_cnt = (u32)tid < toti ? (nk < (u32)XS_RUN ? nk : (u32)XS_RUN) : 0;
             n_sh = (u32)((t.src_bit0 + 2 * gp) & 63);
-            n_raw[0] = raw0; n_raw[1] = raw1; n_raw[2] = raw2;
+            n_raw[0] = raw0; n_raw[1] = raw1; n_raw[2] = raw2; n_vb = svb;
         } else fetch(tid);
         bool win_sent = false;
         XS_STAMP(0);                                                  // tile claim + prologue
         for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
             const u32 cnt = n_cnt;
+            if (EXT) s_vb[tid] = n_vb;                                // (the previous flush has been written: its last barrier is behind us)
             u64 win[2];
             {
                 u64 aw[3];
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 if ((u32)r >= cnt) continue;
                 const u32 pos = s_start[((u32)(key[r] >> 32) >> sh0) & 255u] + rk[r];
                 rk[r] = pos;                                           // position in the sorted order of the flush
-                if (pos < (u32)XS_CHUNK) s_stage[pos] = key[r];
+                if (pos < (u32)XS_CHUNK) { s_stage[pos] = key[r]; if (EXT) s_src[pos] = (u16)((tid << 4) | r); }
             }
             XS_STAMP(4);                                              // sync + permute
             if (tid < 256 && c) {
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 if (w0) {
 #pragma unroll
                     for (int r = 0; r < XS_RUN; ++r)
-                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) s_stage[rk[r] - w0] = key[r];
+                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) { s_stage[rk[r] - w0] = key[r]; if (EXT) s_src[rk[r] - w0] = (u16)((tid << 4) | r); }
                 }
                 xs_barrier();
                 const u32 wn = tot - w0 < (u32)XS_CHUNK ? tot - w0 : (u32)XS_CHUNK;
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                     const u32 g = w0 + i, sp = s_split[d];
                     const u32 o = g + (g < sp ? s_dl[0][d] : (g < sp + (u32)XS_CHUNK ? s_dl[1][d] : s_dl[2][d]));   // (mod 2^32)
                     t.chunks[o] = kk;
+                    if (EXT) { const u32 src = s_src[i]; t.vchunks[o] = s_vb[src >> 4] + (u64)(src & 15u); }
                 }
                 xs_barrier();                                      // the stage is rewritten by the next window / flush
             }

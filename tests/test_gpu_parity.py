@@ -626,6 +626,24 @@ def test_random_configurations_vs_oracle(H, O, seed):
             assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
 
 
+def test_extension_fused_scatter_equals_two_pass_path():
+    """EXTENSION through the expand fused with the first scatter pass (payload chunks beside the key chunks, default) and
+    through expand + two passes with payload (HSK_FUSED_SCATTER_EXT=0): same k-mers, counts, task offsets, and the same
+    payload multiset per k-mer (order inside one k-mer is free: an order-independent sum of hashed (pos, rid) pairs)."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "c = H.Context(K=31, M=17, L=2, U=60, EXT=1, ntasks=16)\n"
+            "dp, nb, do, dl = c.synth_reads(3000000, 150, 400000, 5)\n"
+            "r = c.count_device(dp, nb, do, dl, 400000, rid_base=7)\n"
+            "h = (r.pos.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (r.rid.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))\n"
+            "per = np.add.reduceat(h, r.payload_off[:len(r)].astype(np.int64)) if len(r) else h[:0]\n"
+            "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + per.tobytes()).hexdigest(), len(r), len(r.pos))\n") % util.ROOT
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+            for env in ({}, {"HSK_FUSED_SCATTER_EXT": "0"}, {"HSK_FUSED_SCATTER": "0"})]
+    assert outs[0] == outs[1] == outs[2], outs
+    assert int(outs[0][1]) > 100000 and int(outs[0][2]) > int(outs[0][1])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fused_scatter_sweep_vs_oracle(H, O, seed):
     """The benchmark path (one-word keys, no payload, whole batches of 8 tasks: expand fused with the first scatter pass,
