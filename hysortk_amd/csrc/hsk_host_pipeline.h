@@ -280,7 +280,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
     // (EXTENSION: payload chunks beside the key chunks, HSK_FUSED_SCATTER_EXT=0 turns that variant off)
     static const bool xs_ext_enabled = !(getenv("HSK_FUSED_SCATTER_EXT") && atoi(getenv("HSK_FUSED_SCATTER_EXT")) == 0);
-    const bool xs = batch && (!ext || xs_ext_enabled) && NW == 1 && scatter_enabled() && scatter_store_keys(max_task) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    static const bool xs_wide_enabled = !(getenv("HSK_FUSED_SCATTER_WIDE") && atoi(getenv("HSK_FUSED_SCATTER_WIDE")) == 0);      // two-word keys
+    constexpr int XS_CH = XsCfg<(NW <= 2 ? NW : 1)>::CHUNK;
+    const bool xs = batch && (NW == 1 ? (!ext || xs_ext_enabled) : (NW == 2 && !ext && xs_wide_enabled)) && scatter_enabled() &&
+                    scatter_store_keys(max_task, XS_CH) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
     ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
@@ -289,8 +292,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     if (max_task) {
         for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
             DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
-            DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task) : max_task * NW) * 8 + 64);   // xs: the chunk store of the first pass
-            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task) : max_task) * 8 + 64); }
+            DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * NW * 8 + 64);   // xs: the chunk store of the first pass
+            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
         }
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
@@ -353,10 +356,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         int rc;
         if (xs && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
-            if constexpr (NW == 1) {
+            if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
-                rc = scatter_expand_batch(c, jobs, bts[sl], plan, sbatch[sl], xstream); if (rc) return rc;
+                rc = scatter_expand_batch<NW>(c, jobs, bts[sl], plan, sbatch[sl], xstream); if (rc) return rc;
             }
         } else { rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc; }
         pt.end(PH_EXTRACT, xstream);
@@ -382,7 +385,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
-        if (sbatch[sl].active) { if constexpr (NW == 1) { int rc = sort_batch_prescattered(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
+        if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
         else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);

@@ -19,7 +19,7 @@ static bool scatter_enabled()
     return on;
 }
 // keys the chunk store of a task of n k-mers must hold (less than one chunk is wasted per digit)
-static size_t scatter_store_keys(u64 n) { return (size_t)(n / XS_CHUNK + 257) * XS_CHUNK; }
+static size_t scatter_store_keys(u64 n, int chunk) { return (size_t)(n / chunk + 257) * chunk; }
 
 static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
 {
@@ -30,8 +30,10 @@ static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
 
 // jobs[i] is the task XCD i expands (ts->ntiles == 0: none); its keys go to the chunk store jobs[i].keys, the histogram
 // of the second pass's digit to jobs[i].ghist + 256.  plan: the two 8-bit passes of the prefix plan.
+template <int NW>
 static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTask *bt, const PassDesc *plan, ScatterBatch &sb, hipStream_t stream)
 {
+    constexpr int XS_CHUNK = XsCfg<NW>::CHUNK;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     sb = ScatterBatch();
     ScatterArgs &a = sb.args; memset(&a, 0, sizeof a);
@@ -68,22 +70,26 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid; t.vchunks = j.vals;
         ntot += n;
     }
-    a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.err = c->d_err;
+    a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.chunk = XS_CHUNK; a.err = c->d_err;
     const bool ext = c->cfg.extension != 0;
-    static int occ_c[2] = {0, 0};
+    static int occ_c[2] = {0, 0};                             // (per instantiation of this template: per NW)
     int &occ = occ_c[ext ? 1 : 0];
     if (!occ) {
         int nb = 0;
-        hipError_t e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<true>, XS_THREADS, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<false>, XS_THREADS, 0);
+        hipError_t e;
+        if constexpr (NW == 1) e = ext ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<1, true>, XS_THREADS, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<1, false>, XS_THREADS, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<NW, false>, XS_THREADS, 0);
         occ = (e == hipSuccess && nb > 0) ? nb : 2;
     }
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * (ext ? 16 : 8); (void)hipEventRecord(ep.a, stream); }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * (ext ? 16 : 8 * NW); (void)hipEventRecord(ep.a, stream); }
     // beside the sort of the previous batch (second stream): HSK_SCATTER_SHARE percent of the resident workgroups
     static const int share_pct = getenv("HSK_SCATTER_SHARE") ? atoi(getenv("HSK_SCATTER_SHARE")) : 100;
     const u32 grid = (stream != c->stream) ? std::max(8u, (u32)occ * 256u * (u32)share_pct / 100u) : (u32)occ * 256u;
-    if (ext) hipLaunchKernelGGL(expand_scatter_kernel<true>, dim3(grid), dim3(XS_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL(expand_scatter_kernel<false>, dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    if constexpr (NW == 1) {
+        if (ext) hipLaunchKernelGGL((expand_scatter_kernel<1, true>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((expand_scatter_kernel<1, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    } else hipLaunchKernelGGL((expand_scatter_kernel<NW, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     sb.active = true;
@@ -92,8 +98,10 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
 
 // Second (stable) pass over a batch whose first pass was done by expand_scatter_kernel: input = the chunk stores bt[i].kB,
 // output = bt[i].kA.  d_ghist: [XCD_BATCH][MAX_PASSES][256], row 1 = the histogram of this pass's digit.
+template <int NW>
 static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *plan, u64 *d_ghist, ScatterBatch &sb)
 {
+    constexpr int XS_CHUNK = XsCfg<NW>::CHUNK;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const bool has_val = bt[0].vA != nullptr;
     for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = bt[i].kA; bt[i].out_v = has_val ? bt[i].vA : nullptr; }
@@ -141,10 +149,10 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
         a.ticket = d_tickets + i; a.err = c->d_err; a.tile_src = sb.d_tile_src[i];
     }
     const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * (has_val ? 16 : 8); (void)hipEventRecord(ep.a, c->stream); }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * (has_val ? 16 : 8 * NW); (void)hipEventRecord(ep.a, c->stream); }
     if (max_tiles) {
-        if (has_val) { if (wide) launch_onesweep_multi<1, true, u64>(c, ms, grid); else launch_onesweep_multi<1, true, u32>(c, ms, grid); }
-        else { if (wide) launch_onesweep_multi<1, false, u64>(c, ms, grid); else launch_onesweep_multi<1, false, u32>(c, ms, grid); }
+        if (has_val) { if (wide) launch_onesweep_multi<NW, true, u64>(c, ms, grid); else launch_onesweep_multi<NW, true, u32>(c, ms, grid); }
+        else { if (wide) launch_onesweep_multi<NW, false, u64>(c, ms, grid); else launch_onesweep_multi<NW, false, u32>(c, ms, grid); }
     }
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());

@@ -32,16 +32,20 @@ namespace hsk {
 constexpr int XS_THREADS = 512;
 constexpr int XS_WAVES = XS_THREADS / WAVE;
 constexpr int XS_TILE = EXP_TILE;                     // supermers per tile: one per thread (the tile lists are shared with expand_kernel)
-constexpr int XS_RUN = 16;                            // k-mers per work item: nearly every supermer is one item (expand_kernel: 8)
-constexpr int XS_MAX_ITEMS = XS_TILE * (128 / XS_RUN);
-constexpr int XS_CHUNK = SortTile<1>::TILE;           // keys per chunk
 constexpr int XS_MAXSEG = 64;                        // segments (source ranks) whose tiles are looked up in LDS; more: no prefetch
 constexpr int XS_CLAIM = 4;                          // tiles per claim
 constexpr int XS_SPAN = 3;                            // chunks one reservation can touch
 constexpr u32 XS_SPIN_LIMIT = 1u << 22;
+// per key width: k-mers per work item (one-word keys: 16, nearly every supermer is one item; two-word keys: 8, the keys of
+// an item stay in 32 registers either way), keys per chunk (= one tile of the second pass, 32 KB)
+template <int NW> struct XsCfg {
+    static constexpr int RUN = NW == 1 ? 16 : 8;
+    static constexpr int MAX_ITEMS = XS_TILE * (128 / RUN);
+    static constexpr int CHUNK = SortTile<NW>::TILE;
+    static_assert(XS_THREADS * RUN <= (XS_SPAN - 1) * CHUNK, "a reservation touches at most XS_SPAN chunks of a digit");
+    static_assert((CHUNK & (CHUNK - 1)) == 0, "chunk size is a power of two");
+};
 static_assert(XS_THREADS == XS_TILE, "one supermer per thread in the tile prologue");
-static_assert(XS_THREADS * XS_RUN <= (XS_SPAN - 1) * XS_CHUNK, "a reservation touches at most XS_SPAN chunks of a digit");
-static_assert((XS_CHUNK & (XS_CHUNK - 1)) == 0, "chunk size is a power of two");
 
 struct ScatterTask {
     const ExpSeg *segs; int nseg; u32 vmax;          // vmax: map entries per digit (n / XS_CHUNK + 1)
@@ -56,7 +60,7 @@ struct ScatterTask {
     const u32 *sm_pos; const int32_t *sm_rid;        // EXTENSION: position in read and read id of every supermer
     u64 *vchunks;                                    // EXTENSION: payload chunk store (same slots as `chunks`)
 };
-struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1; u32 *err; };     // shift0, shift1 >= 32 (the digits are in the top 16 bits)
+struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1, chunk; u32 *err; };     // shift0, shift1 >= 32 (the digits are in the top 16 bits)
 
 // Workgroup barrier for LDS traffic only: waits for the wave's LDS operations, not for its outstanding global loads, stores
 // and atomics (__syncthreads() drains those too, which would put every prefetch and the reservation round trip on the
@@ -87,9 +91,11 @@ __device__ unsigned long long g_xs_diag[16];
 
 // EXT: every k-mer carries pos | rid << 32 (reference include/kmer.hpp:350-360) = its item's base value + the round; the stage
 // keeps (lane, round) per slot and the lanes' base values sit in LDS, so the payload is rebuilt when the run is written.
-template <bool EXT>
+template <int NW, bool EXT>
 __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
 {
+    constexpr int XS_RUN = XsCfg<NW>::RUN, XS_MAX_ITEMS = XsCfg<NW>::MAX_ITEMS, XS_CHUNK = XsCfg<NW>::CHUNK;
+    static_assert(!(EXT && NW != 1), "the payload variant is built for one-word keys");
 #ifdef HSK_DIAG
     __shared__ unsigned long long xs_acc[16];                 // (LDS: sixteen 64-bit accumulators in registers would cost the kernel its occupancy)
     if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) xs_acc[i] = 0; xs_acc[15] = __builtin_amdgcn_s_memtime(); }
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     __shared__ u32 s_ioff[XS_TILE + 1];
     __shared__ u16 s_isup[XS_MAX_ITEMS];
     __shared__ u64 s_gpos[XS_TILE];
-    __shared__ u64 s_stage[XS_CHUNK];
+    __shared__ u64 s_stage[XS_CHUNK * NW];
     __shared__ u64 s_vb[EXT ? XS_THREADS : 1];
     __shared__ u16 s_src[EXT ? XS_CHUNK : 1];
     __shared__ u32 s_cnt[256], s_start[256], s_split[256], s_hist[256];
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     const ScatterTask &t = a.t[xcc];
     if (t.ntiles == 0) return;
     const int k = a.k;
-    const int low = 64 - 2 * k;
+    const int low = 64 * NW - 2 * k;                       // unused low bits of the last word
     const u64 lastmask = ~0ULL << low;
     const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u;
     const int nseg = t.nseg;
@@ -132,8 +138,10 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     }
     xs_barrier();
     u64 blk = s_blk[0], nblk = s_blk[1];
-    u32 p_len = 0; u64 p_gpos = 0, p_raw[3] = {0, 0, 0}, p_vb = 0; bool p_have = false, p_win = false;
+    u32 p_len = 0; u64 p_gpos = 0, p_raw[NW + 2], p_vb = 0; bool p_have = false, p_win = false;
     // lengths and positions of the tile's supermers (byte streams: the tile's input offset instead of the positions)
+#pragma unroll
+    for (int x = 0; x < NW + 2; ++x) p_raw[x] = 0;
     auto prefetch_meta = [&](u64 tl) {
         p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0; p_vb = 0;
         if (p_have) {
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         if (p_win) {
             const u64 wi = (t.src_bit0 + 2 * p_gpos) >> 6;
 #pragma unroll
-            for (int x = 0; x < 3; ++x) p_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+            for (int x = 0; x < NW + 2; ++x) p_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
         }
     };
     prefetch_meta(blk); prefetch_win();
@@ -187,7 +195,9 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         const bool have_win = p_win, had_meta = p_have;
         u64 svb = p_vb;                                               // EXTENSION: base value of supermer `tid`
         if (EXT && !p_have && (u32)tid < ns) svb = (u64)t.sm_pos[sg_sup + first + tid] | ((u64)(u32)t.sm_rid[sg_sup + first + tid] << 32);
-        const u64 raw0 = p_raw[0], raw1 = p_raw[1], raw2 = p_raw[2];
+        u64 rawp[NW + 2];
+#pragma unroll
+        for (int x = 0; x < NW + 2; ++x) rawp[x] = p_raw[x];
         if (!p_have) {
             len = ((u32)tid < ns) ? t.sm_len[sg_sup + first + tid] : 0;
             gp = (inplace && (u32)tid < ns) ? t.sm_gpos[sg_sup + first + tid] : 0;
@@ -211,9 +221,11 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         xs_barrier();
         XS_STAMP(14);
 
-        u32 n_cnt = 0, n_sh = 0; u64 n_raw[3], n_vb = 0;
+        u32 n_cnt = 0, n_sh = 0; u64 n_raw[NW + 2], n_vb = 0;
         auto fetch = [&](u32 item) {
-            n_cnt = 0; n_sh = 0; n_raw[0] = n_raw[1] = n_raw[2] = 0;
+            n_cnt = 0; n_sh = 0;
+#pragma unroll
+            for (int x = 0; x < NW + 2; ++x) n_raw[x] = 0;
             if (item < toti) {
                 const u32 sidx = s_isup[item];
                 const u32 i0 = (item - s_ioff[sidx]) * XS_RUN;
@@ -222,48 +234,64 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 const u64 bit = inplace ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
                 const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
 #pragma unroll
-                for (int x = 0; x < 3; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
+                for (int x = 0; x < NW + 2; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;
                 if (EXT) { const u64 sabs = sg_sup + first + sidx; n_vb = (u64)(t.sm_pos[sabs] + i0) | ((u64)(u32)t.sm_rid[sabs] << 32); }
             }
         };
         if (have_win && (ei == (u32)tid || (u32)tid >= toti)) {         // the speculation held for this lane (or it has no item)
             n_cnt = (u32)tid < toti ? (nk < (u32)XS_RUN ? nk : (u32)XS_RUN) : 0;
             n_sh = (u32)((t.src_bit0 + 2 * gp) & 63);
-            n_raw[0] = raw0; n_raw[1] = raw1; n_raw[2] = raw2; n_vb = svb;
+#pragma unroll
+            for (int x = 0; x < NW + 2; ++x) n_raw[x] = rawp[x];
+            n_vb = svb;
         } else fetch(tid);
         bool win_sent = false;
         XS_STAMP(0);                                                  // tile claim + prologue
         for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
             const u32 cnt = n_cnt;
             if (EXT) s_vb[tid] = n_vb;                                // (the previous flush has been written: its last barrier is behind us)
-            u64 win[2];
+            u64 win[NW + 1];
             {
-                u64 aw[3];
+                u64 aw[NW + 2];
 #pragma unroll
-                for (int x = 0; x < 3; ++x) aw[x] = __builtin_bswap64(n_raw[x]);
+                for (int x = 0; x < NW + 2; ++x) aw[x] = __builtin_bswap64(n_raw[x]);
 #pragma unroll
-                for (int x = 0; x < 2; ++x) win[x] = n_sh ? ((aw[x] << n_sh) | (aw[x + 1] >> (64 - n_sh))) : aw[x];
+                for (int x = 0; x < NW + 1; ++x) win[x] = n_sh ? ((aw[x] << n_sh) | (aw[x + 1] >> (64 - n_sh))) : aw[x];
             }
             if (it0 + XS_THREADS < toti) fetch(it0 + XS_THREADS + tid);
             // ---- roll the item's k-mers; rank every key inside its digit (arrival order: the pass is not stable) ----
-            u64 key[XS_RUN]; u32 rk[XS_RUN];
-            u64 fw = win[0] & lastmask;
-            Mer<1> f1; f1.w[0] = fw;
-            u64 rc = twin<1>(f1, k).w[0];
+            u64 key[XS_RUN][NW]; u32 rk[XS_RUN];
+            Mer<NW> fw, rc;
+#pragma unroll
+            for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
+            fw.w[NW - 1] &= lastmask;
+            rc = twin<NW>(fw, k);
 #pragma unroll
             for (int r = 0; r < XS_RUN; ++r) {
                 if (r > 0) {
-                    win[0] = (win[0] << 2) | (win[1] >> 62); win[1] <<= 2;
-                    fw = win[0] & lastmask;
-                    const u64 nbase = (fw >> low) & 3;
-                    rc = ((rc >> 2) | ((3 - nbase) << 62)) & lastmask;
+                    // one base further: window left by 2 bits; twin right by 2 bits, complement of the entering base on top
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) win[x] = (win[x] << 2) | (win[x + 1] >> 62);
+                    win[NW] <<= 2;
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
+                    fw.w[NW - 1] &= lastmask;
+                    const u64 nbase = (fw.w[NW - 1] >> low) & 3;
+#pragma unroll
+                    for (int x = NW - 1; x > 0; --x) rc.w[x] = (rc.w[x] >> 2) | (rc.w[x - 1] << 62);
+                    rc.w[0] = (rc.w[0] >> 2) | ((3 - nbase) << 62);
+                    rc.w[NW - 1] &= lastmask;
                 }
-                key[r] = 0; rk[r] = 0;
+#pragma unroll
+                for (int x = 0; x < NW; ++x) key[r][x] = 0;
+                rk[r] = 0;
                 if ((u32)r < cnt) {
-                    const u64 kk = rc < fw ? rc : fw;
-                    key[r] = kk;
-                    rk[r] = atomicAdd(&s_cnt[((u32)(kk >> 32) >> sh0) & 255u], 1u);
-                    atomicAdd(&s_hist[((u32)(kk >> 32) >> sh1) & 255u], 1u);
+                    const bool use_rc = mer_less<NW>(rc, fw);
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) key[r][x] = use_rc ? rc.w[x] : fw.w[x];
+                    const u32 hi = (u32)(key[r][NW - 1] >> 32);          // the digits are in the top 16 bits of the most significant word
+                    rk[r] = atomicAdd(&s_cnt[(hi >> sh0) & 255u], 1u);
+                    atomicAdd(&s_hist[(hi >> sh1) & 255u], 1u);
                 }
             }
             if (!win_sent) { prefetch_win(); win_sent = true; }       // the next tile's positions have arrived by now
@@ -287,9 +315,13 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
 #pragma unroll
             for (int r = 0; r < XS_RUN; ++r) {
                 if ((u32)r >= cnt) continue;
-                const u32 pos = s_start[((u32)(key[r] >> 32) >> sh0) & 255u] + rk[r];
+                const u32 pos = s_start[((u32)(key[r][NW - 1] >> 32) >> sh0) & 255u] + rk[r];
                 rk[r] = pos;                                           // position in the sorted order of the flush
-                if (pos < (u32)XS_CHUNK) { s_stage[pos] = key[r]; if (EXT) s_src[pos] = (u16)((tid << 4) | r); }
+                if (pos < (u32)XS_CHUNK) {
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) s_stage[pos * NW + x] = key[r][x];
+                    if (EXT) s_src[pos] = (u16)((tid << 4) | r);
+                }
             }
             XS_STAMP(4);                                              // sync + permute
             if (tid < 256 && c) {
@@ -323,16 +355,26 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 if (w0) {
 #pragma unroll
                     for (int r = 0; r < XS_RUN; ++r)
-                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) { s_stage[rk[r] - w0] = key[r]; if (EXT) s_src[rk[r] - w0] = (u16)((tid << 4) | r); }
+                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) {
+#pragma unroll
+                            for (int x = 0; x < NW; ++x) s_stage[(rk[r] - w0) * NW + x] = key[r][x];
+                            if (EXT) s_src[rk[r] - w0] = (u16)((tid << 4) | r);
+                        }
                 }
                 xs_barrier();
                 const u32 wn = tot - w0 < (u32)XS_CHUNK ? tot - w0 : (u32)XS_CHUNK;
                 for (u32 i = tid; i < wn; i += XS_THREADS) {
-                    const u64 kk = s_stage[i];
-                    const u32 d = ((u32)(kk >> 32) >> sh0) & 255u;
+                    u64 kw[NW];
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) kw[x] = s_stage[i * NW + x];
+                    const u32 d = ((u32)(kw[NW - 1] >> 32) >> sh0) & 255u;
                     const u32 g = w0 + i, sp = s_split[d];
                     const u32 o = g + (g < sp ? s_dl[0][d] : (g < sp + (u32)XS_CHUNK ? s_dl[1][d] : s_dl[2][d]));   // (mod 2^32)
-                    t.chunks[o] = kk;
+                    if (NW == 2) *reinterpret_cast<ulonglong2 *>(t.chunks + (u64)o * 2) = make_ulonglong2(kw[0], kw[NW - 1]);
+                    else {
+#pragma unroll
+                        for (int x = 0; x < NW; ++x) t.chunks[(u64)o * NW + x] = kw[x];
+                    }
                     if (EXT) { const u32 src = s_src[i]; t.vchunks[o] = s_vb[src >> 4] + (u64)(src & 15u); }
                 }
                 xs_barrier();                                      // the stage is rewritten by the next window / flush
@@ -363,12 +405,13 @@ __global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
     if (t.ntiles == 0) return;
     const int d = threadIdx.x;
     const u64 cnt = t.cursor[d];
-    const u64 nch = (cnt + XS_CHUNK - 1) / XS_CHUNK;
+    const u64 CH = (u64)a.chunk;
+    const u64 nch = (cnt + CH - 1) / CH;
     u64 off = block_excl_scan_256<u64>(nch, s_scr, nullptr);
     const u32 *mp = t.map + (u64)d * t.vmax;
     for (u64 v = 0; v < nch; ++v) {
-        const u64 left = cnt - v * XS_CHUNK;
-        t.tile_src[off + v] = ((u64)(mp[v] - 1) << 32) | (left < (u64)XS_CHUNK ? left : (u64)XS_CHUNK);
+        const u64 left = cnt - v * CH;
+        t.tile_src[off + v] = ((u64)(mp[v] - 1) << 32) | (left < CH ? left : CH);
     }
 }
 

@@ -644,6 +644,22 @@ def test_extension_fused_scatter_equals_two_pass_path():
     assert int(outs[0][1]) > 100000 and int(outs[0][2]) > int(outs[0][1])
 
 
+@pytest.mark.parametrize("K", [51, 41, 63])
+def test_two_word_keys_fused_scatter_equals_two_pass_path(K):
+    """32 < K < 64 through the fused expand + scatter (2048-key chunks of 16-byte keys, items of 8 k-mers; default) and through
+    expand + two passes (HSK_FUSED_SCATTER_WIDE=0): byte-identical lists."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "c = H.Context(K=%d, M=17, L=2, U=60, ntasks=16)\n"
+            "dp, nb, do, dl = c.synth_reads(3000000, 150, 400000, 5)\n"
+            "r = c.count_device(dp, nb, do, dl, 400000)\n"
+            "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r), c.stats()['fused_tasks'])\n") % (util.ROOT, K)
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+            for env in ({}, {"HSK_FUSED_SCATTER_WIDE": "0"})]
+    assert outs[0] == outs[1], outs
+    assert int(outs[0][1]) > 100000 and int(outs[0][2]) == 16
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fused_scatter_sweep_vs_oracle(H, O, seed):
     """The benchmark path (one-word keys, no payload, whole batches of 8 tasks: expand fused with the first scatter pass,
