@@ -1,28 +1,36 @@
-// hsk_scatter.h -- expand fused with the first scatter pass (one-word keys, no payload, aggregating finish).
+// hsk_scatter.h -- expand fused with the first scatter pass (aggregating finish; one-word keys with or without the
+// EXTENSION payload, two-word keys without).
 //
 // The two-pass prefix plan (hsk_host_sort.h) orders a task by its top 16 key bits: a first pass on the lower 8 of them,
-// whose output order inside a digit is free, and a stable second pass on the upper 8.  The first pass needs nothing but
-// the keys, so it runs where the keys are born: expand_scatter_kernel rolls the k-mers of a tile exactly like
+// whose output order inside a digit is free, and a second pass on the upper 8.  The first pass needs nothing but the
+// keys, so it runs where the keys are born: expand_scatter_kernel rolls the k-mers of a tile exactly like
 // expand_kernel (hsk_expand.h; reference GatheredSupermer::receive_from_buffer_stage2 src/kmerops.cpp:484-521) and,
 // instead of writing them in input order for a radix pass to read back, ranks them by digit in LDS and writes them
-// straight into the digit's bin: 16 bytes of HBM traffic per k-mer less (the key array written by the expand and read
-// by the first pass is never materialised).
+// straight into the digit's bin: two record sizes of HBM traffic per k-mer less (the key array written by the expand and
+// read by the first pass is never materialised).
 //
 // The digit histogram of the keys is not known before they exist, so a bin is not a pre-sized range but a LIST OF CHUNKS
-// of XS_CHUNK keys (= one tile of the second pass).  cursor[d] counts the keys reserved for digit d; a flush takes its
-// range [p, p + c) with one atomic add; virtual chunk v = p / XS_CHUNK of digit d lives in physical chunk map[d][v],
-// allocated (bump counter) by the one reservation that contains the chunk's first slot and published through the map;
-// everybody else whose range touches the chunk polls the map entry.  The allocator publishes before it waits for
-// anything, so the wait is bounded by one L2 round trip (and by XS_SPIN_LIMIT: error word, HSK_ERR_INTERNAL).
-// A task wastes less than one chunk per digit: the chunk store holds n / XS_CHUNK + 257 chunks.
+// of CHUNK keys (= one tile of the second pass: 4096 one-word, 2048 two-word keys).  cursor[d] counts the keys reserved
+// for digit d; a flush takes its range [p, p + c) with one atomic add; virtual chunk v = p / CHUNK of digit d lives in
+// physical chunk map[d][v], allocated (bump counter) by the one reservation that contains the chunk's first slot and
+// published through the map; everybody else whose range touches the chunk polls the map entry.  The allocator publishes
+// before it waits for anything, so the wait is bounded by one L2 round trip (and by XS_SPIN_LIMIT: error word,
+// HSK_ERR_INTERNAL).  A task wastes less than one chunk per digit: the chunk store holds n / CHUNK + 257 chunks.
 //
 // One task per XCD (HW_REG_XCC_ID, like onesweep_multi_kernel): cursors, map and chunk counter of a task are only ever
 // touched from one XCD, so their atomics execute in that XCD's L2 (workgroup-scope RMW, L1-bypassing polls), and the
 // short runs that neighbouring reservations of a digit write into the same 128-byte line merge in that L2 before they
 // go to HBM.  The host checks afterwards that the cursors add up to the task's k-mer count.
 //
+// The kernel is a chain of short dependent phases per tile (prologue, roll + rank, digit scan, reservation, permute, run
+// stores) on two 512-thread workgroups per CU.  What keeps the chain short: tiles are claimed two blocks ahead, so the
+// next tile's supermer lengths, positions and first windows are in flight while the current tile is worked on; every
+// barrier waits for LDS only (xs_barrier), so neither those loads nor the reservation atomic nor the run stores are
+// drained at a barrier; the reservation is resolved while the keys are permuted.
+//
 // chunk_tiles_kernel then lists the chunks in (digit, virtual chunk) order as the tiles of the second pass
-// (SortArgs::tile_src): tile = {physical chunk, keys in it}.
+// (SortArgs::tile_src): tile = {physical chunk, keys in it}.  A tile holds one first-pass digit, so the second pass may
+// rank its keys in any order too.
 #pragma once
 #include "hsk_expand.h"
 #include "hsk_sort.h"
@@ -48,10 +56,10 @@ template <int NW> struct XsCfg {
 static_assert(XS_THREADS == XS_TILE, "one supermer per thread in the tile prologue");
 
 struct ScatterTask {
-    const ExpSeg *segs; int nseg; u32 vmax;          // vmax: map entries per digit (n / XS_CHUNK + 1)
+    const ExpSeg *segs; int nseg; u32 vmax;          // vmax: map entries per digit (n / CHUNK + 1)
     const u8 *sm_len; const u64 *src8; u64 src_bit0, src_words;
     const u64 *sm_gpos; const u64 *tile_off; u64 ntiles;
-    u64 *chunks;                                     // chunk store
+    u64 *chunks;                                     // chunk store (records of NW words)
     u64 *cursor;                                     // [256] keys reserved per digit (zeroed)
     u32 *map;                                        // [256][vmax] physical chunk + 1 (zeroed)
     u32 *ctl;                                        // [0] tile ticket, [1] chunks handed out (zeroed)
