@@ -212,7 +212,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         }
         XS_STAMP(12);
         const u32 nb = ((u32)tid < ns) ? ((len + 3) >> 2) : 0;
-        const u32 nk = ((u32)tid < ns) ? (len - k + 1) : 0;
+        u32 nk = ((u32)tid < ns) ? (len - k + 1) : 0;
+        if (nk > 128u) { atomicOr(a.err, 4u); nk = 0; }               // not a supermer of this library (at most 128 k-mers, at least one): the item tables would overflow
         const u32 ni = (nk + XS_RUN - 1) / XS_RUN;
         u32 tot2;
         const u32 e2 = block_excl_scan_512((nk << 13) | ni, s_scr, &tot2);   // sums: items <= 4096, k-mers <= 65536
