@@ -804,16 +804,29 @@ __global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *rof
     }
 }
 
+// column sums of the COUNT matrix for task t; eight rows are requested before the first is added (one thread walks
+// ~1000 rows: a load per step would be a memory latency per row)
+__device__ __forceinline__ void col_sums(const u64 *blk_cnt, u32 nblocks, u32 ntasks, u32 t, u64 &s, u64 &b, u64 &k)
+{
+    constexpr int U = 8;
+    u32 blk = 0;
+    for (; blk + U <= nblocks; blk += U) {
+        u64 v[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const u64 *c = blk_cnt + ((u64)(blk + u) * ntasks + t) * 3; v[u][0] = c[0]; v[u][1] = c[1]; v[u][2] = c[2]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s += v[u][0]; b += v[u][1]; k += v[u][2]; }
+    }
+    for (; blk < nblocks; ++blk) { const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3; s += c[0]; b += c[1]; k += c[2]; }
+}
+
 // task_tot[t][3] = column sums of the COUNT matrix (supermers, bytes, k-mers of task t on this rank)
 __global__ void task_totals_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, u64 *task_tot)
 {
     const u32 t = threadIdx.x;
     if (t >= ntasks) return;
     u64 s = 0, b = 0, k = 0;
-    for (u32 blk = 0; blk < nblocks; ++blk) {
-        const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
-        s += c[0]; b += c[1]; k += c[2];
-    }
+    col_sums(blk_cnt, nblocks, ntasks, t, s, b, k);
     task_tot[3 * t] = s; task_tot[3 * t + 1] = b; task_tot[3 * t + 2] = k;
 }
 
@@ -828,10 +841,7 @@ __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, c
     const bool live = t < ntasks && !(skip && skip[t]);      // skipped tasks take no room
     if (t < ntasks) {
         u64 s = 0, b = 0, k = 0;
-        if (live) for (u32 blk = 0; blk < nblocks; ++blk) {
-            const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
-            s += c[0]; b += c[1]; k += c[2];
-        }
+        if (live) col_sums(blk_cnt, nblocks, ntasks, t, s, b, k);
         s_tot[3 * t] = s; s_tot[3 * t + 1] = b; s_tot[3 * t + 2] = k;
         task_tot[3 * t] = s; task_tot[3 * t + 1] = b; task_tot[3 * t + 2] = k;
     }
@@ -847,7 +857,20 @@ __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, c
     __syncthreads();
     if (t < ntasks) {
         u64 s = task_base[3 * t], b = task_base[3 * t + 1];
-        for (u32 blk = 0; blk < nblocks; ++blk) {
+        constexpr int U = 8;
+        u32 blk = 0;
+        for (; blk + U <= nblocks; blk += U) {
+            u64 v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const u64 *c = blk_cnt + ((u64)(blk + u) * ntasks + t) * 3; v[u][0] = c[0]; v[u][1] = c[1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                u64 *o = blk_base + ((u64)(blk + u) * ntasks + t) * 2;
+                o[0] = s; o[1] = b;
+                if (live) { s += v[u][0]; b += v[u][1]; }
+            }
+        }
+        for (; blk < nblocks; ++blk) {
             const u64 *c = blk_cnt + ((u64)blk * ntasks + t) * 3;
             u64 *o = blk_base + ((u64)blk * ntasks + t) * 2;
             o[0] = s; o[1] = b;
