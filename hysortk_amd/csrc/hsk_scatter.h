@@ -418,7 +418,19 @@ __global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
     const u64 nch = (cnt + CH - 1) / CH;
     u64 off = block_excl_scan_256<u64>(nch, s_scr, nullptr);
     const u32 *mp = t.map + (u64)d * t.vmax;
-    for (u64 v = 0; v < nch; ++v) {
+    constexpr int U = 8;                                          // map entries requested per step (a load per step is a latency per chunk)
+    u64 v = 0;
+    for (; v + U <= nch; v += U) {
+        u32 ph[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ph[u] = mp[v + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 left = cnt - (v + u) * CH;
+            t.tile_src[off + v + u] = ((u64)(ph[u] - 1) << 32) | (left < CH ? left : CH);
+        }
+    }
+    for (; v < nch; ++v) {
         const u64 left = cnt - v * CH;
         t.tile_src[off + v] = ((u64)(mp[v] - 1) << 32) | (left < CH ? left : CH);
     }
