@@ -121,6 +121,46 @@ def cpu_baseline(ctx, genome_len, nreads, seed, ncores):
     return port
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this process (which has imported neither torch nor anything that
+    touches HIP) starts the N ranks as a FRESH child -- python -m torch.distributed.run, one process per GPU -- relays
+    rank 0's JSON line and returns the child's exit code."""
+    probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        ndev = int(probe.stdout.strip().splitlines()[-1])
+    except Exception:
+        ndev = 0
+    if ndev < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d MI355X, this machine shows %d HIP device(s); there is no CPU fallback\n" % (a.gpus, a.gpus, ndev))
+        return 2
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line:
+        print(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 3
+    return rc
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -128,9 +168,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("HSK_FORCE_DEVICE") is not None:          # debugging aid: several ranks on one GPU
         local = int(os.environ["HSK_FORCE_DEVICE"])
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))                                # one command runs all ranks (reference: mpiexec -n N ./hysortk, README.md:39)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
         a.gpus = world
     import torch
     import hysortk_amd as H

@@ -48,7 +48,7 @@ UNIQUE_ID_BYTES = 128
 
 # every symbol include/hsk.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
-    "hsk_abi_version", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
+    "hsk_abi_version", "hsk_device_count", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
     "hsk_count", "hsk_count_device", "hsk_count_loopback", "hsk_result_free", "hsk_result_device_task", "hsk_format_entries", "hsk_get_stats",
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
     "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
@@ -79,6 +79,7 @@ def load():
     L = C.CDLL(path)
     vp, u64p = C.c_void_p, C.c_void_p
     L.hsk_abi_version.restype = C.c_int
+    L.hsk_device_count.restype = C.c_int
     L.hsk_init.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.hsk_destroy.argtypes = [vp]
     L.hsk_destroy.restype = None

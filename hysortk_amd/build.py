@@ -1,4 +1,5 @@
 """Builds libhsk.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc."""
+import fcntl
 import os
 import subprocess
 
@@ -19,14 +20,29 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Several ranks may get here at once (torchrun): one
+    of them compiles -- into a temporary file that is renamed over libhsk.so, so nobody ever maps a half-written
+    library -- while the others wait on the lock and then find the library up to date."""
     if not force and not needs_build():
         return LIB
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB,
-           os.path.join(SRC_DIR, "hsk_api.hip"), "-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # somebody else built it while we waited
+                return LIB
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp,
+                   os.path.join(SRC_DIR, "hsk_api.hip"), "-ldl"]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -46,6 +46,13 @@ using namespace hsk;
 // ------------------------------------------------------------------------------------------------
 extern "C" int hsk_abi_version(void) { return HSK_ABI_VERSION; }
 
+extern "C" int hsk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 extern "C" const char *hsk_strerror(int s)
 {
     switch (s) {
@@ -124,6 +131,20 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
     c->d_err = (u32 *)c->pool.alloc(256);
     if (!c->d_err) { delete c; return HSK_ERR_OOM; }
     (void)hipMemsetAsync(c->d_err, 0, 256, c->stream);
+    {   // XCD census: words 16..31 of the error block are scratch here
+        u32 *d_cnt = c->d_err + 16, h_cnt[16] = {0};
+        hipLaunchKernelGGL(xcc_census_kernel, dim3(4096), dim3(64), 0, c->stream, d_cnt);
+        if (hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            hsk_destroy(c); return HSK_ERR_HIP;
+        }
+        (void)hipMemsetAsync(d_cnt, 0, sizeof h_cnt, c->stream);
+        int seen = 0; u32 lo = ~0u;
+        for (int i = 0; i < 8; ++i) { if (h_cnt[i]) ++seen; lo = std::min(lo, h_cnt[i]); }
+        for (int i = 8; i < 16; ++i) if (h_cnt[i]) seen = -100;
+        // every XCD must get a fair share of a round-robin launch (4096 workgroups: 512 each)
+        c->xcd_batch_ok = seen == 8 && lo >= 256;
+        if (getenv("HSK_FORCE_NO_XCD") && atoi(getenv("HSK_FORCE_NO_XCD")) != 0) c->xcd_batch_ok = false;      // test hook
+    }
     *out = c;
     return HSK_OK;
 }

@@ -14,35 +14,52 @@ namespace hsk {
 
 constexpr int HV_THREADS = 256;
 
-// entries {key, count} -> keys[], counts[]
+// entries {key words, count} -> keys[] (NW words each), counts[]
+template <int NW>
 __global__ __launch_bounds__(HV_THREADS) void heavy_split_kernel(const u64 *entries, u64 n, u64 *keys, u64 *cnts)
 {
     const u64 stride = (u64)gridDim.x * HV_THREADS;
-    for (u64 i = (u64)blockIdx.x * HV_THREADS + threadIdx.x; i < n; i += stride) { keys[i] = entries[2 * i]; cnts[i] = entries[2 * i + 1]; }
+    for (u64 i = (u64)blockIdx.x * HV_THREADS + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int x = 0; x < NW; ++x) keys[i * NW + x] = entries[(NW + 1) * i + x];
+        cnts[i] = entries[(NW + 1) * i + NW];
+    }
 }
 
 struct HeavyMergeArgs {
-    const u64 *keys, *cnts; u64 n;      // sorted by key
+    const u64 *keys, *cnts; u64 n;      // sorted by key (records of NW words)
     u64 lower, upper;
     u64 *tile_cnt;                      // COUNT out / EMIT in (exclusive offsets)
-    u64 *entries;                       // EMIT: {key, summed count}
+    u64 *entries;                       // EMIT: {key words, summed count}
     u64 *histo; u32 histo_len;
 };
 
+template <int NW>
+__device__ __forceinline__ bool heavy_same(const u64 *keys, u64 i, const u64 (&k)[NW])
+{
+    bool eq = true;
+#pragma unroll
+    for (int x = 0; x < NW; ++x) eq = eq && keys[i * NW + x] == k[x];
+    return eq;
+}
+
 // one record per lane and tile of 256 records: a run head sums its run (<= nranks records), kept heads are
 // compacted with a block scan: the output stays in key order
-template <bool EMIT>
+template <int NW, bool EMIT>
 __global__ __launch_bounds__(HV_THREADS) void heavy_merge_kernel(HeavyMergeArgs a)
 {
     __shared__ u32 s_scr[8];
     const u64 i = (u64)blockIdx.x * HV_THREADS + threadIdx.x;
-    u64 key = 0, sum = 0; bool keep = false;
+    u64 key[NW], sum = 0; bool keep = false;
+#pragma unroll
+    for (int x = 0; x < NW; ++x) key[x] = 0;
     if (i < a.n) {
-        key = a.keys[i];
-        const bool head = (i == 0) || (a.keys[i - 1] != key);
+#pragma unroll
+        for (int x = 0; x < NW; ++x) key[x] = a.keys[i * NW + x];
+        const bool head = (i == 0) || !heavy_same<NW>(a.keys, i - 1, key);
         if (head) {
             sum = a.cnts[i];
-            for (u64 j = i + 1; j < a.n && a.keys[j] == key; ++j) sum += a.cnts[j];
+            for (u64 j = i + 1; j < a.n && heavy_same<NW>(a.keys, j, key); ++j) sum += a.cnts[j];
             keep = sum >= a.lower && sum <= a.upper;
         }
     }
@@ -51,7 +68,9 @@ __global__ __launch_bounds__(HV_THREADS) void heavy_merge_kernel(HeavyMergeArgs 
     if (!EMIT) { if (threadIdx.x == 0) a.tile_cnt[blockIdx.x] = tot; return; }
     if (keep) {
         const u64 e = a.tile_cnt[blockIdx.x] + o;
-        a.entries[2 * e] = key; a.entries[2 * e + 1] = sum;
+#pragma unroll
+        for (int x = 0; x < NW; ++x) a.entries[(NW + 1) * e + x] = key[x];
+        a.entries[(NW + 1) * e + NW] = sum;
         if (sum < a.histo_len) atomicAdd((unsigned long long *)&a.histo[sum], 1ULL);
     }
 }

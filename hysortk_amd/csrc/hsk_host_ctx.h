@@ -67,6 +67,7 @@ struct hsk_ctx {
     void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
     u32 *d_err = nullptr;
     Comm comm;
+    bool xcd_batch_ok = true;          // hsk_init's census saw workgroups on all eight XCC ids (see xcc_census_kernel)
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 

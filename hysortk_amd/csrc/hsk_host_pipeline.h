@@ -130,16 +130,17 @@ static bool overlap_enabled()
 // ---- heavy-hitter tasks (a8): the owner's side --------------------------------------------------------------
 // d_entries: the {k-mer, count} lists of all ranks for one task, concatenated (n entries, each list key-ordered,
 // a key at most once per list).  Orders them by key with the count as payload, sums equal keys, filters [L, U].
+template <int NW>
 static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_histo, u32 histo_len, TaskOut &out)
 {
     out = TaskOut();
     if (n == 0) return HSK_OK;
     u64 *kA, *kB, *vA, *vB;
-    DALLOC(c, kA, u64 *, n * 8 + 64); DALLOC(c, kB, u64 *, n * 8 + 64); DALLOC(c, vA, u64 *, n * 8 + 64); DALLOC(c, vB, u64 *, n * 8 + 64);
-    hipLaunchKernelGGL(heavy_split_kernel, dim3((u32)std::min<u64>((n + HV_THREADS - 1) / HV_THREADS, 4096)), dim3(HV_THREADS), 0, c->stream, d_entries, n, kA, vA);
+    DALLOC(c, kA, u64 *, n * NW * 8 + 64); DALLOC(c, kB, u64 *, n * NW * 8 + 64); DALLOC(c, vA, u64 *, n * 8 + 64); DALLOC(c, vB, u64 *, n * 8 + 64);
+    hipLaunchKernelGGL(heavy_split_kernel<NW>, dim3((u32)std::min<u64>((n + HV_THREADS - 1) / HV_THREADS, 4096)), dim3(HV_THREADS), 0, c->stream, d_entries, n, kA, vA);
     SortScratch sc; int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     u64 *sk, *sv;
-    rc = sort_task_device<1>(c, kA, kB, vA, vB, n, c->cfg.kmer_size, sc, &sk, &sv);
+    rc = sort_task_device<NW>(c, kA, kB, vA, vB, n, c->cfg.kmer_size, sc, &sk, &sv);
     free_sort_scratch(c, sc);
     if (rc) return rc;
     const u64 ntiles = (n + HV_THREADS - 1) / HV_THREADS;
@@ -147,16 +148,16 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
     DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
     HeavyMergeArgs a; memset(&a, 0, sizeof a);
     a.keys = sk; a.cnts = sv; a.n = n; a.lower = (u64)c->cfg.lower_freq; a.upper = (u64)c->cfg.upper_freq; a.tile_cnt = d_tile; a.histo = d_histo; a.histo_len = histo_len;
-    hipLaunchKernelGGL(heavy_merge_kernel<false>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL((heavy_merge_kernel<NW, false>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
     u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
     HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out.n = tot[0];
     if (out.n) {
-        DALLOC(c, out.entries, u64 *, out.n * 16);
+        DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
         a.entries = out.entries;
-        hipLaunchKernelGGL(heavy_merge_kernel<true>, dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((heavy_merge_kernel<NW, true>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -190,7 +191,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
     // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
     // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
-    static const bool batch_enabled = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    static const bool batch_env = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    const bool batch_enabled = batch_env && c->xcd_batch_ok;          // the one-task-per-XCD kernels need all eight XCDs (hsk_init's census)
     std::vector<u32> mine;
     for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
     // A remainder of three or more tasks is padded to a full batch with empty slots (an XCD without a task idles, which
@@ -445,7 +447,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     if (ex && ex->heavy_in) {
         pt.begin(PH_COUNT);
         for (const HeavyIn &hv : *ex->heavy_in) {
-            if constexpr (NW == 1) { int rc = heavy_merge_task(c, hv.d_entries, hv.n, d_histo, histo_len, touts[hv.task]); if (rc) return rc; }
+            { int rc = heavy_merge_task<NW>(c, hv.d_entries, hv.n, d_histo, histo_len, touts[hv.task]); if (rc) return rc; }
             mine.push_back(hv.task);
         }
         pt.end(PH_COUNT);
@@ -509,13 +511,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
 }
 
 // ---- heavy-hitter tasks (a8): the sending side ----------------------------------------------------------------
-// HeavyHitterClassifier (reference src/kmerops.cpp:1157-1199) on the GLOBAL k-mer counts; forced plain with
-// EXTENSION or PLAIN_CLASSIFIER (kmerops.cpp:109-113) and, here, for keys of more than one word.
-static bool heavy_enabled(hsk_ctx *c, int nw, int nranks)
+// HeavyHitterClassifier (reference src/kmerops.cpp:1157-1199) on the GLOBAL k-mer counts, for every key width (the
+// reference's ScatteredKmerList is generic over TKmer, kmerops.cpp:363-401); forced plain with EXTENSION or
+// PLAIN_CLASSIFIER (kmerops.cpp:109-113).
+static bool heavy_enabled(hsk_ctx *c, int /*nw*/, int nranks)
 {
     static const bool env_on = !(getenv("HSK_HEAVY") && atoi(getenv("HSK_HEAVY")) == 0);
-    return env_on && nranks > 1 && nw == 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0 &&
-           hybrid_enabled() && finish_enabled() && agg_enabled();
+    return env_on && nranks > 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0;
 }
 static double heavy_ratio() { static const double r = getenv("HSK_UNBALANCED_RATIO") ? atof(getenv("HSK_UNBALANCED_RATIO")) : 2.3; return r; }
 

@@ -300,6 +300,14 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(SortArgs a)
 struct MultiSortArgs { SortArgs t[8]; };
 constexpr unsigned XCC_ID_GETREG = 20u | (0u << 6) | (3u << 11);     // HW_REG_XCC_ID, bits [3:0]
 
+// Census for hsk_init: how many workgroups of a plain launch land on each XCC id.  The batch kernels (one task per
+// XCD) need all eight ids to show up; on a partitioned device (CPX / DPX / QPX), under a CU mask or on any other
+// placement they are switched off and every task takes the placement-independent single-task kernels.
+__global__ void xcc_census_kernel(u32 *cnt)
+{
+    if (threadIdx.x == 0) atomicAdd(&cnt[__builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 15u], 1u);
+}
+
 template <int NW, bool HAS_VAL, typename LB>
 __global__ __launch_bounds__(SORT_THREADS) void onesweep_multi_kernel(MultiSortArgs m)
 {

@@ -123,6 +123,7 @@ typedef struct {
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int  hsk_abi_version(void);
+int  hsk_device_count(void);                       /* HIP devices visible to this process (0 if none / no driver) */
 int  hsk_init(const hsk_config *cfg, hsk_ctx **out);
 void hsk_destroy(hsk_ctx *ctx);
 const char *hsk_strerror(int status);

@@ -29,12 +29,15 @@ namespace hysortk {
 
 namespace detail {
 
-struct Ranks { int rank = 0, size = 1; };
+struct Ranks { int rank = 0, size = 1, local = 0; };       // local: rank among the processes of this node (one GPU each)
 inline Ranks ranks_of(MPI_Comm comm)
 {
     Ranks r;
 #ifdef HSK_WITH_MPI
     MPI_Comm_rank(comm, &r.rank); MPI_Comm_size(comm, &r.size);
+    MPI_Comm node;
+    if (MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, r.rank, MPI_INFO_NULL, &node) == MPI_SUCCESS) { MPI_Comm_rank(node, &r.local); MPI_Comm_free(&node); }
+    else r.local = r.rank;
 #else
     (void)comm;
 #endif
@@ -62,10 +65,11 @@ inline hsk_ctx *context(MPI_Comm comm)
 #ifdef PLAIN_DISPATCHER
     cfg.plain_dispatcher = PLAIN_DISPATCHER;
 #endif
-    int ndev = 1;
+    int ndev = hsk_device_count();                               // GPUs this process can see (0: hsk_init reports HSK_ERR_NO_DEVICE)
     if (const char *e = std::getenv("HSK_GPUS_PER_NODE")) ndev = std::max(1, atoi(e));
-    else if (r.size > 1) ndev = 8;
-    cfg.device = r.rank % ndev;                                  // one rank per GPU
+    if (ndev > 0 && r.size > ndev && r.local >= ndev)
+        throw std::runtime_error("more ranks on this node than GPUs: one rank per GPU (RCCL does not share a device between ranks)");
+    cfg.device = ndev > 0 ? r.local % ndev : 0;                  // one rank per GPU, by node-local rank
     check(hsk_init(&cfg, &ctx), nullptr, "hsk_init");
 #ifdef HSK_WITH_MPI
     if (r.size > 1) {

@@ -1,0 +1,43 @@
+"""Worker of tests/test_gpu_rccl.py: one of WORLD_SIZE processes, one GPU each.  Runs the PRODUCT path end to end --
+hsk_comm_init (RCCL communicator; the id travels over a gloo group) and hsk_count on this rank's share of the reads --
+and dumps the rank's list.  Nothing here touches the oracle: the parent test compares."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import hysortk_amd as H  # noqa: E402
+from hysortk_amd import dist as hdist  # noqa: E402
+
+
+def main():
+    spec = json.loads(sys.argv[1])
+    comm = hdist.Comm(backend="gloo")
+    rank, size = comm.rank, comm.size
+    seqs = json.load(open(spec["reads"]))
+    counts = H.plan_partition_reads([len(s) for s in seqs], size)          # FastaIndex::getpartition
+    first = int(counts[:rank].sum())
+    mine = seqs[first:first + int(counts[rank])]
+    dna = H.DnaBuffer.from_sequences(mine)
+    rid_base = comm.exscan_sum(dna.size())
+    assert rid_base == first
+    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], EXT=spec["EXT"], ntasks=spec["ntasks"], device=comm.local_rank)
+    ctx.comm_init(comm)
+    res = ctx.count(dna, rid_base=rid_base)
+    st = ctx.stats()
+    out = dict(kmers=res.kmers, cnt=res.cnt, task_off=res.task_off, histo=res.histo, heavy=np.array([st["heavy_tasks"]]),
+               total_kmers=np.array([res.info["total_kmers"]]))
+    if spec["EXT"]:
+        out.update(payload_off=res.payload_off, pos=res.pos, rid=res.rid)
+    np.savez(spec["out"] % rank, **out)
+    ctx.close()
+    comm.barrier()
+    comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

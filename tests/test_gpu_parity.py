@@ -240,6 +240,54 @@ def test_edge_cases(H, O):
             assert res.info["total_kmers"] == ores.stats["total_kmers"], name
 
 
+def _random_record(seed, n):
+    codes = np.random.Generator(np.random.PCG64(seed)).integers(0, 4, size=n, dtype=np.uint8)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes().decode()
+
+
+@pytest.mark.parametrize("ntasks", [5, 0])
+def test_s_ecoli_single_record(H, O, ntasks):
+    """BASELINE.json configs[0] (S-ecoli stand-in): ONE record of 4 641 652 uniform random bases
+    (PCG64 seed 42), K=31 M=17 L=1 U=65535 -> N = 4 641 622 k-mers, every one of them once: histogram text
+    "#count\tnumkmers\n1\t4641622\n\n" as the reference prints it (src/hysortk.cpp:122-131).  One read spans ~2270 parse
+    tiles and ~9000 supermer cuts; ntasks = 5 is the reference's own task count for 1 rank x 8 threads."""
+    seq = _random_record(42, 4_641_652)
+    dna = H.DnaBuffer.from_sequences([seq])
+    packed, off, lens = dna.arrays()
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=ntasks) as c:
+        res = c.count(dna)
+    assert res.info["total_kmers"] == 4_641_622
+    assert H.histogram_text(res.histo) == "#count\tnumkmers\n1\t4641622\n\n"
+    assert len(res) == 4_641_622 and int(res.cnt.sum()) == 4_641_622
+    ores = O.count(packed, off, lens, k=31, m=17, L=1, U=65535, ntasks=res.info["ntasks"], fast=True)
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+
+
+@pytest.mark.parametrize("ntasks", [1, 5, 40])
+def test_long_records_and_tile_edges(H, O, ntasks):
+    """Mbp-long records: a record that ends exactly on a 2048-position parse tile edge (the next one starts on it), a 1 Mbp
+    record, one that is a repeat of the first (counts of 2), a record shorter than K between them, and a last record that
+    ends exactly at the end of a tile; single-task path, padded batch and full batches."""
+    a = _random_record(7, 2048 * 489)                       # 1 001 472 bases: ends on a tile edge (records are byte-aligned)
+    b = _random_record(8, 1_000_000)
+    reads = [a, b, "ACGTACGTACGT", a[1000:300000]]
+    pre = sum((len(r) + 3) // 4 for r in reads)             # bytes in front of the last record
+    reads.append(_random_record(9, 4 * ((-pre) % 512 + 1024)))
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    assert (int(off[1]) * 4) % 2048 == 0 and (packed.size * 4) % 2048 == 0
+    ores = O.count(packed, off, lens, k=31, m=17, L=1, U=65535, ntasks=ntasks, fast=True)
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=ntasks) as c:
+        res = c.count(dna)
+    assert res.info["total_kmers"] == sum(max(0, len(r) - 30) for r in reads)
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert int(res.histo[2]) >= 299000 - 30
+
+
 def test_invalid_config_is_rejected(H):
     for kw in (dict(K=32), dict(K=2), dict(K=96), dict(M=31, K=31), dict(L=0), dict(L=5, U=4), dict(U=70000), dict(EXT=2)):
         with pytest.raises(H.HskError):
@@ -447,7 +495,7 @@ def test_fused_finish_equals_two_pass_path(H):
     # ... and the parse: fast path (scan/place kernels), the general kernels, and the fast path overflowing its record
     # capacity (falls back to the general kernels; a capacity of 300 is hit by some tiles only)
     for env in ({"HSK_FUSED_FINISH": "1"}, {"HSK_AGG": "0"}, {"HSK_FUSED_FINISH": "0"}, {"HSK_HYBRID": "0"}, {"HSK_XCD_BATCH": "0"},
-                {"HSK_PARSE_FAST": "0"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_PIPELINE": "1"}, {"HSK_ONEPASS": "1"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}):
+                {"HSK_PARSE_FAST": "0"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_PIPELINE": "1"}, {"HSK_ONEPASS": "1"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}):
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000

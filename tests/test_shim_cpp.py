@@ -84,7 +84,7 @@ def test_example_driver_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
-def test_example_driver_extension_k51(tmp_path):
+def test_example_driver_extension(tmp_path):
     exe = str(tmp_path / "hysortk_ext")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(util.ROOT, "include"), "-DKMER_SIZE=31", "-DMINIMIZER_SIZE=17",
                            "-DLOWER_KMER_FREQ=1", "-DUPPER_KMER_FREQ=65535", "-DEXTENSION=1", "-o", exe,
@@ -95,3 +95,19 @@ def test_example_driver_extension_k51(tmp_path):
     subprocess.check_call([exe, util.GOLDEN + "/reads_small.fa", str(outdir)], stdout=subprocess.DEVNULL)
     lines = sorted(open(outdir / "0.out").read().splitlines())
     assert lines == sorted("%s\t%d" % (g[0], g[1]) for g in util.load_count("count_k31ext.txt"))
+
+
+@pytest.mark.gpu
+def test_example_driver_k51(tmp_path):
+    """Two-word keys through the C++ shim: -DKMER_SIZE=51, raw list against the reference's K=51 (RADULS) run."""
+    exe = str(tmp_path / "hysortk_k51")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(util.ROOT, "include"), "-DKMER_SIZE=51", "-DMINIMIZER_SIZE=17",
+                           "-DLOWER_KMER_FREQ=1", "-DUPPER_KMER_FREQ=65535", "-DEXTENSION=0", "-o", exe,
+                           os.path.join(util.ROOT, "examples", "hysortk_main.cpp"), "-L", os.path.join(util.ROOT, "hysortk_amd"), "-lhsk",
+                           "-Wl,-rpath," + os.path.join(util.ROOT, "hysortk_amd")])
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    so = subprocess.check_output([exe, util.GOLDEN + "/reads_small.fa", str(outdir)]).decode()
+    assert open(util.GOLDEN + "/hist_k51.txt").read() in so
+    lines = sorted(open(outdir / "0.out").read().splitlines())
+    assert lines == sorted("%s\t%d" % (g[0], g[1]) for g in util.load_count("count_k51.txt"))
