@@ -10,13 +10,21 @@ For N > 1 every rank holds 10 Gbp of reads sampled from ONE genome of N x 312.5 
 N=8: 80 Gbp), so the minimizer exchange is real; scaling is weak.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scale S]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (radix scatter pass): algorithmic
-bytes per launch (2 x 8 B x keys) / average launch duration measured with HIP events on the launch
-stream inside the timed region.  `cpu_baseline` times the CPU path on the host cores on a bounded
-sample (1/`--cpu-div` of the workload): the real reference binary built by oracle/build_ref.sh when
-it is present and runnable ("reference"), else the C restatement in oracle/ ("port").
+`--gpus N` (N > 1) without a launcher starts the N ranks itself (one fresh child:
+python -m torch.distributed.run, one process per GPU); under a launcher (WORLD_SIZE set) this file is a rank.
+
+Rank 0 prints ONE JSON line:
+  value / ms_per_step   the device-resident rate above (`value` never includes PCIe)
+  roofline              the HBM-bound kernel (radix scatter pass): algorithmic bytes per launch (2 x 8 B x keys)
+                        / average launch duration from HIP events on the launch stream inside the timed region;
+                        .whole_path: the step against the PMC-measured traffic of profiles/traffic.json
+  kernels               the five kernels that make up the step, ms per step and what bounds each
+  e2e_host              (N = 1) the metric as SURVEY 8(d) defines it: wall time of hsk_count() from a DnaBuffer in
+                        (pinned) host RAM to the KmerListS entries in host RAM, L=15/U=40, with its PCIe shares
+  cpu_baseline          the CPU path on the host cores on a bounded sample (1/`--cpu-div` of the workload): the
+                        real reference binary built by oracle/build_ref.sh when it travelled ("reference"; best of
+                        several ranks x threads layouts, its entry count checked), else the C restatement ("port")
 """
 import argparse
 import json
@@ -46,27 +54,38 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; 1.0 = BASELINE config)")
     ap.add_argument("--ntasks", type=int, default=0)
-    ap.add_argument("--cpu-div", type=int, default=200, help="cpu_baseline sample = workload / this")
+    ap.add_argument("--cpu-div", type=int, default=20, help="cpu_baseline sample = workload / this")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (N = 1)")
     ap.add_argument("--ext", type=int, default=0)
     ap.add_argument("--k", type=int, default=31, help="k-mer size (informational runs; the headline metric is K=31)")
     return ap.parse_args()
 
 
-def write_fasta_sample(path, seqs, width=80):
-    with open(path, "w") as f, open(path + ".fai", "w") as fai:
-        off = 0
-        for i, s in enumerate(seqs):
-            hdr = ">r%d\n" % i
-            f.write(hdr)
-            off += len(hdr)
-            fai.write("r%d\t%d\t%d\t%d\t%d\n" % (i, len(s), off, width, width + 1))
-            body = "\n".join(s[j:j + width] for j in range(0, len(s), width)) + "\n"
-            f.write(body)
-            off += len(body)
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): test infrastructure timed beside the product, never on its path
+# ---------------------------------------------------------------------------------------------------------------------
+def write_fasta_sample(path, packed, nreads):
+    """One record per line (header, 150 bases), vectorised; .fai beside it."""
+    nbr = (READ_LEN + 3) // 4
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rec = np.empty((nreads, 3 + READ_LEN + 1), dtype=np.uint8)
+    rec[:, :3] = np.frombuffer(b">r\n", dtype=np.uint8)
+    rec[:, 3 + READ_LEN] = 10
+    step = 1 << 18
+    for a in range(0, nreads, step):
+        pk = packed[a * nbr:(a + step) * nbr].reshape(-1, nbr)
+        codes = np.stack([(pk >> 6) & 3, (pk >> 4) & 3, (pk >> 2) & 3, pk & 3], axis=2).reshape(pk.shape[0], nbr * 4)[:, :READ_LEN]
+        rec[a:a + pk.shape[0], 3:3 + READ_LEN] = lut[codes]
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+    w = rec.shape[1]
+    with open(path + ".fai", "w") as f:
+        for a in range(0, nreads, step):
+            f.write("".join("r\t%d\t%d\t%d\t%d\n" % (READ_LEN, i * w + 3, READ_LEN, READ_LEN + 1) for i in range(a, min(a + step, nreads))))
 
 
-def cpu_baseline(ctx, genome_len, nreads, seed, ncores):
+def cpu_baseline(ctx, genome_len, nreads, seed, ncores, fraction):
     """Times the CPU path on a bounded sample of the same workload; returns the JSON object."""
     from oracle import hsk_oracle as O
     dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed)
@@ -76,46 +95,51 @@ def cpu_baseline(ctx, genome_len, nreads, seed, ncores):
     off = np.arange(nreads, dtype=np.uint64) * np.uint64(nbr)
     lens = np.full(nreads, READ_LEN, dtype=np.uint32)
     nk = nreads * (READ_LEN - K + 1)
-    sample = "S-reads(G=%d, c=%d): %d x %d-bp reads, %d k-mers" % (genome_len, COVERAGE, nreads, READ_LEN, nk)
-    # --- the C restatement (OpenMP over reads and tasks)
+    sample = "S-reads(G=%d, c=%d): %d x %d-bp reads, %d k-mers = 1/%d of the GPU workload" % (genome_len, COVERAGE, nreads, READ_LEN, nk, round(1 / fraction))
+    # --- the C restatement (OpenMP over reads and tasks), filter off like the reference build below
     t0 = time.time()
-    ores = O.count(packed, off, lens, k=K, m=M, L=L, U=U, ntasks=max(ncores * 2, 8), fast=True)
+    ores = O.count(packed, off, lens, k=K, m=M, L=1, U=65535, ntasks=max(ncores * 2, 8), fast=True)
     t_port = time.time() - t0
-    port = {"value": nk / t_port, "unit": "k-mers/s", "cores": ncores, "kind": "port", "sample": sample,
-            "seconds": round(t_port, 3), "entries": int(ores.cnt.size)}
+    n_distinct = int(ores.cnt.size)
+    del ores
+    port = {"value": nk / t_port, "unit": "k-mers/s", "cores": ncores, "kind": "port", "sample": sample, "sample_fraction": fraction,
+            "seconds": round(t_port, 3), "entries": n_distinct}
     # --- the real reference, if its binary travelled and runs here
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "k31", "hysortk_ref")
     mpiexec = "/opt/conda/bin/mpiexec"
     if os.path.exists(ref_bin) and os.path.exists(mpiexec):
         try:
-            lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-            pk = packed.reshape(nreads, nbr)
-            codes = np.stack([(pk >> 6) & 3, (pk >> 4) & 3, (pk >> 2) & 3, pk & 3], axis=2).reshape(nreads, nbr * 4)[:, :READ_LEN]
-            seqs = [r.tobytes().decode() for r in lut[codes]]
             tmp = tempfile.mkdtemp(prefix="hsk_cpu_")
             fa = os.path.join(tmp, "sample.fa")
-            write_fasta_sample(fa, seqs)
+            write_fasta_sample(fa, packed, nreads)
             env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib")
-            best = None
-            # the reference scales with ranks ~ NUMA domains (README.md:46): try ranks x threads layouts
-            layouts = [(r, max(1, ncores // r)) for r in (max(1, ncores // 2), max(1, ncores // 4), max(1, ncores // 8)) if r >= 1]
+            # the reference scales with ranks ~ NUMA domains (README.md:46): ranks x threads = cores
+            layouts = [(r, max(1, ncores // r)) for r in (8, 16, 32, 64) if r <= ncores]
+            if ncores < 16:
+                layouts.append((max(1, ncores // 2), 2))
+            tried, best = [], None
+            t_leg = time.time()
             for ranks, thr in dict.fromkeys(layouts):
-                if ranks > nreads:
+                if ranks > nreads or time.time() - t_leg > 150:
                     continue
                 e = dict(env, OMP_NUM_THREADS=str(thr))
-                p = subprocess.run([mpiexec, "-n", str(ranks), ref_bin, fa], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                   text=True, timeout=120)
+                p = subprocess.run([mpiexec, "-n", str(ranks), ref_bin, fa], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
                 m = re.search(r"Overall kmer counting \(Excluding I/O\):\s*\n\s*total time \(user seconds\):\s*([0-9.]+)", p.stdout)
-                if p.returncode == 0 and m:
-                    t = float(m.group(1))
-                    if best is None or t < best[0]:
-                        best = (t, ranks, thr)
+                hist = re.search(r"#count\tnumkmers\n((?:\d+\t\d+\n)*)", p.stdout)
+                entries = sum(int(l.split("\t")[1]) for l in hist.group(1).splitlines()) if hist else -1
+                ok = p.returncode == 0 and m is not None and entries == n_distinct      # oversubscribed, the reference silently drops entries
+                tried.append({"ranks": ranks, "threads": thr, "seconds": float(m.group(1)) if m else None, "entries": entries, "entries_ok": entries == n_distinct})
+                if ok and (best is None or float(m.group(1)) < best[0]):
+                    best = (float(m.group(1)), ranks, thr)
+            for f_ in (fa, fa + ".fai"):
+                os.remove(f_)
+            os.rmdir(tmp)
             if best:
-                ref = {"value": nk / best[0], "unit": "k-mers/s", "cores": ncores, "kind": "reference",
-                       "sample": sample + "; reference built with L=1 U=65535 (filter off), RADULS, %d ranks x %d threads, its own "
-                       "'Overall kmer counting (Excluding I/O)' timer" % (best[1], best[2]),
-                       "seconds": best[0], "port": port}
-                return ref
+                return {"value": nk / best[0], "unit": "k-mers/s", "cores": ncores, "kind": "reference", "sample_fraction": fraction,
+                        "sample": sample + "; reference built with L=1 U=65535 (filter off), RADULS, best of the layouts below: %d ranks x %d threads, "
+                        "its own 'Overall kmer counting (Excluding I/O)' timer (src/hysortk.cpp:58,91); entry count checked against the C restatement" % (best[1], best[2]),
+                        "seconds": best[0], "entries": n_distinct, "layouts": tried, "port": port}
+            port["reference_layouts"] = tried
         except Exception as e:  # the baseline must never break the bench line
             port["reference_error"] = str(e)[:200]
     return port
@@ -159,6 +183,56 @@ def launch_ranks(a):
         sys.stderr.write("bench.py: the ranks exited without a result line\n")
         rc = 3
     return rc
+
+
+def measured_copy_peak(torch):
+    """Device-to-device copy of 4 GiB, best of 5: GB/s of bytes read + written (the 'measured copy peak' of SURVEY 8d)."""
+    n = 1 << 32
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
+
+
+def e2e_host_leg(H, KK, ext, ntasks, local, genome_len, nreads, seed, steps):
+    """hsk_count() from a DnaBuffer in pinned host RAM to KmerListS entries in pinned host RAM (what the reference times as
+    'Overall kmer counting (Excluding I/O)', src/hysortk.cpp:58,91), L=15 U=40."""
+    ctx = H.Context(K=KK, M=M, L=L, U=U, EXT=ext, ntasks=ntasks, device=local, profile=True, keep_device=False)
+    dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed)
+    packed = H.pinned_empty(nb, np.uint8)
+    off = H.pinned_empty(nreads, np.uint64)
+    lens = H.pinned_empty(nreads, np.uint32)
+    ctx.d2h_into(packed, dp, nb)
+    ctx.d2h_into(off, do, nreads * 8)
+    ctx.d2h_into(lens, dl, nreads * 4)
+    ctx.synth_free(dp, do, dl)
+    ctx.count_host_timed(packed, off, lens)                   # warm-up: pools, pinned result block, entries-per-k-mer estimate
+    ctx.stats(reset=True)
+    secs, n_entries, info = [], 0, None
+    for _ in range(steps):
+        s, n_entries, info = ctx.count_host_timed(packed, off, lens)
+        secs.append(s)
+    st = ctx.stats(reset=True)
+    ctx.close()
+    H.pinned_free(packed); H.pinned_free(off); H.pinned_free(lens)
+    nk = nreads * (READ_LEN - KK + 1)
+    mean = sum(secs) / len(secs)
+    return {"value": nk / mean, "unit": "k-mers/s", "ms_per_step": mean * 1e3, "steps": steps, "L": L, "U": U, "entries": n_entries,
+            "input": "DnaBuffer in pinned host memory (hsk_host_alloc): packed reads read in place over PCIe by the minimizer scan, read index copied ahead",
+            "output": "KmerListS entries + histogram in pinned host memory; batches copied while later batches are counted",
+            "h2d_bytes_per_step": st["h2d_bytes"] / steps, "d2h_bytes_per_step": st["d2h_bytes"] / steps,
+            "h2d_ms": st["h2d_ms"] / steps, "d2h_ms": st["d2h_ms"] / steps,
+            "device_ms_total": info["ms_total"], "host_syncs_per_step": st["host_syncs"] / steps, "host_waits_covered_per_step": st["host_waits_covered"] / steps}
 
 
 def main():
@@ -219,22 +293,47 @@ def main():
     if comm is not None:
         dt = comm.allreduce_max(dt)
     if rank == 0:
-        total_kmers = nk_rank * world * a.steps
+        S = a.steps
+        total_kmers = nk_rank * world * S
         value = total_kmers / dt
+        ms_step = dt / S * 1e3
         launches = max(int(st["scatter_launches"]), 1)
         avg_ms = st["scatter_ms"] / launches
         bytes_per_launch = st["scatter_bytes"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch (rocprofv3), if collected
+        traffic, path_traffic = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes (rocprofv3 passes of an earlier run of this build)
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("onesweep_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("onesweep_bytes_per_launch")
+                path_traffic = tj.get("path_bytes_per_step")
             except Exception:
-                traffic = None
+                pass
+        rec = 8 * ((KK + 31) // 32)
+        copy_peak = measured_copy_peak(torch) if world == 1 else None
+
+        def kern(name, ms, n, alg_bytes, bound, note):
+            d = {"kernel": name, "ms_per_step": ms / S, "launches_per_step": n / S, "bound": bound, "note": note}
+            if alg_bytes and ms > 0:
+                d["algorithmic_GBs"] = alg_bytes / (ms * 1e-3) / 1e9
+                d["frac_of_hbm_peak"] = d["algorithmic_GBs"] / HBM_PEAK_GBS
+            return d
+        kernels = [
+            kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
+                 "minimizer hashes + supermer records: ~108 VALU instructions per base position, 70 of them MurmurHash3; algorithmic bytes = packed reads + 4-byte supermer records"),
+            kern("expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
+                 "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins"),
+            kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
+            kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"], "lds-issue", "per-prefix-bin LDS hash aggregation: reads every record once; bound by divergent LDS probes, not by HBM"),
+            kern("place_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 13.0, "hbm-scattered",
+                 "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
+        ]
+        kernels.sort(key=lambda d: -d["ms_per_step"])
+        ms_total = phase.get("ms_total", 0) / S
         out = {
-            "metric": "k-mers counted/sec at K=%d" % KK, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "k-mers counted/sec at K=%d" % KK, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": S, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("u64" if KK <= 32 else "u128") + ("" if not a.ext else "+u64 payload"), "data": "synthetic",
             "config": {"workload": "S-reads(G=%d bp x %d GPU, c=%d): %d x %d-bp reads per GPU = %.3g bp, %d k-mers per GPU" % (
                 int(GENOME_PER_GPU * a.scale), world, COVERAGE, nreads, READ_LEN, nreads * READ_LEN, nk_rank),
@@ -242,27 +341,42 @@ def main():
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD; with the first pass fused into the expand this is the one remaining pass, over chunk tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": int(st["scatter_launches"]),
-                         "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch,
-                         # kind-1 events: expand_scatter_kernel (expand + first scatter pass; bytes = keys written) when the fused
-                         # path runs, the histogram kernel otherwise
-                         "expand_scatter_avg_launch_ms": (st["hist_ms"] / max(int(st["hist_launches"]), 1)) if st["hist_ms"] else None,
-                         "expand_scatter_written_GBs": (st["hist_bytes"] / max(st["hist_ms"], 1e-9) / 1e6) if st["hist_ms"] else None,
-                         "agg_GBs": (st["agg_bytes"] / max(st["agg_ms"], 1e-9) / 1e6) if st["agg_ms"] else None,
-                         "agg_avg_launch_ms": (st["agg_ms"] / max(int(st["agg_launches"]), 1)) if st["agg_ms"] else None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this build (tools/gpu_round_artifacts.sh), NOT measured in this run",
+                         "launches": int(st["scatter_launches"]), "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch,
+                         "measured_copy_peak_GBs": copy_peak, "frac_of_copy_peak": (achieved / copy_peak) if copy_peak else None,
+                         "whole_path": {
+                             "traffic_bytes_per_step": path_traffic, "traffic_source": "profiles/traffic.json (PMC, earlier run of this build; not this run)",
+                             "GBs": (path_traffic / (ms_total * 1e-3) / 1e9) if path_traffic and ms_total else None,
+                             "frac_of_hbm_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_traffic and ms_total else None,
+                             "frac_of_copy_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / copy_peak) if path_traffic and ms_total and copy_peak else None,
+                             "reference_algorithm_GBs": ((152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)) * nk_rank) / (ms_total * 1e-3) / 1e9 if ms_total else None,
+                             "reference_algorithm_note": "SURVEY 8(d) fixed accounting (8-bit LSD over all key bytes: 152.3 B per 31-mer) x k-mers / device time: the REFERENCE "
+                                                         "algorithm's byte count, not bytes this build moves (2 passes + LDS aggregation, ~49 B per k-mer) and so not a roofline fraction"}},
+            "kernels": kernels,
+            "host_syncs_per_step": st["host_syncs"] / S, "host_waits_covered_per_step": st["host_waits_covered"] / S,
             "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks", "onepass_misses") if k_ in st},
-            "phases_ms_per_step": {k_: v / a.steps for k_, v in sorted(phase.items())},
-            "whole_path_algorithmic_GBs": ((152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)) * nk_rank) / (phase.get("ms_total", 0) / a.steps * 1e-3) / 1e9 if phase.get("ms_total") else None,
+            "phases_ms_per_step": {k_: v / S for k_, v in sorted(phase.items())},
         }
+        ctx.synth_free(dp, do, dl)
+        ctx.close()
+        if world == 1 and not a.no_e2e:
+            try:
+                out["e2e_host"] = e2e_host_leg(H, KK, a.ext, a.ntasks, local, genome_len, nreads, seed, max(a.steps, 3))
+            except Exception as e:
+                out["e2e_host"] = {"error": str(e)[:300]}
         if world == 1 and not a.no_cpu:
             ncores = os.cpu_count() or 1
             div = max(a.cpu_div, 1)
             g_s = max(int(GENOME_PER_GPU * a.scale) // div, 10000)
-            out["cpu_baseline"] = cpu_baseline(ctx, g_s, g_s * COVERAGE // READ_LEN, seed + 1, ncores)
+            c2 = H.Context(K=K, M=M, device=local)
+            out["cpu_baseline"] = cpu_baseline(c2, g_s, g_s * COVERAGE // READ_LEN, seed + 1, ncores, 1.0 / div)
+            c2.close()
         print(json.dumps(out))
         sys.stdout.flush()
-    ctx.synth_free(dp, do, dl)
-    ctx.close()
+    else:
+        ctx.synth_free(dp, do, dl)
+        ctx.close()
     if comm is not None:
         comm.barrier()
         comm.destroy()

@@ -39,6 +39,9 @@ class Stats(C.Structure):
         ("fused_tasks", C.c_int64), ("redone_tasks", C.c_int64),
         ("agg_launches", C.c_uint64), ("agg_bytes", C.c_uint64), ("agg_ms", C.c_double),
         ("agg_retried_tasks", C.c_int64), ("parse_fallbacks", C.c_int64), ("heavy_tasks", C.c_int64), ("onepass_misses", C.c_int64),
+        ("scan_launches", C.c_uint64), ("scan_bytes", C.c_uint64), ("scan_ms", C.c_double),
+        ("place_launches", C.c_uint64), ("place_supermers", C.c_uint64), ("place_ms", C.c_double),
+        ("host_syncs", C.c_uint64), ("host_waits_covered", C.c_uint64), ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
     ]
 
 
@@ -48,7 +51,7 @@ UNIQUE_ID_BYTES = 128
 
 # every symbol include/hsk.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
-    "hsk_abi_version", "hsk_device_count", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
+    "hsk_abi_version", "hsk_device_count", "hsk_host_alloc", "hsk_host_free", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
     "hsk_count", "hsk_count_device", "hsk_count_loopback", "hsk_result_free", "hsk_result_device_task", "hsk_format_entries", "hsk_get_stats",
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
     "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
@@ -80,6 +83,10 @@ def load():
     vp, u64p = C.c_void_p, C.c_void_p
     L.hsk_abi_version.restype = C.c_int
     L.hsk_device_count.restype = C.c_int
+    L.hsk_host_alloc.restype = C.c_void_p
+    L.hsk_host_alloc.argtypes = [C.c_uint64]
+    L.hsk_host_free.restype = None
+    L.hsk_host_free.argtypes = [C.c_void_p]
     L.hsk_init.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.hsk_destroy.argtypes = [vp]
     L.hsk_destroy.restype = None

@@ -41,6 +41,28 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_PINNED = {}
+
+
+def pinned_empty(n, dtype=np.uint8):
+    """numpy array of n elements in pinned host memory (hsk_host_alloc): a DnaBuffer held in such arrays is read by the GPU
+    in place (hsk_count's zero-copy ingest).  Release with pinned_free()."""
+    dt = np.dtype(dtype)
+    nbytes = max(int(n) * dt.itemsize, 1)
+    p = _lib.load().hsk_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("hsk_host_alloc(%d) failed" % nbytes)
+    arr = np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=dt, count=int(n))
+    _PINNED[arr.ctypes.data] = p
+    return arr
+
+
+def pinned_free(arr):
+    p = _PINNED.pop(arr.ctypes.data, None)
+    if p:
+        _lib.load().hsk_host_free(p)
+
+
 def pack_sequence(seq):
     """2-bit packs one read exactly like DnaSeq::compress (reference src/dnaseq.cpp:9-31): base i in
     byte i/4 at shift 6-2*(i%4); tail bits zero; a non-ACGTN byte yields code 4 whose shifted value
@@ -314,6 +336,21 @@ class Context:
         self._check(self.lib.hsk_count(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, rid_base, C.byref(res)))
         return self._wrap(res)
 
+    def count_host_timed(self, packed, off, lens, rid_base=0):
+        """Wall time of ONE hsk_count() call on host arrays (bench.py's e2e_host leg): returns (seconds, entries, info); the
+        result block is handed back to the library right away (no numpy copy: the C ABI result is the product)."""
+        import time
+        res = _lib.Result()
+        t0 = time.perf_counter()
+        rc = self.lib.hsk_count(self.h, _p(packed), packed.size, _p(off), _p(lens), lens.size, rid_base, C.byref(res))
+        dt = time.perf_counter() - t0
+        self._check(rc)
+        n = int(res.n)
+        info = dict(ms_total=res.ms_total, ms_parse=res.ms_parse, ms_extract=res.ms_extract, ms_sort=res.ms_sort, ms_count=res.ms_count, ms_d2h=res.ms_d2h,
+                    total_kmers=int(res.total_kmers), ntasks=int(res.ntasks))
+        self.lib.hsk_result_free(self.h, C.byref(res))
+        return dt, n, info
+
     def count_device(self, d_packed, packed_bytes, d_off, d_len, nreads, rid_base=0):
         res = _lib.Result()
         self._check(self.lib.hsk_count_device(self.h, d_packed, packed_bytes, d_off, d_len, nreads, rid_base, C.byref(res)))
@@ -409,6 +446,9 @@ class Context:
         buf = np.zeros(int(need.value), dtype=np.uint8)
         self._check(self.lib.hsk_format_entries(self.h, _p(e), n, nw, 0, _p(buf), buf.size, C.byref(need)))
         return buf.tobytes()
+
+    def d2h_into(self, arr, dptr, nbytes):
+        self._check(self.lib.hsk_memcpy_d2h(self.h, _p(arr), dptr, nbytes))
 
     def d2h(self, dptr, nbytes):
         out = np.zeros(nbytes, dtype=np.uint8)

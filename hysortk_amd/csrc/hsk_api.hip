@@ -46,6 +46,15 @@ using namespace hsk;
 // ------------------------------------------------------------------------------------------------
 extern "C" int hsk_abi_version(void) { return HSK_ABI_VERSION; }
 
+// pinned (page-locked, device-visible) host memory for the caller's DnaBuffer: hsk_count() then reads it in place
+extern "C" void *hsk_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void hsk_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int hsk_device_count(void)
 {
     int n = 0;
@@ -125,7 +134,8 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
     c->nw = (cfg->kmer_size + 31) / 32;
     memset(&c->stats, 0, sizeof c->stats);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HSK_ERR_HIP; }
+        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HSK_ERR_HIP; }
     c->pinned_bytes = 1 << 20;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) { delete c; return HSK_ERR_OOM; }
     c->d_err = (u32 *)c->pool.alloc(256);
@@ -158,6 +168,8 @@ extern "C" void hsk_destroy(hsk_ctx *c)
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     for (auto &p : c->ev_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->pool.destroy();
+    c->hpool.destroy();
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
@@ -171,6 +183,10 @@ static void drain_profile_events(hsk_ctx *c)
         if (hipEventElapsedTime(&f, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { c->stats.scatter_launches++; c->stats.scatter_keys += p.keys; c->stats.scatter_bytes += p.bytes; c->stats.scatter_ms += f; }
             else if (p.kind == 2) { c->stats.agg_launches++; c->stats.agg_bytes += p.bytes; c->stats.agg_ms += f; }
+            else if (p.kind == 3) { c->stats.scan_launches++; c->stats.scan_bytes += p.bytes; c->stats.scan_ms += f; }
+            else if (p.kind == 4) { c->stats.place_launches++; c->stats.place_supermers += p.keys; c->stats.place_ms += f; }
+            else if (p.kind == 5) { c->stats.h2d_ms += f; }
+            else if (p.kind == 6) { c->stats.d2h_ms += f; }
             else { c->stats.hist_launches++; c->stats.hist_bytes += p.bytes; c->stats.hist_ms += f; }
         }
         ev_put(c, p.a); ev_put(c, p.b);
@@ -213,7 +229,7 @@ extern "C" void hsk_result_free(hsk_ctx *c, hsk_result *r)
     if (!r) return;
     ResultPriv *rp = (ResultPriv *)r->priv;
     if (rp) {
-        for (void *p : rp->host_blocks) (void)hipHostFree(p);
+        for (void *p : rp->host_blocks) { if (c) c->hpool.release(p); else (void)hipHostFree(p); }
         if (c) for (auto &to : rp->dev_tasks) free_task_out(c, to);
         delete rp;
     }
@@ -240,18 +256,25 @@ extern "C" int hsk_result_device_task(const hsk_result *r, int32_t task, const v
 // Uploads the DnaBuffer description; returns device arrays with nreads+1 offsets.
 
 static int upload_input(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
-                        uint64_t nreads, DevInput &d)
+                        uint64_t nreads, DevInput &d, bool wait = true)
 {
     DALLOC(c, d.packed, u8 *, packed_bytes + 64);
     DALLOC(c, d.roff, u64 *, (nreads + 1) * 8);
     DALLOC(c, d.rlen, u32 *, (nreads + 1) * 4);
-    if (packed_bytes) HIPCHK(c, hipMemcpyAsync(d.packed, packed, packed_bytes, hipMemcpyHostToDevice, c->stream));
+    if (packed_bytes && packed) HIPCHK(c, hipMemcpyAsync(d.packed, packed, packed_bytes, hipMemcpyHostToDevice, c->stream));   // (null: the scan reads the host buffer in place)
     if (nreads) {
         HIPCHK(c, hipMemcpyAsync(d.roff, off, nreads * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(d.roff + nreads, &packed_bytes, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffers (and &packed_bytes) may go away after return
+    if (wait) {
+        HIPCHK(c, hipMemcpyAsync(d.roff + nreads, &packed_bytes, 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffers (and &packed_bytes) may go away after return
+    } else {
+        // hsk_count returns after the pipeline's final wait: the caller's buffers outlive the copies, only the stack value needs a home
+        u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
+        *stage = packed_bytes;
+        HIPCHK(c, hipMemcpyAsync(d.roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
+    }
     return HSK_OK;
 }
 static void free_input(hsk_ctx *c, DevInput &d) { c->pool.release(d.packed); c->pool.release(d.roff); c->pool.release(d.rlen); d = DevInput(); }
@@ -269,15 +292,45 @@ static int check_host_index(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *o
     return HSK_OK;
 }
 
+// Inputs in pinned host memory (hsk_host_alloc, hipHostMalloc, hipHostRegister) are not copied first: scan_kernel reads the
+// packed reads in place over PCIe -- once, while it hashes them -- and leaves the copy the later stages need in HBM, so the
+// transfer hides behind the VALU-bound scan; only the read index (12 bytes per read) travels ahead of it.  Pageable inputs
+// take staged copies.  HSK_ZERO_COPY=0 always copies.
+static bool zero_copy_enabled()
+{
+    static const bool on = !(getenv("HSK_ZERO_COPY") && atoi(getenv("HSK_ZERO_COPY")) == 0);
+    return on;
+}
+
 extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
                          uint64_t nreads, int64_t rid_base, hsk_result *out)
 {
     if (!c || !out || (nreads && (!off || !len)) || (packed_bytes && !packed)) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
+    tmark(nullptr); tmark("hsk_count enter");
+    const bool device_check = nreads >= (1u << 20);          // a serial host loop over 10^8 reads costs more than the whole count
+    int rc = device_check ? HSK_OK : check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
+    const u8 *zc = nullptr;
+    if (zero_copy_enabled() && packed_bytes >= (16u << 20)) {
+        hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, packed) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) zc = (const u8 *)at.devicePointer;
+        else (void)hipGetLastError();
+    }
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     DevInput d;
-    rc = upload_input(c, packed, packed_bytes, off, len, nreads, d);
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 5; (void)hipEventRecord(ep.a, c->stream); }
+    rc = upload_input(c, zc ? nullptr : packed, packed_bytes, off, len, nreads, d, false);
+    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    c->stats.h2d_bytes += packed_bytes + nreads * 12;
+    if (rc == HSK_OK && device_check) {
+        hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, d.roff, d.rlen, nreads, packed_bytes, c->d_err);
+        c->index_unchecked = true;
+    }
+    c->zc_src = zc;
+    tmark(zc ? "input enqueued (zero-copy packed)" : "input enqueued (copies)");
     if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
+    tmark("pipeline returned");
+    c->zc_src = nullptr; c->index_unchecked = false;
     free_input(c, d);
     return rc;
 }

@@ -52,6 +52,39 @@ struct DevPool {
     }
 };
 
+// pinned host memory for results (hipHostMalloc of gigabytes takes longer than counting them: freed result blocks are kept)
+struct HostPool {
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    void *alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 64;
+        // sizes are rounded up to 1/8 of their power of two: the result of the next call (a few per cent larger or
+        // smaller) lands in the same size class and takes this call's block instead of pinning gigabytes again (~0.2 s per GB)
+        { size_t g = 4096; while (g * 16 <= bytes) g <<= 1; bytes = (bytes + g - 1) & ~(g - 1); }
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+            void *p = it->second; live[p] = it->first; free_blocks.erase(it); return p;
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            trim();
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        live[p] = bytes;
+        return p;
+    }
+    void release(void *p)
+    {
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.insert({it->second, p}); live.erase(it);
+    }
+    void trim() { for (auto &kv : free_blocks) (void)hipHostFree(kv.second); free_blocks.clear(); }
+    void destroy() { trim(); for (auto &kv : live) (void)hipHostFree(kv.first); live.clear(); }
+};
+
 struct EvPair { hipEvent_t a, b; int kind; u64 keys; u64 bytes; };
 
 struct hsk_ctx {
@@ -59,7 +92,10 @@ struct hsk_ctx {
     int nw = 1;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;
+    hipStream_t d2h_stream = nullptr;  // result copies, overlapped with the kernels of the following batches
     DevPool pool;
+    HostPool hpool;
+    double entries_per_kmer = 0;       // kept entries per input k-mer of the last hsk_count (sizes the pinned result block of the next one)
     char err[512] = {0};
     hsk_stats stats;
     std::vector<hipEvent_t> ev_free;
@@ -67,6 +103,8 @@ struct hsk_ctx {
     void *pinned = nullptr; size_t pinned_bytes = 0;     // small staging area (histograms, totals)
     u32 *d_err = nullptr;
     Comm comm;
+    const u8 *zc_src = nullptr;        // hsk_count() with pinned input: device view of the caller's packed reads (scan_kernel reads them in place)
+    bool index_unchecked = false;      // hsk_count(): the read index is validated on the device (index_check_kernel), the verdict is read with the task totals
     bool xcd_batch_ok = true;          // hsk_init's census saw workgroups on all eight XCC ids (see xcc_census_kernel)
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
@@ -93,6 +131,23 @@ static int fail(hsk_ctx *c, int code, const char *fmt, ...)
         ptr = (type)(c)->pool.alloc(bytes);                                                      \
         if (!ptr) return fail(c, HSK_ERR_OOM, "device allocation of %zu bytes failed (%s:%d)", (size_t)(bytes), __FILE__, __LINE__); \
     } while (0)
+
+// HSK_TIMING=1 (diagnostic): host-side wall-clock marks of one hsk_count call on stderr
+#include <chrono>
+static bool timing_enabled() { static const bool on = getenv("HSK_TIMING") && atoi(getenv("HSK_TIMING")) != 0; return on; }
+static void tmark(const char *what)
+{
+    if (!timing_enabled()) return;
+    static auto t0 = std::chrono::steady_clock::now();
+    static auto last = t0;
+    const auto now = std::chrono::steady_clock::now();
+    if (!what) { t0 = last = now; return; }
+    fprintf(stderr, "[hsk %8.2f ms  +%7.2f] %s\n", std::chrono::duration<double, std::milli>(now - t0).count(), std::chrono::duration<double, std::milli>(now - last).count(), what);
+    last = now;
+}
+
+// every blocking wait of the host on a stream inside the counting path goes through here (hsk_stats.host_syncs)
+static hipError_t hsk_sync(hsk_ctx *c, hipStream_t s) { c->stats.host_syncs++; return hipStreamSynchronize(s); }
 
 static hipEvent_t ev_get(hsk_ctx *c)
 {

@@ -139,7 +139,7 @@ static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src
     hipLaunchKernelGGL(pack_kernel, dim3((u32)all.ntiles), dim3(EXP_THREADS), 0, c->stream, x.d_segs, 1, st.sm_len, src.src8, src.bit0, src.nwords,
                        st.sm_gpos, x.d_tile_off, st.sm_bytes);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));          // `all` lives on this stack frame
+    HIPCHK(c, hsk_sync(c, c->stream));          // `all` lives on this stack frame
     expand_release(c, x);
     return HSK_OK;
 }

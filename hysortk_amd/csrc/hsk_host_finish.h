@@ -24,7 +24,7 @@ static int count_task_device(hsk_ctx *c, const u64 *keys, const u64 *vals, u64 n
     hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile_cnt, ntiles, d_total);
     u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
     HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     out.n = tot[0]; out.npay = ext ? n : 0;
     if (ext) {
         // the payload of a kept run is its slice of the sorted payload array: split the whole array once
@@ -69,12 +69,16 @@ struct ResultPriv {
     std::vector<TaskOut> dev_tasks;      // kept in HBM with HSK_FLAG_KEEP_DEVICE
 };
 
-static void *host_alloc(ResultPriv *rp, size_t bytes)
+static void *host_alloc(hsk_ctx *c, ResultPriv *rp, size_t bytes)
 {
-    void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    rp->host_blocks.push_back(p);
+    void *p = c->hpool.alloc(bytes);
+    if (p) rp->host_blocks.push_back(p);
     return p;
+}
+static void host_release(hsk_ctx *c, ResultPriv *rp, void *p)
+{
+    for (size_t i = 0; i < rp->host_blocks.size(); ++i) if (rp->host_blocks[i] == p) { rp->host_blocks.erase(rp->host_blocks.begin() + i); break; }
+    c->hpool.release(p);
 }
 
 static bool finish_enabled();
@@ -152,7 +156,7 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
     struct { u32 flags[8]; u64 total[8]; } h; memset(&h, 0, sizeof h);
     HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
     for (int i = 0; i < XCD_BATCH; ++i) if (bt[i].n) HIPCHK(c, hipMemcpyAsync(&h.total[i], d_cnt + cnt_off[i] + ntiles[i], 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     static int occ = 0;
     if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, finish_compact_kernel, FN_THREADS, 0) == hipSuccess && nb > 0) ? nb : 4; }
     int rc = HSK_OK;
@@ -182,7 +186,7 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
         }
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
+    HIPCHK(c, hsk_sync(c, c->stream));         // scratch buffers are reused by the next batch
     for (int i = 0; i < XCD_BATCH; ++i) if (own_scratch[i]) c->pool.release(scratch[i]);
     c->pool.release(d_ctl);
     return rc;
@@ -195,81 +199,125 @@ static bool agg_enabled()
     return on;
 }
 
-template <int NW>
+// The aggregating finish of a batch in two stages, so that the host never has to wait for the GPU with nothing queued
+// behind the wait:
+//   agg_stage1  launches bin bounds, the aggregation with the first-choice table and the bin-count scan, asks for the
+//               per-task flags and totals (pinned slot) and records an event;
+//   agg_stage2  (called after the NEXT batch's expand / scatter / stage 1 have been enqueued) waits for that event,
+//               retries the tasks whose bins overflowed with the large table, sizes the outputs exactly, launches the
+//               compaction and sends tasks the tables cannot take the long way.
 // prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way;
 // prefix_bits = 8: bins of the top 8 bits (one scatter pass), agg_big_kernel; a task it cannot take is reported in
 // outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
-static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
+struct AggHostRead { u32 flags[AG_BATCH]; u32 pad[AG_BATCH]; u64 total[AG_BATCH]; };
+struct AggPending {
+    bool active = false;
+    BatchTask bt[AG_BATCH];
+    AggArgs a;
+    u64 *d_bounds = nullptr, *d_cnt = nullptr; u32 *d_flags = nullptr;
+    bool own_scratch[AG_BATCH] = {false};
+    bool big = false, large_first = false;
+    u32 nbins = 0, slot_shift = 0; int K = 0; u64 ntot = 0;
+    hipEvent_t ev = nullptr;
+    AggHostRead *h = nullptr;                           // pinned
+};
+
+template <int NW>
+static int agg_launch_run(hsk_ctx *c, AggPending &p, int log2cap)
+{
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    const AggArgs &a = p.a; const u32 nbins = p.nbins;
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = p.ntot; ep.bytes = p.ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+    if (NW == 2) {
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    } else
+    if (p.big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
+    else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(p.h->flags, p.d_flags, sizeof p.h->flags, hipMemcpyDeviceToHost, c->stream));
+    // the eight totals sit behind the last bin of every task's count row: one strided copy
+    HIPCHK(c, hipMemcpy2DAsync(p.h->total, 8, p.d_cnt + nbins, ((size_t)nbins + 8) * 8, 8, AG_BATCH, hipMemcpyDeviceToHost, c->stream));
+    return HSK_OK;
+}
+
+// slot: which of the two pinned read-back areas (two batches can be between their stages at once)
+template <int NW>
+static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, int slot, AggPending &p)
 {
     static_assert(NW <= 2, "the aggregating finish handles one- and two-word keys");
     constexpr u32 EW = NW + 1;                          // words per entry
-    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    p = AggPending();
     const u32 L = (u32)c->cfg.lower_freq;
-    const u32 slot_shift = L >= 2 ? 1 : 0;              // a bin of n records keeps at most n / L entries of 16 bytes
-    const bool big = prefix_bits == 8;
-    const u32 nbins = 1u << prefix_bits;
+    p.slot_shift = L >= 2 ? 1 : 0;                      // a bin of n records keeps at most n / L entries
+    p.big = prefix_bits == 8;
+    p.nbins = 1u << prefix_bits; p.K = K;
+    p.h = (AggHostRead *)((char *)c->pinned + c->pinned_bytes - 4096 + (size_t)slot * 512);
+    memset(p.h, 0, sizeof *p.h);
+    const u32 nbins = p.nbins;
     const size_t per = (size_t)nbins + 8;
-    u64 *d_bounds, *d_cnt; u32 *d_flags;
-    DALLOC(c, d_bounds, u64 *, per * 8 * AG_BATCH);
-    DALLOC(c, d_cnt, u64 *, per * 8 * AG_BATCH);
-    DALLOC(c, d_flags, u32 *, 256);
-    HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
-    AggArgs a; memset(&a, 0, sizeof a);
+    DALLOC(c, p.d_bounds, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, p.d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, p.d_flags, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(p.d_flags, 0, 64, c->stream));
+    AggArgs &a = p.a; memset(&a, 0, sizeof a);
     a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
-    bool own_scratch[AG_BATCH] = {false};
-    u64 ntot = 0;
+    u64 nmax = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
         AggTask &t = a.t[i];
-        outs[i] = TaskOut();
+        p.bt[i] = bt[i];
         if (bt[i].n == 0) continue;
         u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
-        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
-        t.slot_shift = slot_shift; t.active = 1; ntot += bt[i].n;
-        if (slot_shift) t.scratch = other;               // the idle ping-pong buffer: n / 2 entries
+        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = p.d_bounds + per * i; t.bin_cnt = p.d_cnt + per * i; t.flags = p.d_flags + i;
+        t.slot_shift = p.slot_shift; t.active = 1; p.ntot += bt[i].n; nmax = std::max(nmax, bt[i].n);
+        if (p.slot_shift) t.scratch = other;             // the idle ping-pong buffer: n / 2 entries
         else {
-            t.scratch = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); own_scratch[i] = true;
+            t.scratch = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); p.own_scratch[i] = true;
             if (!t.scratch) return fail(c, HSK_ERR_OOM, "finish scratch of %llu bytes", (unsigned long long)(bt[i].n * EW * 8));
         }
     }
-    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
-    auto run = [&](int log2cap) -> int {
-        EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
-        if (NW == 2) {
-            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-            else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        } else
-        if (big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
-        else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
-        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return HSK_OK;
-    };
-    memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     // bins of 6144 records and more on average (tasks far above 2^28 k-mers) rarely fit the small table: start with the large one
-    u64 nmax = 0; for (int i = 0; i < AG_BATCH; ++i) nmax = std::max(nmax, bt[i].n);
-    const bool large_first = !big && nmax / nbins >= 6144;
-    int rc = run(large_first ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL); if (rc) return rc;
+    p.large_first = !p.big && nmax / nbins >= 6144;
+    int rc = agg_launch_run<NW>(c, p, p.large_first ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL); if (rc) return rc;
+    p.ev = ev_get(c);
+    HIPCHK(c, hipEventRecord(p.ev, c->stream));
+    p.active = true;
+    return HSK_OK;
+}
+
+// covered: later work has already been enqueued behind stage 1 (the wait does not leave the GPU idle)
+template <int NW>
+static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, TaskOut *outs, bool covered)
+{
+    constexpr u32 EW = NW + 1;
+    for (int i = 0; i < AG_BATCH; ++i) outs[i] = TaskOut();
+    if (!p.active) return HSK_OK;
+    AggArgs &a = p.a; const BatchTask *bt = p.bt; const u32 nbins = p.nbins; const bool big = p.big;
+    c->stats.host_syncs++; if (covered) c->stats.host_waits_covered++;
+    HIPCHK(c, hipEventSynchronize(p.ev));
+    ev_put(c, p.ev); p.ev = nullptr;
+    AggHostRead &h = *p.h;
     bool retry = false, done[AG_BATCH];
     u64 total[AG_BATCH];
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
-    if (retry && !big && !large_first) {
-        // second chance with the large table for the tasks that overflowed
+    int rc = HSK_OK;
+    if (retry && !big && !p.large_first) {
+        // second chance with the large table for the tasks that overflowed (rare: the wait below is a plain one)
         AggArgs keep = a;
         for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
-        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
+        HIPCHK(c, hipMemsetAsync(p.d_flags, 0, 64, c->stream));
         memset(&h, 0, sizeof h);
-        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
+        rc = agg_launch_run<NW>(c, p, AG_LOG2CAP_LARGE); if (rc) return rc;
+        HIPCHK(c, hsk_sync(c, c->stream));
         for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
         a = keep;
     }
     AggCompactArgs ca; memset(&ca, 0, sizeof ca);
-    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
+    ca.slot_shift = p.slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
     bool any = false;
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || !done[i]) continue;
@@ -288,19 +336,29 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_tas
         if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
         // the long way for this task: full-width passes from the current order, then the two-pass counter
         c->stats.redone_tasks++;
-        if (own_scratch[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; own_scratch[i] = false; }
+        if (p.own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; p.own_scratch[i] = false; }   // (stream-ordered reuse)
         SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
         u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
-        rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, K, sc1, &sk, &sv, false);
+        rc = sort_task_device<NW>(c, cur, other, nullptr, nullptr, bt[i].n, p.K, sc1, &sk, &sv, false);
         free_sort_scratch(c, sc1);
         if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, nullptr, bt[i].n, 0, d_histo, histo_len, outs[i]);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));         // scratch buffers are reused by the next batch
-    for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) c->pool.release(a.t[i].scratch);
-    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
-    (void)max_task;
+    // no wait here: the scratch (the batch's idle ping-pong buffers, or pool blocks) is next touched by work that is
+    // enqueued on this stream after the compaction
+    for (int i = 0; i < AG_BATCH; ++i) if (p.own_scratch[i]) c->pool.release(a.t[i].scratch);
+    c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_flags);
+    p.active = false;
     return rc;
+}
+
+// both stages back to back (callers that do not pipeline their batches)
+template <int NW>
+static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 /*max_task*/, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
+{
+    AggPending p;
+    int rc = agg_stage1<NW>(c, bt, K, prefix_bits, 0, p); if (rc) return rc;
+    return agg_stage2<NW>(c, p, d_histo, histo_len, outs, false);
 }
 
 // ---- EXTENSION: two passes + grouping aggregation (hsk_agg.h: agg_ext_kernel) ---------------------------------------
@@ -353,7 +411,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
         for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         return HSK_OK;
     };
     memset(&h, 0, sizeof h);
@@ -391,7 +449,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         if (bt[i].n == 0 || done[i]) continue;
         // the long way for this task: full-width passes (payload carried) from the current order, then the two-pass counter
         c->stats.redone_tasks++;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); own_scratch[i] = false; }
         const u64 payadd = pay_before[i];
         free_task_out(c, outs[i]);
@@ -403,7 +461,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         if (rc == HSK_OK) rc = count_task_device<1>(c, sk, sv, bt[i].n, payadd, d_histo, histo_len, outs[i]);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); }
     c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
     return rc;

@@ -109,7 +109,7 @@ struct GroupFeeder {
     int finish()
     {
         while (posted < ngroups) { int rc = post(posted); if (rc) return rc; ++posted; }
-        HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+        HIPCHK(c, hsk_sync(c, c->comm_stream));
         release_below(ngroups);
         return HSK_OK;
     }
@@ -152,7 +152,7 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
     hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
     u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
     HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     out.n = tot[0];
     if (out.n) {
         DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
@@ -160,7 +160,7 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
         hipLaunchKernelGGL((heavy_merge_kernel<NW, true>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     c->pool.release(kA); c->pool.release(kB); c->pool.release(vA); c->pool.release(vB); c->pool.release(d_tile); c->pool.release(d_total);
     return HSK_OK;
 }
@@ -270,15 +270,25 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         while (mine.size() % XCD_BATCH) mine.push_back(EMPTY_TASK);
     const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
     const int nsets = batch ? XCD_BATCH : 1;
-    // Two batches in flight (single GPU): batch b+1 is expanded on the second stream while batch b is sorted and
-    // counted on the main stream.  The expand kernel waits on memory latency for most of its life, the radix passes
-    // are bandwidth-bound and the aggregation is issue-bound: side by side they fill each other's gaps.  Every
-    // buffer the second stream touches is allocated up front (the pool's reuse rule is per stream).
-    // (off unless HSK_PIPELINE=1: the gain is ~1.5 % and every per-kernel duration, hence the reported roofline of the
-    // scatter pass, is inflated by whatever runs beside it)
-    static const bool pipe_enabled = getenv("HSK_PIPELINE") && atoi(getenv("HSK_PIPELINE")) != 0;
-    const bool piped = batch && !feeder && pipe_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
-    const int nslot = piped ? 2 : 1;
+    // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
+    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
+    const bool agg = fused && agg_enabled();
+    // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
+    const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
+    // Two batches in flight on ONE stream (two sets of sort buffers): the host enqueues expand / scatter / aggregation of
+    // batch b + 1 BEFORE it waits for the aggregation totals of batch b, sizes batch b's outputs and enqueues its
+    // compaction.  The GPU therefore never runs dry while the host waits (HSK_LAG=0: one batch at a time, every wait drains
+    // the stream).  An earlier version expanded batch b + 1 on a second stream beside the sort of batch b (HSK_PIPELINE):
+    // every kernel of the path already fills the chip, the gain was 1 %, and it is gone.
+    // Measured (10 Gbp, 5 batches): the batch interval is the same with and without the lag (18.7 / 18.8 ms: a drained
+    // stream costs well under 0.1 ms against ~19 ms of kernels per batch), but the lag delays every batch's compaction,
+    // and with it the batch's result copy, by one batch: host results take 214 ms with it and 197 ms without.  Default: on
+    // when the result stays in HBM (nothing to copy), off when it goes to the host; HSK_LAG=0/1 forces it.
+    const bool keep_dev = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
+    static const int lag_env = getenv("HSK_LAG") ? atoi(getenv("HSK_LAG")) : -1;
+    const bool lag_enabled = lag_env < 0 ? keep_dev : lag_env != 0;
+    const bool lag = batch && agg && NW <= 2 && lag_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
+    const int nslot = lag ? 2 : 1;
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
     // (EXTENSION: payload chunks beside the key chunks, HSK_FUSED_SCATTER_EXT=0 turns that variant off)
     static const bool xs_ext_enabled = !(getenv("HSK_FUSED_SCATTER_EXT") && atoi(getenv("HSK_FUSED_SCATTER_EXT")) == 0);
@@ -300,39 +310,50 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
     }
     u64 *d_ghist_slot[2] = {nullptr, nullptr};
-    ExpandScratch xpre[2][XCD_BATCH];
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    bool done_valid[2] = {false, false};
-    hipStream_t xstream = piped ? c->comm_stream : c->stream;
     if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
-    if (piped) {
-        u64 max_tiles = 0; size_t max_seg = 1;
-        for (u32 t : mine) { if (t == EMPTY_TASK) continue; max_tiles = std::max(max_tiles, segs[t].ntiles); max_seg = std::max(max_seg, segs[t].segs.size()); }
-        for (int sl = 0; sl < 2; ++sl) {
-            for (int i = 0; i < XCD_BATCH; ++i) {
-                DALLOC(c, xpre[sl][i].d_segs, ExpSeg *, sizeof(ExpSeg) * max_seg);
-                DALLOC(c, xpre[sl][i].d_tile_sum, u64 *, max_tiles * 16 + 64);
-                DALLOC(c, xpre[sl][i].d_tile_off, u64 *, max_tiles * 16 + 64);
-                if (i == 0) DALLOC(c, xpre[sl][i].d_cursor, u64 *, 256);
-            }
-            ev_ready[sl] = ev_get(c); ev_done[sl] = ev_get(c);
-        }
-        // everything the pool handed out above may still be in use by earlier main-stream work
-        hipEvent_t fence = ev_get(c);
-        HIPCHK(c, hipEventRecord(fence, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(xstream, fence, 0));
-        ev_put(c, fence);
-    }
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
     { u64 acc = 0; for (u32 t : mine) { if (t == EMPTY_TASK) continue; pay_before[t] = acc; if (ext) acc += segs[t].nkmers; } }
     TaskInput dflt; dflt.len = x_len; dflt.src = x_src; dflt.pos = x_pos; dflt.rid = x_rid;
-    // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
-    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
-    const bool agg = fused && agg_enabled();
-    // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
-    const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
+    // ---- result copies that overlap the kernels (host result, no payload, tasks finished in ascending id) ------------
+    // The pinned block is sized from the entries-per-k-mer ratio of the previous call (or of this call's first batch);
+    // should the list outgrow it, the early copies are abandoned and everything is copied again at the end.
+    const bool keep = keep_dev;
+    static const bool early_enabled = !(getenv("HSK_EARLY_D2H") && atoi(getenv("HSK_EARLY_D2H")) == 0);
+    bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty()) && mine_done.empty();
+    u64 *early_buf = nullptr; u64 early_cap = 0, early_used = 0, early_kmers = 0;
+    std::vector<u8> copied(ntasks, 0);
+    std::vector<EvPair> d2h_ev;
+    const bool profile_ev = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    auto early_copy = [&](const u32 *tasks, int ntk) -> int {
+        if (!early) return HSK_OK;
+        u64 nb = 0, kb = 0;
+        for (int i = 0; i < ntk; ++i) if (tasks[i] != EMPTY_TASK) { nb += touts[tasks[i]].n; kb += segs[tasks[i]].nkmers; }
+        if (!early_buf) {
+            const double ratio = c->entries_per_kmer > 0 ? c->entries_per_kmer : (kb ? (double)nb / (double)kb : 1.0);
+            early_cap = (u64)(ratio * 1.08 * (double)total_kmers) + (1u << 16);
+            if (early_cap * (NW + 1) * 8 > (64ULL << 30)) { early = false; return HSK_OK; }      // not worth pinning that much on a guess
+            early_buf = (u64 *)host_alloc(c, rp, early_cap * (NW + 1) * 8);
+            if (!early_buf) { early = false; return HSK_OK; }
+        }
+        if (early_used + nb > early_cap) { early = false; return HSK_OK; }                       // the guess was too small: copy at the end
+        hipEvent_t done = ev_get(c);
+        HIPCHK(c, hipEventRecord(done, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, done, 0));
+        ev_put(c, done);
+        EvPair ep{}; if (profile_ev) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 6; (void)hipEventRecord(ep.a, c->d2h_stream); }
+        for (int i = 0; i < ntk; ++i) {
+            const u32 t = tasks[i];
+            if (t == EMPTY_TASK) continue;
+            TaskOut &to = touts[t];
+            if (to.n) HIPCHK(c, hipMemcpyAsync(early_buf + early_used * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->d2h_stream));
+            early_used += to.n; copied[t] = 1;
+        }
+        if (profile_ev) { (void)hipEventRecord(ep.b, c->d2h_stream); d2h_ev.push_back(ep); }
+        early_kmers += kb;
+        return HSK_OK;
+    };
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
     BatchTask bts[2][XCD_BATCH];
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
@@ -341,9 +362,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
         const int npass = batch_pass_plan<NW>(c, K, fused || fused_ext, prefix_bits, plan);
-        if (piped && done_valid[sl]) HIPCHK(c, hipStreamWaitEvent(xstream, ev_done[sl], 0));     // the slot's previous batch is counted
-        pt.begin(PH_EXTRACT, xstream);
-        HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, xstream));
+        pt.begin(PH_EXTRACT);
+        HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
         ExpandJob jobs[XCD_BATCH];
         for (int i = 0; i < XCD_BATCH; ++i) {
             const u32 t = mine[bpos + i];
@@ -361,28 +381,39 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
-                rc = scatter_expand_batch<NW>(c, jobs, bts[sl], plan, sbatch[sl], xstream); if (rc) return rc;
+                rc = scatter_expand_batch<NW>(c, jobs, bts[sl], plan, sbatch[sl], c->stream); if (rc) return rc;
             }
-        } else { rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, xstream, piped ? xpre[sl] : nullptr); if (rc) return rc; }
-        pt.end(PH_EXTRACT, xstream);
-        if (piped) HIPCHK(c, hipEventRecord(ev_ready[sl], xstream));
+        } else { rc = expand_batch<NW>(c, jobs, XCD_BATCH, npass, plan, c->stream, nullptr); if (rc) return rc; }
+        pt.end(PH_EXTRACT);
+        return HSK_OK;
+    };
+    AggPending pend[2]; size_t pend_pos[2] = {0, 0};
+    // second stage of the aggregating finish of the batch in slot sl: totals -> outputs -> compaction -> result copy
+    auto finish_stage2 = [&](int sl, bool covered) -> int {
+        if constexpr (NW <= 2) {
+            TaskOut fo[XCD_BATCH];
+            pt.begin(PH_COUNT);
+            int rc = agg_stage2<NW>(c, pend[sl], d_histo, histo_len, fo, covered);
+            pt.end(PH_COUNT);
+            tmark("batch stage 2 done (totals waited for, compaction enqueued)");
+            if (rc) return rc;
+            u32 tk[XCD_BATCH];
+            for (int i = 0; i < XCD_BATCH; ++i) { tk[i] = mine[pend_pos[sl] + i]; if (tk[i] != EMPTY_TASK) touts[tk[i]] = fo[i]; }
+            for (int i = 0; i < XCD_BATCH; ++i) if (tk[i] != EMPTY_TASK && fo[i].failed) early = false;
+            return early_copy(tk, XCD_BATCH);
+        }
         return HSK_OK;
     };
     size_t pos = 0;
     const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
-    if (piped) { int rc = issue_expand(0, 0); if (rc) return rc; }
     for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
-        const int sl = piped ? (int)(b & 1) : 0;
+        const int sl = lag ? (int)(b & 1) : 0;
         if (feeder) {                                   // exposed (not overlapped) part of the exchange
             pt.begin(PH_EXCH);
             for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK) continue; int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
             pt.end(PH_EXCH);
         }
-        if (!piped) { int rc = issue_expand(pos, 0); if (rc) return rc; }
-        else {
-            if (b + 1 < nbatch) { int rc = issue_expand(pos + XCD_BATCH, (int)((b + 1) & 1)); if (rc) return rc; }
-            HIPCHK(c, hipStreamWaitEvent(c->stream, ev_ready[sl], 0));
-        }
+        { int rc = issue_expand(pos, sl); if (rc) return rc; }
         BatchTask *bt = bts[sl];
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
@@ -390,41 +421,50 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
         else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
-        pt.begin(PH_COUNT);
         if (fused_ext) {
             if constexpr (NW == 1) {
+                pt.begin(PH_COUNT);
                 TaskOut fo[XCD_BATCH]; u64 pb[XCD_BATCH];
                 for (int i = 0; i < XCD_BATCH; ++i) pb[i] = mine[pos + i] != EMPTY_TASK ? pay_before[mine[pos + i]] : 0;
                 int rc = agg_ext_finish_batch_device(c, bt, K, pb, d_histo, histo_len, fo); if (rc) return rc;
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
+                pt.end(PH_COUNT);
+            }
+        } else if (agg) {
+            if constexpr (NW <= 2) {
+                // the previous batch first: this batch's expand and scatter pass are queued behind its aggregation, so the
+                // wait for its totals does not idle the GPU, and its compaction (and result copy) starts one kernel earlier
+                // (stage 2 of the previous batch BEFORE this batch's stage 1 would start its result copy one kernel earlier, but a
+                // device-to-host copy running beside agg_finish_kernel stretches a batch from 19 to 32 ms: measured, off)
+                static const bool s2first = getenv("HSK_STAGE2_FIRST") && atoi(getenv("HSK_STAGE2_FIRST")) != 0;
+                if (lag && b > 0 && s2first) { int rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                pt.begin(PH_COUNT);
+                int rc = agg_stage1<NW>(c, bt, K, prefix_bits, sl, pend[sl]);
+                pt.end(PH_COUNT);
+                if (rc) return rc;
+                pend_pos[sl] = pos;
+                if (lag && b > 0 && !s2first) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                if (!lag) { rc = finish_stage2(sl, false); if (rc) return rc; }
             }
         } else if (fused) {
-            if constexpr (NW <= 2) {
+            if constexpr (NW == 1) {
+                pt.begin(PH_COUNT);
                 TaskOut fo[XCD_BATCH];
-                int rc;
-                if constexpr (NW == 1) rc = agg ? agg_finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits)
-                                                : finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo);
-                else rc = agg_finish_batch_device<NW>(c, bt, K, max_task, d_histo, histo_len, fo, prefix_bits);
-                if (rc) return rc;
+                int rc = finish_batch_device<1>(c, bt, K, max_task, d_histo, histo_len, fo); if (rc) return rc;
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
+                pt.end(PH_COUNT);
             }
         } else {
+            pt.begin(PH_COUNT);
             for (int i = 0; i < XCD_BATCH; ++i) {
                 const u32 t = mine[pos + i];
                 if (t == EMPTY_TASK) continue;
                 int rc = count_task_device<NW>(c, bt[i].out_k, bt[i].out_v, bt[i].n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
             }
-        }
-        pt.end(PH_COUNT);
-        if (piped) { HIPCHK(c, hipEventRecord(ev_done[sl], c->stream)); done_valid[sl] = true; }
-    }
-    if (piped) {
-        HIPCHK(c, hipStreamSynchronize(xstream));
-        for (int sl = 0; sl < 2; ++sl) {
-            for (int i = 0; i < XCD_BATCH; ++i) expand_release(c, xpre[sl][i]);
-            ev_put(c, ev_ready[sl]); ev_put(c, ev_done[sl]);
+            pt.end(PH_COUNT);
         }
     }
+    if (lag && agg && nbatch > 0) { int rc = finish_stage2((int)((nbatch - 1) & 1), false); if (rc) return rc; }
     for (; pos < mine.size(); ++pos) {
         const u32 t = mine[pos];
         const u64 n = segs[t].nkmers;
@@ -455,9 +495,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     for (u32 t : mine) { if (t == EMPTY_TASK) continue; touts[t].pay_base = pay_before[t]; n_total += touts[t].n; pay_total += touts[t].npay; }
     for (u32 t : mine_done) { n_total += touts[t].n; pay_total += touts[t].npay; }
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
-    {
-        int rc = check_device_error(c); if (rc) return rc;
-    }
     for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
     free_sort_scratch(c, sc);
     c->pool.release(d_ghist_slot[0]); c->pool.release(d_ghist_slot[1]);
@@ -465,28 +502,34 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // ---- result ----------------------------------------------------------------------------------------
     pt.begin(PH_D2H);
     out->n = n_total;
-    out->task_off = (uint64_t *)host_alloc(rp, (size_t)(ntasks + 1) * 8);
-    out->histo = (uint64_t *)host_alloc(rp, (size_t)histo_len * 8);
+    out->task_off = (uint64_t *)host_alloc(c, rp, (size_t)(ntasks + 1) * 8);
+    out->histo = (uint64_t *)host_alloc(c, rp, (size_t)histo_len * 8);
     out->histo_len = histo_len;
     if (!out->task_off || !out->histo) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
     HIPCHK(c, hipMemcpyAsync(out->histo, d_histo, (size_t)histo_len * 8, hipMemcpyDeviceToHost, c->stream));
-    const bool keep = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
+    u32 *h_err = (u32 *)((char *)c->pinned + c->pinned_bytes - 64);        // the sticky device error word travels with the result
+    HIPCHK(c, hipMemcpyAsync(h_err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
     if (!keep) {
-        out->entries = (uint64_t *)host_alloc(rp, n_total * (NW + 1) * 8);
+        // the early copies are good if they stayed inside the block and cover a prefix of the list (tasks in ascending id)
+        bool early_ok = early_buf != nullptr && early && n_total <= early_cap;
+        if (early_ok) { bool gap = false; for (u32 t = 0; t < ntasks && early_ok; ++t) { if (!touts[t].n) continue; if (!copied[t]) gap = true; else if (gap) early_ok = false; } }
+        if (early_buf && !early_ok) { HIPCHK(c, hsk_sync(c, c->d2h_stream)); host_release(c, rp, early_buf); early_buf = nullptr; std::fill(copied.begin(), copied.end(), 0); }
+        out->entries = early_buf ? early_buf : (uint64_t *)host_alloc(c, rp, n_total * (NW + 1) * 8);
         if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
         if (ext) {
-            out->payload_off = (uint64_t *)host_alloc(rp, (n_total + 1) * 8);
-            out->pos = (uint32_t *)host_alloc(rp, pay_total * 4);
-            out->rid = (int32_t *)host_alloc(rp, pay_total * 4);
+            out->payload_off = (uint64_t *)host_alloc(c, rp, (n_total + 1) * 8);
+            out->pos = (uint32_t *)host_alloc(c, rp, pay_total * 4);
+            out->rid = (int32_t *)host_alloc(c, rp, pay_total * 4);
             if (!out->payload_off || !out->pos || !out->rid) return fail(c, HSK_ERR_OOM, "pinned host allocation failed");
         }
     }
+    EvPair d2h_tail{}; if (profile_ev && !keep) { d2h_tail.a = ev_get(c); d2h_tail.b = ev_get(c); d2h_tail.kind = 6; (void)hipEventRecord(d2h_tail.a, c->stream); }
     u64 o = 0, po = 0;
     for (u32 t = 0; t < ntasks; ++t) {
         out->task_off[t] = o;
         TaskOut &to = touts[t];
         if (!keep) {
-            if (to.n) HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (to.n && !copied[t]) { HIPCHK(c, hipMemcpyAsync(out->entries + o * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->stream)); c->stats.d2h_bytes += 0; }
             if (ext && to.n) HIPCHK(c, hipMemcpyAsync(out->payload_off + o, to.payoff, to.n * 8, hipMemcpyDeviceToHost, c->stream));
             if (ext && to.npay) {
                 HIPCHK(c, hipMemcpyAsync(out->pos + po, to.pos, to.npay * 4, hipMemcpyDeviceToHost, c->stream));
@@ -496,9 +539,24 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         o += to.n; po += to.npay;
     }
     out->task_off[ntasks] = o;
+    if (profile_ev && !keep) { (void)hipEventRecord(d2h_tail.b, c->stream); d2h_ev.push_back(d2h_tail); }
+    if (!keep) c->stats.d2h_bytes += n_total * (NW + 1) * 8 + (ext ? (n_total + 1) * 8 + pay_total * 8 : 0);
     pt.end(PH_D2H);
     if (pt_total_open) pt.end(PH_TOTAL);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tmark("result copies enqueued");
+    HIPCHK(c, hsk_sync(c, c->stream));
+    tmark("main stream drained");
+    if (early_buf) HIPCHK(c, hsk_sync(c, c->d2h_stream));
+    tmark("copy stream drained");
+    for (auto &e : d2h_ev) c->ev_pending.push_back(e);
+    if (*h_err) {
+        const u32 w = *h_err;
+        (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+        return fail(c, HSK_ERR_INTERNAL, "device-side check failed (error word %u:%s%s%s%s%s)", w, (w & 1) ? " radix look-back timed out;" : "",
+                    (w & 2) ? " chunk map wait timed out;" : "", (w & 4) ? " foreign supermer;" : "",
+                    (w & 8) ? " an XCD did not expand its task (cursors / histogram do not add up);" : "", (w & 16) ? " an XCD did not drain its sort task;" : "");
+    }
+    if (!ext && total_kmers && !c->forbid_long_way) c->entries_per_kmer = (double)n_total / (double)total_kmers;
     if (ext && !keep) out->payload_off[n_total] = pay_total;
     if (keep) { rp->dev_tasks = touts; out->entries_dev = nullptr; }
     else for (auto &to : touts) free_task_out(c, to);
@@ -640,6 +698,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         if (rc) return rc;
     }
     pt.end(PH_PARSE);
+    tmark("parse enqueued (task totals read)");
     out->total_supermers = st.tot_sup; out->total_supermer_bytes = st.tot_bytes + st.tot_sup * (ext ? 9 : 1);
 
     // ---- exchange (multi-GPU) ---------------------------------------------------------------------
@@ -719,7 +778,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             u64 o = 0; for (int p = 0; p < rank; ++p) o += Hn[(size_t)p * nh + i];
             if (hlists[t].n) HIPCHK(c, hipMemcpyAsync((char *)hv.d_entries + o * ew, hlists[t].entries, hlists[t].n * ew, hipMemcpyDeviceToDevice, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         for (auto &to : hlists) free_task_out(c, to);
     }
     pt.end(PH_EXCH);
@@ -818,7 +877,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             }
             hin[owner[t]].push_back(hv);
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         free_hlists();
     }
     auto free_hin = [&]() { for (auto &v : hin) for (auto &hv : v) c->pool.release(hv.d_entries); };
@@ -863,7 +922,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             HIPCHK(c, hipMemcpyAsync(xb[d].rid + pl[d].recv_sup_off[sidx], st[sidx].sm_rid + pl[sidx].send_sup_off[d], n * 4, hipMemcpyDeviceToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     for (int r = 0; r < R; ++r) free_store(c, st[r]);
     // 4. every rank finishes its own tasks
     for (int r = 0; r < R; ++r) {

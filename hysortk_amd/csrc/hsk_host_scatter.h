@@ -9,6 +9,8 @@ struct ScatterBatch {
     u32 *d_ctl = nullptr;                        // [XCD_BATCH][4]
     u32 *d_map[XCD_BATCH] = {nullptr};
     u64 *d_tile_src[XCD_BATCH] = {nullptr};
+    u64 *d_gbase = nullptr;                      // [XCD_BATCH][256] digit bases of the second pass (chunk_tiles_kernel)
+    u32 *d_ntiles = nullptr;                     // [XCD_BATCH] tiles of the second pass (chunk_tiles_kernel)
     ExpandScratch x[EXP_BATCH];                  // segment lists (and tile offsets) the kernel reads
     bool active = false;
 };
@@ -23,7 +25,7 @@ static size_t scatter_store_keys(u64 n, int chunk) { return (size_t)(n / chunk +
 
 static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
 {
-    c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl);
+    c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl); c->pool.release(sb.d_gbase); c->pool.release(sb.d_ntiles);
     for (int i = 0; i < XCD_BATCH; ++i) { c->pool.release(sb.d_map[i]); c->pool.release(sb.d_tile_src[i]); expand_release(c, sb.x[i]); }
     sb = ScatterBatch();
 }
@@ -50,6 +52,9 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, false, offsets); if (rc) return rc;
     DALLOC(c, sb.d_cursor, u64 *, (size_t)XCD_BATCH * 256 * 8);
     DALLOC(c, sb.d_ctl, u32 *, (size_t)XCD_BATCH * 16);
+    DALLOC(c, sb.d_gbase, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    DALLOC(c, sb.d_ntiles, u32 *, 256);
+    HIPCHK(c, hipMemsetAsync(sb.d_ntiles, 0, 64, stream));
     HIPCHK(c, hipMemsetAsync(sb.d_cursor, 0, (size_t)XCD_BATCH * 256 * 8, stream));
     HIPCHK(c, hipMemsetAsync(sb.d_ctl, 0, (size_t)XCD_BATCH * 16, stream));
     u64 ntot = 0;
@@ -67,6 +72,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         t.tile_off = offsets ? x[xi[i]].d_tile_off : nullptr; t.ntiles = j.ts->ntiles;
         t.chunks = j.keys; t.cursor = sb.d_cursor + (size_t)i * 256; t.map = sb.d_map[i]; t.ctl = sb.d_ctl + (size_t)i * 4;
         t.ghist = j.ghist + 256; t.tile_src = sb.d_tile_src[i];
+        t.n = n; t.gbase = sb.d_gbase + (size_t)i * 256; t.ntiles_out = sb.d_ntiles + i;
         t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid; t.vchunks = j.vals;
         ntot += n;
     }
@@ -97,57 +103,46 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
 }
 
 // Second (stable) pass over a batch whose first pass was done by expand_scatter_kernel: input = the chunk stores bt[i].kB,
-// output = bt[i].kA.  d_ghist: [XCD_BATCH][MAX_PASSES][256], row 1 = the histogram of this pass's digit.
+// output = bt[i].kA.  Nothing is read back by the host: chunk_tiles_kernel derives the digit bases, the tile list and the
+// tile count on the device (and checks that every XCD expanded its task), the look-back table and the grid are sized for
+// the most tiles a task of n keys can have (n / CHUNK + 256: every digit wastes less than one chunk), workgroups beyond the
+// real tile count leave at once, and sort_drained_kernel checks afterwards that every XCD drained its task.  A failed
+// check sets the sticky device error word, which the caller reads once per hsk_count (check_device_error).
 template <int NW>
-static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *plan, u64 *d_ghist, ScatterBatch &sb)
+static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *plan, u64 * /*d_ghist*/, ScatterBatch &sb)
 {
     constexpr int XS_CHUNK = XsCfg<NW>::CHUNK;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const bool has_val = bt[0].vA != nullptr;
     for (int i = 0; i < XCD_BATCH; ++i) { bt[i].out_k = bt[i].kA; bt[i].out_v = has_val ? bt[i].vA : nullptr; }
     if (!sb.active) return HSK_OK;
-    std::vector<u64> hh((size_t)XCD_BATCH * MAX_PASSES * 256), cur((size_t)XCD_BATCH * 256), hb((size_t)XCD_BATCH * 256, 0);
-    HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cur.data(), sb.d_cursor, cur.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = check_device_error(c); if (rc) { scatter_release(c, sb); return rc; }
-    u64 ntiles[XCD_BATCH], max_tiles = 0, ntot = 0; bool wide = force_wide_lookback();
+    u64 tile_cap[XCD_BATCH], max_tiles = 0, ntot = 0; bool wide = force_wide_lookback();
     size_t lb_off[XCD_BATCH + 1]; lb_off[0] = 0;
     for (int i = 0; i < XCD_BATCH; ++i) {
-        ntiles[i] = 0;
-        u64 placed = 0, run = 0;
-        for (int d = 0; d < 256; ++d) {
-            const u64 v = cur[(size_t)i * 256 + d];
-            placed += v; ntiles[i] += (v + XS_CHUNK - 1) / XS_CHUNK;
-            hb[(size_t)i * 256 + d] = run; run += hh[((size_t)i * MAX_PASSES + 1) * 256 + d];
-        }
-        // every XCD must have expanded its task (the kernel picks the task by the XCD it runs on)
-        if (placed != bt[i].n || run != bt[i].n) {
-            scatter_release(c, sb);
-            return fail(c, HSK_ERR_INTERNAL, "XCD %d did not expand its task (%llu of %llu k-mers placed)", i, (unsigned long long)placed, (unsigned long long)bt[i].n);
-        }
+        tile_cap[i] = bt[i].n ? bt[i].n / XS_CHUNK + 256 : 0;
         if (bt[i].n >= (1ULL << 30)) wide = true;
-        max_tiles = std::max(max_tiles, ntiles[i]); ntot += bt[i].n;
+        max_tiles = std::max(max_tiles, tile_cap[i]); ntot += bt[i].n;
     }
     const size_t lbw = wide ? 8 : 4;
-    for (int i = 0; i < XCD_BATCH; ++i) lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * lbw;
-    u64 *d_gbase; u32 *d_tickets; void *d_lookback;
-    DALLOC(c, d_gbase, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    for (int i = 0; i < XCD_BATCH; ++i) lb_off[i + 1] = lb_off[i] + (size_t)tile_cap[i] * 256 * lbw;
+    u32 *d_tickets; void *d_lookback;
     DALLOC(c, d_tickets, u32 *, 256);
     DALLOC(c, d_lookback, void *, lb_off[XCD_BATCH] + 256);
-    HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(d_lookback, 0, lb_off[XCD_BATCH], c->stream));
     hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, c->stream, sb.args);
     MultiSortArgs ms; memset(&ms, 0, sizeof ms);
     for (int i = 0; i < XCD_BATCH; ++i) {
         SortArgs &a = ms.t[i];
-        a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.vals_in = has_val ? bt[i].vB : nullptr; a.vals_out = has_val ? bt[i].vA : nullptr; a.n = bt[i].n; a.ntiles = ntiles[i];
+        a.keys_in = bt[i].kB; a.keys_out = bt[i].kA; a.vals_in = has_val ? bt[i].vB : nullptr; a.vals_out = has_val ? bt[i].vA : nullptr; a.n = bt[i].n;
+        a.ntiles = tile_cap[i]; a.ntiles_dev = sb.d_ntiles + i;
         a.word = plan[1].word; a.shift = plan[1].shift; a.bits = plan[1].bits;
         a.unstable = unstable_first_pass() ? 1 : 0;     // a tile is a chunk of ONE first-pass digit: the order inside it is free, the look-back keeps the tiles in order
-        a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lookback + lb_off[i];
+        a.gbase = sb.d_gbase + (size_t)i * 256; a.lookback = (char *)d_lookback + lb_off[i];
         a.ticket = d_tickets + i; a.err = c->d_err; a.tile_src = sb.d_tile_src[i];
     }
+    // the real tile count is n / CHUNK + (digits with a partial chunk) <= the cap; the grid follows the cap (+12 %: the
+    // dispatcher deals workgroups round-robin over the XCDs, not exactly evenly)
     const u32 grid = (u32)(XCD_BATCH * (max_tiles + max_tiles / 8) + 64);
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * (has_val ? 16 : 8 * NW); (void)hipEventRecord(ep.a, c->stream); }
     if (max_tiles) {
@@ -155,13 +150,10 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
         else { if (wide) launch_onesweep_multi<NW, false, u64>(c, ms, grid); else launch_onesweep_multi<NW, false, u32>(c, ms, grid); }
     }
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    hipLaunchKernelGGL(sort_drained_kernel, dim3(1), dim3(64), 0, c->stream, d_tickets, sb.d_ntiles, XCD_BATCH, c->d_err);
     HIPCHK(c, hipGetLastError());
-    u32 tk[XCD_BATCH];
-    HIPCHK(c, hipMemcpyAsync(tk, d_tickets, sizeof tk, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
-        if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (%u of %llu tiles)", i, tk[i], (unsigned long long)ntiles[i]);
-    c->pool.release(d_gbase); c->pool.release(d_tickets); c->pool.release(d_lookback);
+    // released without a wait: every later user of these blocks is enqueued on the same stream
+    c->pool.release(d_tickets); c->pool.release(d_lookback);
     scatter_release(c, sb);
-    return rc;
+    return HSK_OK;
 }

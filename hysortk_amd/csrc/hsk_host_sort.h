@@ -91,7 +91,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
     if (profile) { (void)hipEventRecord(hp.b, c->stream); c->ev_pending.push_back(hp); }
     u64 *hh = (u64 *)c->pinned;                          // [npass][256] histogram, then [npass][256] bases
     HIPCHK(c, hipMemcpyAsync(hh, sc.ghist, (size_t)h.npass * 256 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     u64 *hb = hh + (size_t)MAX_PASSES * 256;
     std::vector<int> todo;
     for (int p = 0; p < h.npass; ++p) {
@@ -142,7 +142,7 @@ static int sort_task_device(hsk_ctx *c, u64 *keysA, u64 *keysB, u64 *valsA, u64 
         std::swap(kin, kout); std::swap(vin, vout);
         u32 *hf = (u32 *)((char *)c->pinned + c->pinned_bytes - 192);
         HIPCHK(c, hipMemcpyAsync(hf, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         if (*hf) {                                             // a long bin with several keys: finish with the full-width passes
             c->stats.redone_tasks++;
             u64 *other = (kin == keysA) ? keysB : keysA;
@@ -209,7 +209,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     }
     std::vector<u64> hh((size_t)XCD_BATCH * MAX_PASSES * 256), hb((size_t)XCD_BATCH * MAX_PASSES * 256, 0);
     HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     std::vector<int> todo;
     for (int p = 0; p < npass; ++p) {
         bool all_trivial = true;
@@ -276,7 +276,7 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
     if (!todo.empty() || hybrid) {
         // every XCD must have drained its task (ticket counters >= tile counts); hybrid: which tasks need the long way
         HIPCHK(c, hipMemcpyAsync(tk.data(), d_tickets, ((size_t)XCD_BATCH * MAX_PASSES + XCD_BATCH) * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
         for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
             for (size_t j = 0; j < todo.size(); ++j)
                 if (tk[(size_t)i * MAX_PASSES + j] < ntiles[i]) { rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain its sort task (pass %zu: %u of %llu tiles)", i, j, tk[(size_t)i * MAX_PASSES + j], (unsigned long long)ntiles[i]); break; }
@@ -308,7 +308,7 @@ static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
     const int per_xcd = nb / 8;
     std::vector<u64> hh((size_t)nb * MAX_PASSES * 256), hb((size_t)nb * 256, 0);
     HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     u64 ntiles[MANY_MAX]; size_t lb_off[MANY_MAX + 1]; lb_off[0] = 0;
     u64 ntot = 0;
     for (int i = 0; i < nb; ++i) {
@@ -346,7 +346,7 @@ static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
     }
     HIPCHK(c, hipMemcpyAsync(d_tasks, ta.data(), sizeof(SortArgs) * nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_pre, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                       // ta / pre / hb are host stack memory
+    HIPCHK(c, hsk_sync(c, c->stream));                       // ta / pre / hb are host stack memory
     ManySortArgs m; m.tasks = d_tasks; m.xcd_prefix = d_pre; m.xcd_counter = d_tk + nb; m.per_xcd = per_xcd;
     const u32 grid = (u32)(8 * (max_xcd + max_xcd / 8) + 64);
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
@@ -355,7 +355,7 @@ static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
     HIPCHK(c, hipGetLastError());
     std::vector<u32> tk(nb + 8);
     HIPCHK(c, hipMemcpyAsync(tk.data(), d_tk, (size_t)(nb + 8) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     int rc = HSK_OK;
     for (int i = 0; i < nb && rc == HSK_OK; ++i) {
         if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain sort task %d (%u of %llu tiles)", i & 7, i, tk[i], (unsigned long long)ntiles[i]);
@@ -382,10 +382,13 @@ static int check_device_error(hsk_ctx *c)
 {
     u32 *e = (u32 *)((char *)c->pinned + c->pinned_bytes - 64);
     HIPCHK(c, hipMemcpyAsync(e, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
     if (*e) {
         (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
-        return fail(c, HSK_ERR_INTERNAL, "radix look-back timed out (device error word %u)", *e);
+        const u32 w = *e;
+        return fail(c, HSK_ERR_INTERNAL, "device-side check failed (error word %u:%s%s%s%s%s)", w, (w & 1) ? " radix look-back timed out;" : "",
+                    (w & 2) ? " chunk map wait timed out;" : "", (w & 4) ? " foreign supermer;" : "",
+                    (w & 8) ? " an XCD did not expand its task (cursors / histogram do not add up);" : "", (w & 16) ? " an XCD did not drain its sort task;" : "");
     }
     return HSK_OK;
 }

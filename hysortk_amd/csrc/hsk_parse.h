@@ -71,6 +71,8 @@ struct ParseArgs {
     u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
     u32 *tile_r0;              // optional [ntiles] (EXTENSION): first read overlapping the tile, kept for resolve_pos_rid_kernel
     const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
+    u32 *packed_copy;          // optional (scan_kernel): `packed` is pinned HOST memory read in place over PCIe; every tile's words are
+                               // also written here (HBM, packed_bytes + 64), so the ingest is fused into the one pass that hashes the reads
 };
 
 enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
@@ -536,6 +538,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
         }
         lds_barrier();
+        if (a.packed_copy && tid < PARSE_TILE / 16 && bbase + 4u * (u64)tid < a.packed_bytes)
+            a.packed_copy[(bbase >> 2) + tid] = __builtin_bswap32(s_words[tid]);      // (a last partial word is padded with zeros: the copy has room)
         // the next tile's word and read-index entries are requested now and land in LDS at the top of the next round (every
         // barrier of the loop is an LDS-only barrier: none of them waits for these loads or for the record stores)
         {
@@ -802,6 +806,19 @@ __global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *rof
         sm_pos[s] = (u32)(g - roff[r] * 4);
         sm_rid[s] = (int32_t)(rid_base + (int64_t)r);
     }
+}
+
+// hsk_count(): the caller's read index must be ascending, non-overlapping and inside the packed buffer (error bit 32)
+__global__ void index_check_kernel(const u64 *roff, const u32 *rlen, u64 nreads, u64 packed_bytes, u32 *err)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+        const u64 o = roff[r], end = o + ((u64)rlen[r] + 3) / 4;
+        if (end > packed_bytes || end < o) bad = true;
+        if (r == 0 ? o != 0 : o < roff[r - 1] + ((u64)rlen[r - 1] + 3) / 4) bad = true;
+    }
+    if (bad) atomicOr(err, 32u);
 }
 
 // column sums of the COUNT matrix for task t; eight rows are requested before the first is added (one thread walks

@@ -65,6 +65,9 @@ struct ScatterTask {
     u32 *ctl;                                        // [0] tile ticket, [1] chunks handed out (zeroed)
     u64 *ghist;                                      // [256] histogram of the second pass's digit (zeroed)
     u64 *tile_src;                                   // out (chunk_tiles_kernel): second-pass tiles
+    u64 n;                                           // k-mers of the task (chunk_tiles_kernel checks the cursors and the histogram against it)
+    u64 *gbase;                                      // out (chunk_tiles_kernel): [256] exclusive scan of ghist = digit bases of the second pass
+    u32 *ntiles_out;                                 // out (chunk_tiles_kernel): number of second-pass tiles
     const u32 *sm_pos; const int32_t *sm_rid;        // EXTENSION: position in read and read id of every supermer
     u64 *vchunks;                                    // EXTENSION: payload chunk store (same slots as `chunks`)
 };
@@ -406,17 +409,29 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
 #endif
 }
 
-// tile_src[i] = (physical chunk << 32) | keys, chunks in (digit, virtual chunk) order; one workgroup per task
+// tile_src[i] = (physical chunk << 32) | keys, chunks in (digit, virtual chunk) order; one workgroup per task.  The kernel
+// also prepares everything else the second pass needs, so that the host does not have to read anything back between the
+// two passes: the digit bases of the second pass (exclusive scan of the histogram the expand counted), the tile count, and
+// the check that the XCD really expanded its task (cursors and histogram add up to the task's k-mer count; error bit 8
+// otherwise: the kernels pick their task by the XCD they run on, the results must never silently depend on the placement).
 __global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
 {
     __shared__ u64 s_scr[8];
     const ScatterTask &t = a.t[blockIdx.x];
-    if (t.ntiles == 0) return;
+    if (t.ntiles == 0) { if (threadIdx.x == 0 && t.ntiles_out) *t.ntiles_out = 0; return; }
     const int d = threadIdx.x;
     const u64 cnt = t.cursor[d];
     const u64 CH = (u64)a.chunk;
     const u64 nch = (cnt + CH - 1) / CH;
-    u64 off = block_excl_scan_256<u64>(nch, s_scr, nullptr);
+    u64 tot_ch, placed, hsum;
+    u64 off = block_excl_scan_256<u64>(nch, s_scr, &tot_ch);
+    (void)block_excl_scan_256<u64>(cnt, s_scr, &placed);
+    const u64 gb = block_excl_scan_256<u64>(t.ghist[d], s_scr, &hsum);
+    if (t.gbase) t.gbase[d] = gb;
+    if (d == 0) {
+        if (t.ntiles_out) *t.ntiles_out = (u32)tot_ch;
+        if (placed != t.n || hsum != t.n) atomicOr(a.err, 8u);
+    }
     const u32 *mp = t.map + (u64)d * t.vmax;
     constexpr int U = 8;                                          // map entries requested per step (a load per step is a latency per chunk)
     u64 v = 0;
@@ -434,6 +449,13 @@ __global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
         const u64 left = cnt - v * CH;
         t.tile_src[off + v] = ((u64)(mp[v] - 1) << 32) | (left < CH ? left : CH);
     }
+}
+
+// after the second pass: every XCD must have drained its task (ticket counter past the tile count); error bit 16 otherwise
+__global__ void sort_drained_kernel(const u32 *tickets, const u32 *ntiles, int n, u32 *err)
+{
+    const int i = threadIdx.x;
+    if (i < n && tickets[i] < ntiles[i]) atomicOr(err, 16u);
 }
 
 } // namespace hsk

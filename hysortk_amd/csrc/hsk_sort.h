@@ -80,6 +80,7 @@ struct SortArgs {
     u32 *ticket;          // zeroed
     u32 *err;             // sticky error word
     const u64 *tile_src;  // null: tile t is keys_in[t * TILE ...]; else tile t = (chunk << 32 | keys) of a chunked input (hsk_scatter.h)
+    const u32 *ntiles_dev; // non-null: the tile count lives in device memory (written by chunk_tiles_kernel); `ntiles` is then an upper bound
 };
 
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
@@ -122,7 +123,8 @@ __device__ __forceinline__ void onesweep_tile(const SortArgs &a)
     __syncthreads();
     DIAG_STAMP(1);
     const u64 tile = s_tile[0];
-    if (tile >= a.ntiles) return;                 // uniform: the whole workgroup leaves (multi kernel: task exhausted)
+    const u64 ntiles_now = a.ntiles_dev ? (u64)*a.ntiles_dev : a.ntiles;
+    if (tile >= ntiles_now) return;               // uniform: the whole workgroup leaves (multi kernel: task exhausted)
     u64 base = tile * TILE;
     u32 nvalid = (u32)((a.n - base) < (u64)TILE ? (a.n - base) : (u64)TILE);
     if (a.tile_src) { const u64 ts = a.tile_src[tile]; base = (ts >> 32) * TILE; nvalid = (u32)ts; }

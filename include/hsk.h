@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HSK_ABI_VERSION 1
+#define HSK_ABI_VERSION 2
 
 typedef enum {
     HSK_OK = 0,
@@ -100,7 +100,7 @@ typedef struct {
     void    *priv;            /* library bookkeeping */
 } hsk_result;
 
-/* Per-kernel accounting of the dominant kernel (radix scatter pass), filled when
+/* Per-kernel accounting (HIP events on the launch stream around every launch of the named kernels), filled when
  * HSK_FLAG_PROFILE is set.  bytes = algorithmic bytes (records read + written). */
 typedef struct {
     uint64_t scatter_launches;
@@ -119,11 +119,29 @@ typedef struct {
     int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
     int64_t  heavy_tasks;         /* heavy-hitter tasks this rank pre-aggregated and shipped as k-mer lists (multi-GPU) */
     int64_t  onepass_misses;      /* tasks the one-pass plan (8-bit prefix bins) could not finish; they took two more passes */
+    /* --- ABI 2 --- */
+    uint64_t scan_launches;       /* scan_kernel (minimizers + supermer records): launches, packed read bytes, duration */
+    uint64_t scan_bytes;
+    double   scan_ms;
+    uint64_t place_launches;      /* place_kernel (supermers to their task slots): launches, supermers placed, duration */
+    uint64_t place_supermers;
+    double   place_ms;
+    uint64_t host_syncs;          /* blocking waits of the host on the GPU (stream or event) inside hsk_count* since the last reset */
+    uint64_t host_waits_covered;  /* ... of which the host had already enqueued the next batch's kernels behind the awaited work,
+                                     so the wait does not leave the GPU idle */
+    uint64_t h2d_bytes;           /* hsk_count(): input bytes copied (or read in place over PCIe) from the host */
+    uint64_t d2h_bytes;           /* result bytes copied to the host */
+    double   h2d_ms;              /* duration of the input copies (0 when the parse reads pinned host memory in place) */
+    double   d2h_ms;              /* duration of the result copies, whether or not they overlapped the kernels */
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int  hsk_abi_version(void);
 int  hsk_device_count(void);                       /* HIP devices visible to this process (0 if none / no driver) */
+/* Pinned (page-locked) host memory for the DnaBuffer handed to hsk_count(): such a buffer is read by the GPU in place, the
+ * transfer overlaps the minimizer scan.  Pageable memory works too (staged copies first).  NULL when the allocation fails. */
+void *hsk_host_alloc(uint64_t bytes);
+void  hsk_host_free(void *p);
 int  hsk_init(const hsk_config *cfg, hsk_ctx **out);
 void hsk_destroy(hsk_ctx *ctx);
 const char *hsk_strerror(int status);

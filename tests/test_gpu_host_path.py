@@ -1,0 +1,49 @@
+"""hsk_count() from host memory: pinned input read in place by the scan (zero-copy ingest), pageable input (staged copy),
+device-side validation of the read index, early result copies -- all must give the list the device-resident path gives."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(H, n=400000):
+    from hysortk_amd import synth
+    return synth.packed_reads(3000000, 150, n, 5)
+
+
+def test_pinned_zero_copy_equals_pageable_and_device_paths(monkeypatch):
+    import hysortk_amd as H
+    packed, off, lens = _workload(H)                           # 15 MB: below the zero-copy threshold unless forced
+    nb = (150 + 3) // 4
+    reps = 3                                                   # > 16 MB of packed reads: the pinned path reads them in place
+    packed = np.tile(packed, reps); lens = np.tile(lens, reps)
+    off = np.arange(lens.size, dtype=np.uint64) * np.uint64(nb)
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
+    with H.Context(K=31, M=17, L=2, U=200, ntasks=16) as c:
+        a = c.count((packed, off, lens))                       # pageable: staged copies
+        b = c.count((pp, po, pl))                              # pinned: scan_kernel reads the host buffer, writes the HBM copy
+        st = c.stats()
+        b2 = c.count((pp, po, pl))                             # again: pinned result block reused, early copies sized from the last call
+    H.pinned_free(pp); H.pinned_free(po); H.pinned_free(pl)
+    assert len(a) > 100000
+    for x in (b, b2):
+        assert np.array_equal(a.kmers, x.kmers) and np.array_equal(a.cnt, x.cnt) and np.array_equal(a.task_off, x.task_off) and np.array_equal(a.histo, x.histo)
+    assert st["h2d_bytes"] > 2 * packed.size and st["d2h_bytes"] > 0
+
+
+def test_invalid_read_index_is_rejected_on_the_device():
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 1000                                       # large enough for the device-side check
+    packed, off, lens = synth.packed_reads(500000, 150, n, 9)
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=8) as c:
+        good = c.count((packed, off, lens))
+        bad = off.copy(); bad[n // 2] = bad[n // 2 - 1]        # overlaps its predecessor
+        with pytest.raises(H.HskError):
+            c.count((packed, bad, lens))
+        bad = lens.copy(); bad[-1] = 4000                      # leaves the packed buffer
+        with pytest.raises(H.HskError):
+            c.count((packed, off, bad))
+        again = c.count((packed, off, lens))                   # the context stays usable
+    assert np.array_equal(good.kmers, again.kmers) and np.array_equal(good.cnt, again.cnt)

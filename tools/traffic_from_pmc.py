@@ -24,5 +24,12 @@ if dom:
     d = res[dom[0]]
     o["dominant_kernel"] = dom[0]
     o["onesweep_bytes_per_launch"] = (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
+# whole counting path (one step; the PMC passes run bench.py --steps 1 --warmup 0): everything but the synthetic-read generator
+path = 0.0
+for k, d in res.items():
+    if k.startswith("synth_"):
+        continue
+    path += d["launches"] * (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
+o["path_bytes_per_step"] = path
 json.dump(o, open(out, "w"), indent=1)
 print(json.dumps({k: o[k] for k in o if k != "kernels"}, indent=1))
