@@ -432,7 +432,7 @@ static int stage_task_kmers_impl(hsk_ctx *c, const DevInput &d, uint64_t packed_
         u64 *dk, *dv = nullptr;
         DALLOC(c, dk, u64 *, ts.nkmers * NW * 8 + 64);
         if (ext) DALLOC(c, dv, u64 *, ts.nkmers * 8 + 64);
-        rc = expand_task<NW>(c, ts, st.sm_len, source_from_packed(d.packed, packed_bytes, st.sm_gpos), st.sm_pos, st.sm_rid, dk, dv);
+        rc = expand_task<NW>(c, ts, st.sm_len, source_from_store(st, d.packed, packed_bytes), st.sm_pos, st.sm_rid, dk, dv);
         if (rc == HSK_OK) {
             HIPCHK(c, hipMemcpyAsync(keys, dk, ts.nkmers * NW * 8, hipMemcpyDeviceToHost, c->stream));
             std::vector<u64> hv;

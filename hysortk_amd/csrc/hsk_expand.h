@@ -154,6 +154,7 @@ struct ExpandTask {
     const ExpSeg *segs; int nseg; u32 pad_;
     const u8 *sm_len; const u64 *src8; u64 src_bit0, src_words;
     const u64 *sm_gpos; const u32 *sm_pos; const int32_t *sm_rid;
+    const u32 *sm_boff;            // byte-store mode: supermer s starts at byte seg.byte_off + sm_boff[s] of src8 (src_bit0 = 0)
     const u64 *tile_off; u64 ntiles;
     u64 *keys_out, *vals_out;
     u64 *ghist;                    // [npass][256] digit histograms of this task (null: none)
@@ -213,7 +214,10 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
             const u32 s = tid * EXP_SPT + i;
             const u32 ni = (nk[i] + EXP_RUN - 1) / EXP_RUN;
             s_boff[s] = eb; s_koff[s] = ek; s_ioff[s] = ei;
-            if (t.sm_gpos && s < ns) s_gpos[s] = t.sm_gpos[seg.sup_off + first + s];
+            if (s < ns) {
+                if (t.sm_boff) s_gpos[s] = 4 * (seg.byte_off + (u64)t.sm_boff[seg.sup_off + first + s]);
+                else if (t.sm_gpos) s_gpos[s] = t.sm_gpos[seg.sup_off + first + s];
+            }
             for (u32 j = 0; j < ni; ++j) s_isup[ei + j] = (u16)s;        // item -> supermer
             eb += nb[i]; ek += nk[i]; ei += ni;
         }
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(EXP_THREADS) void expand_kernel(ExpandArgs a)
                 const u32 nks = s_koff[sidx + 1] - k0;
                 n_cnt = nks - i0 < (u32)EXP_RUN ? nks - i0 : (u32)EXP_RUN;
                 n_out0 = k0 + i0;
-                const u64 bit = t.sm_gpos ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
+                const u64 bit = (t.sm_gpos || t.sm_boff) ? (t.src_bit0 + 2 * (s_gpos[sidx] + (u64)i0)) : (8 * (byte_abs + s_boff[sidx]) + 2 * (u64)i0);
                 const u64 wi = bit >> 6; n_sh = (u32)(bit & 63);
 #pragma unroll
                 for (int x = 0; x < NW + 2; ++x) n_raw[x] = (wi + x < t.src_words) ? t.src8[wi + x] : 0;

@@ -67,7 +67,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
         for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles) { tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; ++m; }
         // (ts.segs is host memory owned by the caller and stays alive until the next sync)
         // bases read in place (one GPU, one segment per task): no tile sums, a tile takes its output range with an atomic
-        for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles && (!jobs[i].src.gpos || jobs[i].ts->segs.size() != 1)) reserve = false;
+        for (int i = 0; i < njobs; ++i) if (jobs[i].ts->ntiles && (!reads_in_place(jobs[i].src) || jobs[i].ts->segs.size() != 1)) reserve = false;
         if (!reserve_enabled) reserve = false;
         int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, pre != nullptr, !reserve); if (rc) return rc;
     }
@@ -82,7 +82,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
         if (j.ts->ntiles == 0) continue;
         ExpandTask &t = a.t[nt];
         t.segs = x[nt].d_segs; t.nseg = (int)j.ts->segs.size(); t.sm_len = j.sm_len;
-        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos; t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid;
+        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos; t.sm_boff = j.src.boff; t.sm_pos = j.sm_pos; t.sm_rid = j.sm_rid;
         t.tile_off = reserve ? nullptr : x[nt].d_tile_off; t.kcursor = reserve ? d_kcur + nt : nullptr; t.ntiles = j.ts->ntiles; t.keys_out = j.keys; t.vals_out = j.vals; t.ghist = npass ? j.ghist : nullptr;
         max_tiles = std::max(max_tiles, t.ntiles);
         ++nt;
@@ -128,6 +128,7 @@ static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const B
 // travels (pack_group, on the communication stream, overlapped with the sort of the previous group)
 static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src, bool run_kernel = true)
 {
+    if (st.sm_boff) { st.base = src; st.group_packed.assign(4096, 1); return HSK_OK; }      // byte-store mode: the placement already wrote them
     DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
     st.base = src;
     if (st.tot_sup == 0 || !run_kernel) return HSK_OK;

@@ -9,7 +9,9 @@
 struct BaseSource {
     const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
     const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
+    const u32 *boff = nullptr;                                  // byte-store mode: supermer s starts at byte seg.byte_off + boff[s] of the stream
 };
+static bool reads_in_place(const BaseSource &b) { return b.gpos != nullptr || b.boff != nullptr; }   // no prefix sums needed to find a supermer's bases
 static BaseSource source_from_packed(const u8 *d_packed, u64 packed_bytes, const u64 *gpos)
 {
     BaseSource b; const uintptr_t p = (uintptr_t)d_packed;
@@ -25,6 +27,7 @@ static BaseSource source_from_bytes(const u8 *bytes, u64 nbytes)
 struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
+    u32 *sm_boff = nullptr;       // byte-store mode (place_bytes_kernel): sm_bytes is complete, sm_boff[slot] = offset inside the task's byte run
     u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
     std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
@@ -35,8 +38,29 @@ struct SupermerStore {
 
 static void free_store(hsk_ctx *c, SupermerStore &s)
 {
-    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid);
-    s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr;
+    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid); c->pool.release(s.sm_boff);
+    s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr; s.sm_boff = nullptr;
+}
+
+// where the extraction finds the bases of the store's supermers: the store's own byte runs, or (position mode) the packed reads
+static BaseSource source_from_store(const SupermerStore &st, const u8 *d_packed, u64 packed_bytes)
+{
+    if (!st.sm_boff) return source_from_packed(d_packed, packed_bytes, st.sm_gpos);
+    BaseSource b = source_from_bytes(st.sm_bytes, st.tot_bytes);
+    b.boff = st.sm_boff;
+    return b;
+}
+
+// Byte-store placement or position placement?  Measured on 10 Gbp (one GPU): the byte store cuts the extraction's fetch
+// traffic from ~6.5x to ~1x its algorithmic read bytes, but the extraction does not get faster (38.3 against 37.6 ms: it is
+// bound by its chain of dependent phases, not by bandwidth) while the placement pays for the extra stores (12.8 against
+// 8.4 ms).  With several GPUs the bytes must be produced anyway (they are what travels), and writing them here replaces
+// pack_kernel's scattered gather (~20 ms per rank and step).  So: byte store when the supermers travel, positions when
+// they stay; HSK_PLACE_BYTES=0/1 forces either.
+static bool place_bytes_enabled(bool supermers_travel)
+{
+    static const int env = getenv("HSK_PLACE_BYTES") ? atoi(getenv("HSK_PLACE_BYTES")) : -1;
+    return env < 0 ? supermers_travel : env != 0;
 }
 
 static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen,
@@ -165,7 +189,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
 
 // `order` (storage order of tasks) must be a permutation of 0..ntasks-1.
 // skip (optional, [ntasks]): tasks whose supermers are not stored (they take no room and report zero totals)
-static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st, const std::vector<u8> *skip = nullptr)
+static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, SupermerStore &st, const std::vector<u8> *skip = nullptr, bool supermers_travel = false)
 {
     const bool ext = c->cfg.extension != 0;
     const u32 ntasks = j.ntasks;
@@ -195,14 +219,27 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     a.task_skip = d_skip;
     hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base);
     DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
-    DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);          // reference mode: bases stay in the packed reads
+    // byte-store mode (fast parse path): the supermers' bases are copied into per-task byte runs while the reads stream through
+    // place_bytes_kernel once; positions are kept only where something still needs them (EXTENSION: pos / rid lookup)
+    bool bytes_mode = j.fast && place_bytes_enabled(supermers_travel) && a.rec_cap <= PLACE_BYTES_REC;
+    for (u32 t = 0; t < ntasks && bytes_mode; ++t) if (st.task_tot[3 * t + 1] >= (1ULL << 32)) bytes_mode = false;     // 32-bit offsets inside a task's run
+    if (bytes_mode) {
+        DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 256);
+        DALLOC(c, st.sm_boff, u32 *, st.tot_sup * 4 + 64);
+        HIPCHK(c, hipMemsetAsync(st.sm_bytes + st.tot_bytes, 0, 256, c->stream));     // the extraction's windows read a few words past the last supermer
+    }
+    if (!bytes_mode || ext) DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);      // position mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
-    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos;
+    a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.sm_bytes = st.sm_bytes; a.sm_boff = st.sm_boff; a.task_base3 = d_task_base;
     if (st.tot_sup) {
         if (j.fast) {
             const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
             EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 4; ep.keys = st.tot_sup; (void)hipEventRecord(ep.a, c->stream); }
-            hipLaunchKernelGGL(place_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, c->stream, a);
+            if (bytes_mode) {
+                ParseArgs ab = a;
+                ab.place_group = std::max<u32>(1, std::min<u32>(PLACE_BYTES_TILES, PLACE_BYTES_REC / a.rec_cap));
+                hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4, c->stream, ab);
+            } else hipLaunchKernelGGL(place_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, c->stream, a);
             if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         }
         else if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);

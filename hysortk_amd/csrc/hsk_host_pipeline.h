@@ -610,7 +610,7 @@ static int heavy_preaggregate(hsk_ctx *c, ParseJob &job, const u8 *d_packed, u64
     ResultPriv *rp = new ResultPriv(); tmp.priv = rp; tmp.nw = NW;
     PhaseTimer pt(c);
     ProcExtra ex; ex.force_batch = true;
-    rc = process_rank<NW>(c, ntasks, own, 0, segs, sth.sm_len, source_from_packed(d_packed, packed_bytes, sth.sm_gpos), nullptr, nullptr, &tmp, rp, pt, false, nullptr, &ex);
+    rc = process_rank<NW>(c, ntasks, own, 0, segs, sth.sm_len, source_from_store(sth, d_packed, packed_bytes), nullptr, nullptr, &tmp, rp, pt, false, nullptr, &ex);
     c->cfg = keep; c->forbid_long_way = false;
     if (rc == HSK_OK) {
         for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t] && t < rp->dev_tasks.size()) { lists[t] = rp->dev_tasks[t]; failed[t] = lists[t].failed ? 1 : 0; }
@@ -693,7 +693,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }
             std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
         }
-        rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr);
+        rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr, nranks > 1);
         parse_release(c, job);
         if (rc) return rc;
     }
@@ -705,7 +705,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // After this block `segs[t]` lists where the supermers of owned task t live.
     std::vector<TaskSegs> segs(ntasks);
     const u8 *x_len = st.sm_len; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
-    BaseSource x_src = source_from_packed(d_packed, packed_bytes, st.sm_gpos);
+    BaseSource x_src = source_from_store(st, d_packed, packed_bytes);
     ExchangeBuffers xb;
     GroupFeeder feeder; bool fed = false;
     pt.begin(PH_EXCH);
@@ -854,7 +854,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<SupermerStore> st(R);
     std::vector<u64> M((size_t)R * ntasks * 3, 0);
     for (int r = 0; r < R; ++r) {
-        int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr);
+        int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr, R > 1);
         parse_release(c, jobs[r]);
         if (rc) { release_jobs(); return rc; }
         rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos), !overlap_enabled()); if (rc) { release_jobs(); return rc; }

@@ -46,7 +46,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         xi[i] = -1;
         if (!jobs[i].ts->ntiles) continue;
         tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; xi[i] = m++;
-        if (!jobs[i].src.gpos) offsets = true;           // byte streams: a tile's input offset is a prefix over the tiles before it
+        if (!reads_in_place(jobs[i].src)) offsets = true;           // byte streams: a tile's input offset is a prefix over the tiles before it
     }
     if (m == 0) return HSK_OK;
     int rc = expand_prepare_batch(c, m, tsp, lens, x, stream, false, offsets); if (rc) return rc;
@@ -68,7 +68,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         DALLOC(c, sb.d_tile_src[i], u64 *, (size_t)(n / XS_CHUNK + 257) * 8);
         HIPCHK(c, hipMemsetAsync(sb.d_map[i], 0, (size_t)256 * t.vmax * 4, stream));
         t.segs = x[xi[i]].d_segs; t.nseg = (int)j.ts->segs.size(); t.sm_len = j.sm_len;
-        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos;
+        t.src8 = j.src.src8; t.src_bit0 = j.src.bit0; t.src_words = j.src.nwords; t.sm_gpos = j.src.gpos; t.sm_boff = j.src.boff;
         t.tile_off = offsets ? x[xi[i]].d_tile_off : nullptr; t.ntiles = j.ts->ntiles;
         t.chunks = j.keys; t.cursor = sb.d_cursor + (size_t)i * 256; t.map = sb.d_map[i]; t.ctl = sb.d_ctl + (size_t)i * 4;
         t.ghist = j.ghist + 256; t.tile_src = sb.d_tile_src[i];

@@ -71,6 +71,12 @@ struct ParseArgs {
     u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
     u32 *tile_r0;              // optional [ntiles] (EXTENSION): first read overlapping the tile, kept for resolve_pos_rid_kernel
     const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
+    // byte-store placement (place_bytes_kernel): the supermer's re-aligned bases (SupermerEncoder::copy_bits, reference
+    // src/kmerops.cpp:1096-1107: (len + 3) / 4 bytes, tail bits zero) are written next to its length, task by task, so that the
+    // extraction streams a task's own bytes instead of pulling every line of the packed reads into every XCD's L2
+    u8 *sm_bytes;              // tasks in storage order, a task's supermers in slot order
+    u32 *sm_boff;              // [slot] first byte of the supermer, relative to its task's first byte
+    const u64 *task_base3;     // [ntasks][3] slot / byte / k-mer base of every task (parse_scan_kernel)
     u32 *packed_copy;          // optional (scan_kernel): `packed` is pinned HOST memory read in place over PCIe; every tile's words are
                                // also written here (HBM, packed_bytes + 64), so the ingest is fused into the one pass that hashes the reads
 };
@@ -782,6 +788,126 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
         }
         __syncthreads();
         for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
+    }
+}
+
+// Byte-store placement.  Same job as place_kernel, and in addition every supermer's bases are copied out of the packed
+// reads (staged in LDS for the tiles of the step, read ONCE and in order by the whole grid) into the task's byte run.
+// A record takes its slot AND its byte range with ONE 64-bit LDS atomic per task ({records << 32 | bytes}), so slot order
+// and byte order agree inside a (step, task) run: the byte run of a task is the concatenation of its supermers in slot
+// order (what the exchange ships), and sm_boff[slot] points at each one (what the expand on this GPU uses: no prefix sums).
+// The bytes leave as unaligned 8-byte stores from one lane per supermer: first 8-byte words front to back, then one word
+// ending at the supermer's last byte (overlapping the previous one); consecutive lanes hold consecutive supermers of a
+// task, so a wave instruction covers one contiguous stretch.  gfx950 global stores need no alignment (the kernel-mode
+// driver runs every queue in unaligned-access mode); a word that straddles a cache line is split by the hardware.
+// dynamic LDS: u64 cur[nt], u64 curb[nt], u64 tbase[nt], u64 tc[nt], u32 tpre[nt], u32 pad[nt], u64 srt[PLACE_BYTES_REC], u32 words[...]
+constexpr u32 PLACE_BYTES_REC = 4096;                  // records of one step (rec_cap * place_group)
+constexpr u32 PLACE_BYTES_TILES = 8;                   // tiles per step at most
+constexpr u32 PLACE_BYTES_WORDS = PLACE_BYTES_TILES * (PARSE_TILE / 16) + 24;   // their packed words + the overhang of the last supermer (<= 222 bases) + overread
+__global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
+{
+    constexpr int RPT = PLACE_BYTES_REC / PARSE_THREADS;
+    __shared__ u32 s_scan[12];
+    __shared__ u32 s_go[PLACE_BYTES_TILES + 4];
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];
+    const int tid = threadIdx.x;
+    const int K = a.k;
+    const u32 nt = a.ntasks;
+    u64 *s_curb = s_cur + nt, *s_tbase = s_curb + nt, *s_tc = s_tbase + nt;
+    u32 *s_tpre = reinterpret_cast<u32 *>(s_tc + nt);
+    u64 *s_srt = reinterpret_cast<u64 *>(s_tpre + 2 * nt);
+    u32 *s_words = reinterpret_cast<u32 *>(s_srt + PLACE_BYTES_REC);
+    for (u32 t = tid; t < nt; t += PARSE_THREADS) {
+        s_cur[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2];
+        s_curb[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2 + 1];
+        s_tbase[t] = a.task_base3[3 * t + 1];
+    }
+    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    const u32 G = a.place_group;
+    const u32 *p32 = reinterpret_cast<const u32 *>(a.packed);
+    for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
+        const u64 tfirst = tile0 + t0;
+        if (tfirst >= a.ntiles) break;
+        u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
+        if (tfirst + ng > a.ntiles) ng = (u32)(a.ntiles - tfirst);
+        __syncthreads();                                                // previous step done with s_go / s_tc / s_srt / s_words
+        if (tid == 0) {
+            u32 run = 0;
+            for (u32 j = 0; j < ng; ++j) { s_go[j] = run; u32 n = a.tile_nrec[tfirst + j]; run += n < a.rec_cap ? n : a.rec_cap; }
+            for (u32 j = ng; j <= PLACE_BYTES_TILES; ++j) s_go[j] = run;
+        }
+        for (u32 t = tid; t < nt; t += PARSE_THREADS) s_tc[t] = 0;
+        {   // the packed words of the step's tiles (+ overhang) as big-endian words
+            const u64 w0 = tfirst * (PARSE_TILE / 16);
+            const u32 nw = ng * (PARSE_TILE / 16) + 24;
+            for (u32 i = tid; i < nw; i += PARSE_THREADS) {
+                const u64 b = (w0 + i) * 4;
+                u32 wv = 0;
+                if (b + 4 <= a.packed_bytes) wv = __builtin_bswap32(p32[w0 + i]);
+                else if (b < a.packed_bytes) { for (u64 q = b; q < a.packed_bytes; ++q) wv |= (u32)a.packed[q] << (24 - 8 * (q & 3)); }
+                s_words[i] = wv;
+            }
+        }
+        __syncthreads();
+        const u32 total = s_go[PLACE_BYTES_TILES];
+        u32 rec[RPT]; u64 got[RPT];
+#pragma unroll
+        for (int x = 0; x < RPT; ++x) {
+            const u32 i = x * PARSE_THREADS + tid;
+            rec[x] = 0xFFFFFFFFu; got[x] = 0;
+            if (i < total) {
+                u32 j = 0;
+                while (j + 1 < ng && s_go[j + 1] <= i) ++j;
+                const u32 r = a.tile_rec[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])];
+                rec[x] = r | (j << 28);
+                const u32 nb = (((r >> 11) & 127u) + (u32)K + 3u) >> 2;          // (k-mers - 1) + K bases
+                got[x] = atomicAdd((unsigned long long *)&s_tc[(r >> 18) & 1023u], (1ULL << 32) | (unsigned long long)nb);
+            }
+        }
+        __syncthreads();
+        {   // exclusive prefix of the per-task record counts
+            u32 c4[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; c4[j] = t < nt ? (u32)(s_tc[t] >> 32) : 0; sum += c4[j]; }
+            u32 e = block_excl_scan_256<u32>(sum, s_scan, nullptr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; if (t < nt) s_tpre[t] = e; e += c4[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < RPT; ++x)
+            if (rec[x] != 0xFFFFFFFFu) s_srt[s_tpre[(rec[x] >> 18) & 1023u] + (u32)(got[x] >> 32)] = (u64)rec[x] | (got[x] << 32);   // {record, byte offset in the task's run}
+        __syncthreads();
+        for (u32 i = tid; i < total; i += PARSE_THREADS) {
+            const u64 e = s_srt[i];
+            const u32 r = (u32)e, bo = (u32)(e >> 32);
+            const u32 d = (r >> 18) & 1023u;
+            if (a.task_skip && a.task_skip[d]) continue;
+            const u64 slot = s_cur[d] + (i - s_tpre[d]);
+            const u64 babs = s_curb[d] + bo;
+            const u32 len = ((r >> 11) & 127u) + (u32)K;
+            const u32 nb = (len + 3) >> 2;
+            a.sm_len[slot] = (u8)len;
+            a.sm_boff[slot] = (u32)(babs - s_tbase[d]);
+            if (a.sm_gpos) a.sm_gpos[slot] = (tfirst + (r >> 28)) * PARSE_TILE + (u64)(r & 2047);
+            const u32 bit0 = 2u * ((r >> 28) * (u32)PARSE_TILE + (r & 2047u));
+            const u64 tailmask = (len & 3u) ? ~(u64)(0xFFu >> (2 * (len & 3u))) : ~0ULL;   // zero bits behind the last base (in its byte = the lowest byte of a big-endian word)
+            u8 *dst = a.sm_bytes + babs;
+            if (nb >= 8) {
+                const u32 nfull = nb >> 3, rem = nb & 7u;
+                for (u32 q = 0; q < nfull; ++q) {
+                    u64 v = bits64_be32(s_words, bit0 + 64u * q);
+                    if (rem == 0 && q + 1 == nfull) v &= tailmask;
+                    *reinterpret_cast<u64 *>(dst + 8u * q) = __builtin_bswap64(v);
+                }
+                if (rem) { const u64 v = bits64_be32(s_words, bit0 + 8u * (nb - 8u)) & tailmask; *reinterpret_cast<u64 *>(dst + (nb - 8u)) = __builtin_bswap64(v); }
+            } else {
+                const u64 v = bits64_be32(s_words, bit0) & (tailmask << (8u * (8u - nb)) | ~(~0ULL >> (8u * (nb - 1u))));
+                for (u32 q = 0; q < nb; ++q) dst[q] = (u8)(v >> (56u - 8u * q));
+            }
+        }
+        __syncthreads();
+        for (u32 t = tid; t < nt; t += PARSE_THREADS) { const u64 c = s_tc[t]; s_cur[t] += c >> 32; s_curb[t] += c & 0xFFFFFFFFu; }
     }
 }
 

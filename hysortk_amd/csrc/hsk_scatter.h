@@ -59,6 +59,7 @@ struct ScatterTask {
     const ExpSeg *segs; int nseg; u32 vmax;          // vmax: map entries per digit (n / CHUNK + 1)
     const u8 *sm_len; const u64 *src8; u64 src_bit0, src_words;
     const u64 *sm_gpos; const u64 *tile_off; u64 ntiles;
+    const u32 *sm_boff;                              // byte-store mode: supermer s starts at byte seg.byte_off + sm_boff[s] of src8
     u64 *chunks;                                     // chunk store (records of NW words)
     u64 *cursor;                                     // [256] keys reserved per digit (zeroed)
     u32 *map;                                        // [256][vmax] physical chunk + 1 (zeroed)
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     __shared__ u32 s_dl[XS_SPAN][256];                                  // staged slot + s_dl[j][d] = slot in the chunk store (j-th chunk of the reservation)
     __shared__ u32 s_scr[XS_WAVES];
     __shared__ u32 s_blk[2];
-    __shared__ u64 s_seg[3][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile} of the task's segments
+    __shared__ u64 s_seg[4][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile, first byte} of the task's segments
     typedef __attribute__((address_space(1))) u32 G32;
     const int tid = threadIdx.x;
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
@@ -136,9 +137,12 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     const int nseg = t.nseg;
     const bool single = nseg == 1;                         // one GPU: one segment, kept in scalar registers
     const bool segs_lds = nseg <= XS_MAXSEG;               // the next tile's inputs are prefetched
-    const bool inplace = t.sm_gpos != nullptr;
-    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup;
-    if (!single && segs_lds && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
+    const bool byboff = t.sm_boff != nullptr;
+    const bool inplace = t.sm_gpos != nullptr || byboff;
+    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup, s0_byte = t.segs[0].byte_off;
+    if (!single && segs_lds && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; s_seg[3][tid] = sg.byte_off; }
+    // first base of supermer `idx` (absolute slot) of a segment whose bytes start at seg_byte
+    auto sup_pos = [&](u64 idx, u64 seg_byte) -> u64 { return byboff ? 4 * (seg_byte + (u64)t.sm_boff[idx]) : t.sm_gpos[idx]; };
     if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
 
     // Tiles are claimed in blocks of XS_CLAIM, two blocks ahead: the tile that follows the current one is always known,
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
             if (single) {
                 const u64 sidx = tl * XS_TILE + tid;
                 if (sidx < s0_n) {
-                    p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = t.sm_gpos[s0_sup + sidx];
+                    p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = sup_pos(s0_sup + sidx, s0_byte);
                     if (EXT) p_vb = (u64)t.sm_pos[s0_sup + sidx] | ((u64)(u32)t.sm_rid[s0_sup + sidx] << 32);
                 }
             } else {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
                 const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
                 if (sidx < s_seg[1][sg]) {
-                    p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = t.sm_gpos[s_seg[0][sg] + sidx];
+                    p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = sup_pos(s_seg[0][sg] + sidx, s_seg[3][sg]);
                     if (EXT) p_vb = (u64)t.sm_pos[s_seg[0][sg] + sidx] | ((u64)(u32)t.sm_rid[s_seg[0][sg] + sidx] << 32);
                 }
             }
@@ -191,13 +195,13 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         const u64 ntile = (j + 1 == (u32)XS_CLAIM) ? nblk : tile + 1;
         u32 claim = 0;
         if (j == 0 && tid == 0) claim = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        u64 sg_sup = s0_sup, sg_n = s0_n, sg_t0 = 0;
+        u64 sg_sup = s0_sup, sg_n = s0_n, sg_t0 = 0, sg_byte = s0_byte;
         if (single) { }
         else if (segs_lds) {
             int sg = 0;
             while (sg + 1 < nseg && s_seg[2][sg + 1] <= tile) ++sg;
-            sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg];
-        } else { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; }
+            sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg]; sg_byte = s_seg[3][sg];
+        } else { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; sg_byte = sp->byte_off; }
         const u64 first = (tile - sg_t0) * XS_TILE;
         const u32 ns = (u32)((sg_n - first) < (u64)XS_TILE ? (sg_n - first) : (u64)XS_TILE);
 
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         for (int x = 0; x < NW + 2; ++x) rawp[x] = p_raw[x];
         if (!p_have) {
             len = ((u32)tid < ns) ? t.sm_len[sg_sup + first + tid] : 0;
-            gp = (inplace && (u32)tid < ns) ? t.sm_gpos[sg_sup + first + tid] : 0;
+            gp = (inplace && (u32)tid < ns) ? sup_pos(sg_sup + first + tid, sg_byte) : 0;
         }
         XS_STAMP(12);
         const u32 nb = ((u32)tid < ns) ? ((len + 3) >> 2) : 0;
