@@ -536,6 +536,15 @@ class DeviceDna:
     def count(self, rid_base=None):
         return self.ctx.count_device(self.dp, self.nbytes, self.do, self.dl, self.nreads, rid_base=self.first_read_id if rid_base is None else rid_base)
 
+    def count_resident_device(self, rid_base=None):
+        """hsk_count_device with the result LEFT IN HBM (Context(keep_device=True)): a DeviceResult."""
+        if not self.ctx.keep_device:
+            raise ValueError("count_resident_device needs Context(keep_device=True)")
+        res = _lib.Result()
+        self.ctx._check(self.ctx.lib.hsk_count_device(self.ctx.h, self.dp, self.nbytes, self.do, self.dl, self.nreads,
+                                                      self.first_read_id if rid_base is None else rid_base, C.byref(res)))
+        return DeviceResult(self.ctx, res)
+
     def packed(self):
         return self.ctx.d2h(self.dp, self.nbytes) if self.nbytes else np.zeros(0, np.uint8)
 

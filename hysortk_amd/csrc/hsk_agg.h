@@ -68,9 +68,20 @@ __device__ __forceinline__ u32 agg_slot(u64 k)
     return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
 }
 
+// Diagnostic build only (-DHSK_DIAG): shader-clock sums per phase of agg_finish_kernel, stamped by thread 0 of every workgroup
+#ifdef HSK_DIAG
+__device__ unsigned long long g_agg_diag[16];
+#define AG_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ag_acc[i] = t_ - ag_last; ag_last = t_; } } while (0)
+#else
+#define AG_STAMP(i) do { } while (0)
+#endif
+
 template <int LOG2CAP>
 __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 {
+#ifdef HSK_DIAG
+    unsigned long long ag_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ag_last = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
     __shared__ u64 s_key[CAP];      // hash table, then the distinct keys compacted, then sorted
@@ -83,11 +94,13 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     const int tid = threadIdx.x;
     const u64 s = t.bounds[b], e = t.bounds[b + 1];
     if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+    AG_STAMP(0);                                        // launch -> bounds known
 
 #pragma unroll
     for (int j = 0; j < PER; ++j) { s_key[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
     if (tid == 0) s_ovf = 0;
     __syncthreads();
+    AG_STAMP(1);                                        // table cleared
 
     // ---- 1. count the records of the bin in the table ------------------------------------------------------
     // 16 loads per lane are issued before the first insert: a typical bin (4096 records) costs one memory latency
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         }
     }
     __syncthreads();
+    AG_STAMP(2);                                        // records loaded and counted
     if (s_ovf) {
         if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
         return;
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
     __syncthreads();
+    AG_STAMP(3);                                        // distinct keys compacted
     if (D <= (u32)AG_THREADS) {
         // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
         u64 k = 0; u32 c = 0, r = 0;
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         }
     }
     const u64 *sk = s_key; const u32 *sc = s_cnt;
+    AG_STAMP(4);                                        // distinct keys ordered
 
     // ---- 3. filter, entries in key order to the bin's slots --------------------------------------------------
     u32 kept = 0;
@@ -176,6 +192,10 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         }
     }
     if (tid == 0) t.bin_cnt[b] = tot;
+    AG_STAMP(5);                                        // filtered and written
+#ifdef HSK_DIAG
+    if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_agg_diag[i], ag_acc[i]); atomicAdd(&g_agg_diag[8], 1ULL); atomicAdd(&g_agg_diag[9], (unsigned long long)(e - s)); atomicAdd(&g_agg_diag[10], (unsigned long long)D); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

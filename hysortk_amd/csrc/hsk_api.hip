@@ -92,7 +92,7 @@ static int validate_cfg(const hsk_config *cfg)
 {
     const int K = cfg->kmer_size, M = cfg->minimizer_size;
     if (!(2 < K && K < 96) || (K % 32) == 0) return 0;            // compiletime.h:10; K%32==0 is UB in the reference
-    if (!(0 < M && M < K) || M > 31) return 0;                      // Makefile:50-52
+    if (!(0 < M && M < K) || (M % 32) == 0) return 0;               // Makefile:50-52; M % 32 == 0 is the same undefined shift in Mmer::GetExtension (supermer.hpp:265)
     if (!(0 < cfg->lower_freq && cfg->lower_freq <= cfg->upper_freq && cfg->upper_freq <= 65535)) return 0;  // compiletime.h:21
     if (cfg->extension != 0 && cfg->extension != 1) return 0;
     if (cfg->ntasks < 0 || cfg->ntasks > HSK_MAX_TASKS) return 0;
@@ -789,6 +789,12 @@ extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
 #ifdef HSK_DIAG
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_diag), sizeof(unsigned long long) * n) != hipSuccess) return HSK_ERR_HIP;
     if (n >= 32) { if (hipMemcpyFromSymbol(out + 20, HIP_SYMBOL(hsk::g_scan_diag), sizeof(unsigned long long) * 10) != hipSuccess) return HSK_ERR_HIP; }
+    if (reset & 4) {                                            // agg_finish_kernel's stamps instead
+        unsigned long long z[16] = {0};
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_agg_diag), sizeof(unsigned long long) * (n < 16 ? n : 16)) != hipSuccess) return HSK_ERR_HIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hsk::g_agg_diag), z, sizeof z) != hipSuccess) return HSK_ERR_HIP;
+        return HSK_OK;
+    }
     if (reset & 2) {                                            // the fused expand + scatter kernel's stamps instead
         unsigned long long z[16] = {0};
         if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsk::g_xs_diag), sizeof(unsigned long long) * (n < 16 ? n : 16)) != hipSuccess) return HSK_ERR_HIP;

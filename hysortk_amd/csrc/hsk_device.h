@@ -33,6 +33,26 @@ __host__ __device__ __forceinline__ u64 murmur64_8(u64 key)
     return h1 + h2;
 }
 
+// The same hash over NW 64-bit words (16 / 24 bytes: Mmer<2> / Mmer<3>, minimizers of 33..63 / 65..94 bases): one body
+// block of 16 bytes, and for 24 bytes an 8-byte tail (reference src/hashfuncs.cpp:42-114 with len = 8 * NW).
+template <int NW>
+__host__ __device__ __forceinline__ u64 murmur64_words(const u64 (&w)[NW])
+{
+    if (NW == 1) return murmur64_8(w[0]);
+    const u64 c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    u64 h1 = 313ULL, h2 = 313ULL;
+    u64 k1 = w[0], k2 = w[NW > 1 ? 1 : 0];
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    if (NW == 3) { u64 t1 = w[NW > 2 ? 2 : 0]; t1 *= c1; t1 = rotl64(t1, 31); t1 *= c2; h1 ^= t1; }
+    h1 ^= (u64)(8 * NW); h2 ^= (u64)(8 * NW);
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    return h1 + h2;
+}
+
 // ---- 2-bit sequence helpers ------------------------------------------------------------------
 // Reverse the order of the 32 2-bit groups of x (base i <-> base 31-i).
 __host__ __device__ __forceinline__ u64 rev2(u64 x)

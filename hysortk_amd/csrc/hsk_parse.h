@@ -128,6 +128,19 @@ __device__ __forceinline__ void supermer_runs(const u16 *s_dest, u64 *s_bnd, u32
     }
 }
 
+// canonical M-mer hash at base position p of the staged tile, M > 32: Mmer<2> / Mmer<3> (reference include/supermer.hpp:23,
+// GetRep :299, GetHash :308-313 = murmur over all 16 / 24 key bytes)
+template <int MW>
+__device__ __forceinline__ u64 wide_mmer_hash(const u32 *s_words, u32 p, int M)
+{
+    Mer<MW> fw;
+#pragma unroll
+    for (int x = 0; x < MW; ++x) fw.w[x] = bits64_be32(s_words, 2u * p + 64u * (u32)x);
+    fw.w[MW - 1] &= ~0ULL << (64 * MW - 2 * M);
+    const Mer<MW> c = canonical<MW>(fw, M);
+    return murmur64_words<MW>(c.w);
+}
+
 template <int MODE, bool EXT>
 __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
 {
@@ -205,12 +218,18 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
         const int p0 = tid * PARSE_PPT;
         const bool cached = cached_emit;
         // ---- 2. canonical m-mer hashes for positions [0, TILE + W - 1) ---------------------------
-        const u64 mmask = ~0ULL << (64 - 2 * M);
+        const u64 mmask = ~0ULL << (64 - 2 * (M < 32 ? M : 31));
         if (!cached) {
-            for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) {
-                u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
-                u64 tw = twin1(fw, M);
-                s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+            if (M < 32) {
+                for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) {
+                    u64 fw = bits64_be32(s_words, 2u * (u32)p) & mmask;
+                    u64 tw = twin1(fw, M);
+                    s_hash[p] = murmur64_8(tw < fw ? tw : fw);
+                }
+            } else if (M < 64) {
+                for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) s_hash[p] = wide_mmer_hash<2>(s_words, (u32)p, M);
+            } else {
+                for (int p = tid; p < PARSE_TILE + W - 1; p += PARSE_THREADS) s_hash[p] = wide_mmer_hash<3>(s_words, (u32)p, M);
             }
         }
         __syncthreads();

@@ -42,7 +42,7 @@ typedef enum {
 /* Runtime form of the reference's compile-time macros (reference Makefile:1-46). */
 typedef struct {
     int32_t kmer_size;        /* KMER_SIZE        2 < K < 96, K % 32 != 0 (reference UB, kmer.hpp:260) */
-    int32_t minimizer_size;   /* MINIMIZER_SIZE   0 < M < K, M <= 31 */
+    int32_t minimizer_size;   /* MINIMIZER_SIZE   0 < M < K, M % 32 != 0 (one-, two- and three-word minimizers) */
     int32_t lower_freq;       /* LOWER_KMER_FREQ  1 <= L <= U */
     int32_t upper_freq;       /* UPPER_KMER_FREQ  U <= 65535 */
     int32_t extension;        /* EXTENSION        0 | 1: carry (PosInRead, ReadId) through the sort */

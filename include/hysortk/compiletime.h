@@ -24,7 +24,8 @@
 
 static_assert(KMER_SIZE > 2 && KMER_SIZE < 96, "KMER_SIZE must be in (2, 96)");
 static_assert(KMER_SIZE % 32 != 0, "KMER_SIZE % 32 == 0 is undefined behaviour in the reference (kmer.hpp:260) and rejected here");
-static_assert(MINIMIZER_SIZE > 0 && MINIMIZER_SIZE < KMER_SIZE && MINIMIZER_SIZE <= 31, "MINIMIZER_SIZE must be < KMER_SIZE and <= 31");
+static_assert(MINIMIZER_SIZE > 0 && MINIMIZER_SIZE < KMER_SIZE && MINIMIZER_SIZE % 32 != 0,
+              "MINIMIZER_SIZE must be < KMER_SIZE; MINIMIZER_SIZE % 32 == 0 is undefined behaviour in the reference (supermer.hpp:265) and rejected here");
 static_assert(LOWER_KMER_FREQ > 0 && LOWER_KMER_FREQ <= UPPER_KMER_FREQ && UPPER_KMER_FREQ <= std::numeric_limits<uint16_t>::max(),
               "need 0 < LOWER_KMER_FREQ <= UPPER_KMER_FREQ <= 65535");
 static_assert(EXTENSION == 0 || EXTENSION == 1, "EXTENSION is 0 or 1");

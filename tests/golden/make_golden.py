@@ -36,7 +36,11 @@ VARIANTS = {  # name: (K, M, L, U, EXT, SORT, LOG)
     "k31f": (31, 17, 3, 40, 0, 2, 1),
     "k21": (21, 9, 1, 65535, 0, 1, 1),
     "k31log": (31, 17, 1, 65535, 0, 2, 2),
+    # multi-word minimizers (Mmer<2>, Mmer<3>: 16- and 24-byte murmur), added in round 2 with `--only k51m35,k77m65`
+    "k51m35": (51, 35, 1, 65535, 0, 2, 1),
+    "k77m65": (77, 65, 1, 65535, 0, 2, 1),
 }
+ROUND1 = ("k31", "k31ext", "k51", "k51p", "k31f", "k21", "k31log")
 
 
 def build(v):
@@ -106,9 +110,28 @@ def hist_of(stdout):
     return body[: j + 2]
 
 
+def only_variants(names):
+    """Fixtures of additional macro sets on the SAME inputs (stage reads re-derived from the seed, reads_small.fa as committed)."""
+    rng = np.random.default_rng(20251003)
+    seqs = stage_reads(rng)
+    tmp = os.path.join(REF, "stage_reads.txt")
+    open(tmp, "w").write("\n".join(seqs) + "\n")
+    fa = os.path.join(HERE, "reads_small.fa")
+    for v in names:
+        build(v)
+        out = run([os.path.join(REF, v, "ref_harness"), "stages", tmp, "5", "47"])
+        json.dump(json.loads(out), open(os.path.join(HERE, "stages_%s.json" % v), "w"), separators=(",", ":"))
+        outp = os.path.join(HERE, "count_%s.txt" % v)
+        so = run([os.path.join(REF, v, "ref_harness"), "count", fa, outp])
+        open(os.path.join(HERE, "hist_%s.txt" % v), "w").write(hist_of(so))
+        print("wrote fixtures of", v)
+
+
 def main():
+    if '--only' in sys.argv:
+        return only_variants(sys.argv[sys.argv.index('--only') + 1].split(","))
     only_mr = '--multirank-only' in sys.argv
-    for v in VARIANTS:
+    for v in ROUND1:
         build(v)
     rng = np.random.default_rng(20251003)
     fa = os.path.join(HERE, "reads_small.fa")

@@ -46,7 +46,7 @@ def test_pack_matches_reference_bytes(H):
 # ---------------------------------------------------------------------------------------------------
 # a4: destinations
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,tot", [("k31", 5), ("k31", 47), ("k51", 5), ("k21", 47)])
+@pytest.mark.parametrize("variant,tot", [("k31", 5), ("k31", 47), ("k51", 5), ("k21", 47), ("k51m35", 5), ("k51m35", 47), ("k77m65", 47)])
 def test_stage_destinations_golden(H, variant, tot):
     g = util.load_json("stages_%s.json" % variant)
     seqs = [rd["seq"] for rd in g["reads"]]
@@ -153,7 +153,7 @@ def test_stage_count_sorted(H, L, U, nw):
 # ---------------------------------------------------------------------------------------------------
 # the whole path against the reference's own output
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["k31", "k31f", "k21", "k51"])
+@pytest.mark.parametrize("variant", ["k31", "k31f", "k21", "k51", "k51m35", "k77m65"])
 def test_count_golden_raw_order(H, variant):
     """ntasks = 5 (what the reference used: 1 rank x 8 threads): the raw KmerListS is reproduced
     element for element, and so is the printed histogram."""
@@ -289,7 +289,7 @@ def test_long_records_and_tile_edges(H, O, ntasks):
 
 
 def test_invalid_config_is_rejected(H):
-    for kw in (dict(K=32), dict(K=2), dict(K=96), dict(M=31, K=31), dict(L=0), dict(L=5, U=4), dict(U=70000), dict(EXT=2)):
+    for kw in (dict(K=32), dict(K=2), dict(K=96), dict(M=31, K=31), dict(M=32, K=51), dict(M=64, K=77), dict(L=0), dict(L=5, U=4), dict(U=70000), dict(EXT=2)):
         with pytest.raises(H.HskError):
             H.Context(**kw)
 
@@ -388,6 +388,72 @@ def test_full_size_properties_both_expand_paths():
     outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split() for env in ({}, {"HSK_FUSED_SCATTER": "0"})]
     assert outs[0] == outs[1], outs
     assert int(outs[0][0]) > 300_000_000 and int(outs[0][3]) == 40 and int(outs[0][4]) == 40
+
+
+def test_full_size_properties_k51(H):
+    """BASELINE.md section 3, second record shape at full size: the 10 Gbp of reads at K=51 (two-word keys, 6.67e9 51-mers,
+    unfiltered).  Size-independent properties: checksum of counts = number of k-mers, histogram consistent, every task strictly
+    ascending as a little-endian two-word integer (RADULS order), unused low bits clear, no k-mer in two tasks (sampled), and the
+    list is reproduced exactly by a second run."""
+    G, RL = 312_500_000, 150
+    NR = G * 32 // RL
+    total = NR * (RL - 51 + 1)
+    sums = []
+    for _ in range(2):
+        with H.Context(K=51, M=17, L=1, U=65535, ntasks=0) as c:
+            dp, nb, do, dl = c.synth_reads(G, RL, NR, 20251003)
+            r = c.count_device(dp, nb, do, dl, NR)
+            c.synth_free(dp, do, dl)
+            st = c.stats()
+        assert r.info["total_kmers"] == total
+        w0, w1, cnt = r.kmers[:, 0], r.kmers[:, 1], r.cnt
+        assert int(cnt.sum(dtype=np.uint64)) == total
+        assert int((r.histo * np.arange(r.histo.size, dtype=np.uint64)).sum()) == total and int(r.histo.sum()) == len(cnt)
+        assert not np.any(w1 & np.uint64((1 << 26) - 1))                 # K=51: 19 bases in word 1, 26 low bits unused
+        up = (w1[1:] > w1[:-1]) | ((w1[1:] == w1[:-1]) & (w0[1:] > w0[:-1]))
+        starts = r.task_off[1:-1].astype(np.int64)
+        up[starts[(starts > 0) & (starts < len(cnt))] - 1] = True
+        assert bool(up.all())
+        assert st["fused_tasks"] + st["redone_tasks"] == r.info["ntasks"]
+        h = np.bitwise_xor.reduce((w0 * np.uint64(0x9E3779B97F4A7C15)) ^ (w1 * np.uint64(0xC2B2AE3D27D4EB4F)) ^ cnt)
+        sums.append((len(cnt), int(h), int(w0.sum(dtype=np.uint64)), r.info["ntasks"]))
+        if len(sums) == 1:
+            sel = np.arange(0, len(cnt), 97)
+            pairs = np.stack([w1[sel], w0[sel]], axis=1)
+            assert np.unique(pairs, axis=0).shape[0] == sel.size         # sampled: a k-mer lives in exactly one task
+        del r, w0, w1, cnt, up
+    assert sums[0] == sums[1] and sums[0][0] > 250_000_000
+
+
+def test_full_size_properties_extension(H):
+    """Third record shape at full size: the 10 Gbp of reads at K=31 with EXTENSION=1 (8.0e9 k-mers, each carrying PosInRead and
+    ReadId through the sort), unfiltered, the result left in HBM and inspected task by task: the counts of a task's entries add up
+    to its payload length, payload slices tile the payload array exactly (payload_off = running sum of counts), every position is
+    a k-mer start of a 150-base read, every read id is one of this rank's reads, and the totals equal the number of k-mers."""
+    G, RL = 312_500_000, 150
+    NR = G * 32 // RL
+    total = NR * (RL - 31 + 1)
+    rid_base = 1000
+    with H.Context(K=31, M=17, L=1, U=65535, EXT=1, ntasks=0, keep_device=True) as c:
+        dp, nb, do, dl = c.synth_reads(G, RL, NR, 20251003)
+        with H.DeviceDna(c, dp, nb, do, dl, NR).count_resident_device(rid_base=rid_base) as dev:
+            seen_pay, seen_cnt, n_entries = 0, 0, 0
+            pos_hist = np.zeros(RL - 31 + 1, dtype=np.int64)
+            for t in range(dev.ntasks):
+                d = dev.fetch(t)
+                if not d["n"]:
+                    continue
+                k, cnt = d["kmers"][:, 0], d["cnt"]
+                assert np.all(k[1:] > k[:-1]) and not np.any(k & np.uint64(3))
+                assert int(cnt.sum(dtype=np.uint64)) == d["npay"]
+                po = d["payload_off"].astype(np.int64) - d["payload_base"]
+                assert po[0] == 0 and np.array_equal(po[1:], np.cumsum(cnt[:-1].astype(np.int64)))
+                assert int(d["pos"].max()) <= RL - 31 and int(d["rid"].min()) >= rid_base and int(d["rid"].max()) < rid_base + NR
+                pos_hist += np.bincount(d["pos"], minlength=pos_hist.size)
+                seen_pay += d["npay"]; seen_cnt += int(cnt.sum(dtype=np.uint64)); n_entries += d["n"]
+            assert seen_pay == seen_cnt == total and n_entries == dev.n
+            assert np.all(pos_hist == NR)                                 # every k-mer start position of every read exactly once
+        c.synth_free(dp, do, dl)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -631,7 +697,7 @@ def test_fasta_ingest_on_device(H, O, tmp_path):
     assert np.array_equal(res_d.kmers, res_h.kmers) and np.array_equal(res_d.cnt, res_h.cnt)
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_random_configurations_vs_oracle(H, O, seed):
     """Seeded sweep over K (one, two and three key words), M (window widths below and above 8, M > 25 takes the general parse
     kernels), task counts (single-task path, padded batches, full batches), L/U, EXTENSION and ragged reads (shorter than K,
@@ -639,6 +705,8 @@ def test_random_configurations_vs_oracle(H, O, seed):
     rng = np.random.default_rng(1000 + seed)
     K = int(rng.choice([5, 11, 15, 21, 27, 31, 33, 39, 41, 51, 63, 65, 77, 95]))
     M = int(rng.integers(max(1, min(K - 60, 20)), min(K, 32)))
+    if seed % 4 == 3 and K > 34:                                  # multi-word minimizers (M > 32; M % 32 == 0 is rejected like K % 32 == 0)
+        M = int(rng.choice([m for m in range(33, K) if m % 32]))
     EXT = int(rng.integers(0, 2)) if K < 64 else 0
     ntasks = int(rng.choice([1, 2, 5, 8, 11, 16, 24]))
     L = int(rng.choice([1, 1, 2, 3])); U = int(rng.choice([4, 40, 65535]))

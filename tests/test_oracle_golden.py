@@ -18,7 +18,7 @@ def test_murmur_known_answers():
     assert O.murmur64([0x1BE429F040000000]) == 0x465BB05EB02CF5F5
 
 
-@pytest.mark.parametrize("variant", ["k31", "k31ext", "k51", "k21"])
+@pytest.mark.parametrize("variant", ["k31", "k31ext", "k51", "k21", "k51m35", "k77m65"])
 def test_stage_vectors(variant):
     cfg = util.VARIANTS[variant]
     g = util.load_json("stages_%s.json" % variant)
@@ -56,7 +56,7 @@ def _oracle_count(variant, ntasks=5, **kw):
     return cfg, O.count(packed, off, lens, ntasks=ntasks, **cfg)
 
 
-@pytest.mark.parametrize("variant", ["k31", "k31f", "k21", "k51"])
+@pytest.mark.parametrize("variant", ["k31", "k31f", "k21", "k51", "k51m35", "k77m65"])
 def test_count_raw_order(variant):
     """1 rank x 8 threads -> tot_tasks = 5; the raw vector (per-task ascending runs, ascending task id)
     is reproduced element for element (k51: RADULS order = little-endian multiword)."""

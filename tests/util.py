@@ -14,6 +14,8 @@ VARIANTS = {  # name: dict(K, M, L, U, ext, sorter)   -- the macro sets the gold
     "k51p": dict(k=51, m=17, L=1, U=65535, ext=0, sorter=1),
     "k31f": dict(k=31, m=17, L=3, U=40, ext=0, sorter=2),
     "k21": dict(k=21, m=9, L=1, U=65535, ext=0, sorter=1),
+    "k51m35": dict(k=51, m=35, L=1, U=65535, ext=0, sorter=2),      # two-word minimizers (Mmer<2>, 16-byte murmur)
+    "k77m65": dict(k=77, m=65, L=1, U=65535, ext=0, sorter=2),      # three-word k-mers and minimizers (24-byte murmur)
 }
 
 
