@@ -138,6 +138,7 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
         hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HSK_ERR_HIP; }
     c->pinned_bytes = 1 << 20;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) { delete c; return HSK_ERR_OOM; }
+    c->comm.stage = (char *)c->pinned + (512u << 10); c->comm.stage_bytes = 256u << 10;     // second half of the staging area, 256 KB
     c->d_err = (u32 *)c->pool.alloc(256);
     if (!c->d_err) { delete c; return HSK_ERR_OOM; }
     (void)hipMemsetAsync(c->d_err, 0, 256, c->stream);
@@ -647,6 +648,15 @@ extern "C" int hsk_comm_selftest(hsk_ctx *c)
             (rc = cm.check(cm.api->AllReduce(d_a, d_a, h.size(), RCCL_UINT64, RCCL_MAX, cm.comm, c->stream), "ncclAllReduce(max)"))) { out = fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str()); break; }
         if (hipMemcpyAsync(h2.data(), d_a, h.size() * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { out = fail(c, HSK_ERR_HIP, "selftest download"); break; }
         if (h2 != h) { out = fail(c, HSK_ERR_COMM, "one-rank all-reduce changed the data"); break; }
+        // the host-vector all-reduce the pipeline uses (pinned staging, one wait) and its status element
+        cm.solo = true; cm.stage = c->comm.stage; cm.stage_bytes = c->comm.stage_bytes;
+        std::vector<u64> v(h.begin(), h.begin() + 1000);
+        if (cm.allreduce_with_status(v, RCCL_SUM, false, c->stream, c->pool) != 0 || v.size() != 1000 || !std::equal(v.begin(), v.end(), h.begin())) { out = fail(c, HSK_ERR_COMM, "staged all-reduce with status (sum) failed: %s", cm.last_error.c_str()); break; }
+        if (cm.allreduce_with_status(v, RCCL_MAX, true, c->stream, c->pool) != 1 || v.size() != 1000 || !std::equal(v.begin(), v.end(), h.begin())) { out = fail(c, HSK_ERR_COMM, "staged all-reduce with status (max, failed rank) failed: %s", cm.last_error.c_str()); break; }
+        std::vector<u64> big(h); big.resize(40000, 7);                       // larger than the staging area: unstaged path
+        std::vector<u64> big0(big);
+        if (cm.allreduce_with_status(big, RCCL_SUM, false, c->stream, c->pool) != 0 || big != big0) { out = fail(c, HSK_ERR_COMM, "unstaged all-reduce with status failed"); break; }
+        cm.solo = false;
         // two messages to self inside one group, on the second stream (as post_exchange does per peer and array)
         hipStream_t s = c->comm_stream;
         if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart")) ||

@@ -74,7 +74,8 @@ struct Comm {
     int nranks = 1, rank = 0;
     std::string last_error;
 
-    bool active() const { return comm != nullptr && nranks > 1; }
+    bool solo = false;                                            // selftest: treat a one-rank communicator as active
+    bool active() const { return comm != nullptr && (nranks > 1 || solo); }
 
     static int get_unique_id(void *id128)
     {
@@ -105,19 +106,39 @@ struct Comm {
         return rc;
     }
 
+    // small host-side vectors (task sizes, flags): staged through `stage` (pinned, stage_bytes) when they fit, so that the
+    // round trip is copy -> all-reduce -> copy -> ONE wait
+    void *stage = nullptr; size_t stage_bytes = 0;
     template <typename Pool>
     int allreduce_u64(uint64_t *host, size_t n, int op, hipStream_t s, Pool &pool)
     {
         if (!active()) return 0;
         PoolBuf<Pool> b(pool, n * 8);
         if (!b.p) { last_error = "oom"; return -1; }
-        if (hipMemcpyAsync(b.p, host, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
-        if (hipStreamSynchronize(s) != hipSuccess) return -2;
+        const bool staged = stage != nullptr && n * 8 <= stage_bytes;
+        if (staged) memcpy(stage, host, n * 8);
+        if (hipMemcpyAsync(b.p, staged ? stage : (void *)host, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+        if (!staged && hipStreamSynchronize(s) != hipSuccess) return -2;
         int rc = check(api->AllReduce(b.p, b.p, n, RCCL_UINT64, op, comm, s), "ncclAllReduce");
         if (rc) return rc;
-        if (hipMemcpyAsync(host, b.p, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return -2;
+        if (hipMemcpyAsync(staged ? stage : (void *)host, b.p, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return -2;
         if (hipStreamSynchronize(s) != hipSuccess) return -2;
+        if (staged) memcpy(host, stage, n * 8);
         return 0;
+    }
+    // All-reduce of `v` with one extra element: the local status.  Afterwards EVERY rank knows whether some rank has failed
+    // since the last collective, and all of them leave together (a rank that returned alone would leave its peers blocked
+    // in the next collective for ever).  local_failed: this rank's own status; returns < 0: RCCL error, 1: some rank failed, 0: fine.
+    template <typename Pool>
+    int allreduce_with_status(std::vector<uint64_t> &v, int op, bool local_failed, hipStream_t s, Pool &pool)
+    {
+        if (!active()) return local_failed ? 1 : 0;
+        v.push_back(local_failed ? 1 : 0);
+        const int rc = allreduce_u64(v.data(), v.size(), op, s, pool);
+        const bool any = v.back() != 0;
+        v.pop_back();
+        if (rc) return rc < 0 ? rc : -3;
+        return any ? 1 : 0;
     }
     template <typename Pool> int allreduce_sum_u64(uint64_t *h, size_t n, hipStream_t s, Pool &p) { return allreduce_u64(h, n, RCCL_SUM, s, p); }
     template <typename Pool> int allreduce_max_u64(uint64_t *h, size_t n, hipStream_t s, Pool &p) { return allreduce_u64(h, n, RCCL_MAX, s, p); }
@@ -234,14 +255,14 @@ template <typename Pool>
 inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int /*K*/, uint32_t ntasks, const std::vector<int32_t> &owner,
                               const std::vector<uint32_t> &order, const std::vector<uint64_t> &task_tot, const std::vector<uint64_t> &task_base,
                               const uint8_t *sm_len, const uint8_t *sm_bytes, const uint32_t *sm_pos, const int32_t *sm_rid,
-                              ExchangeBuffers &xb, std::vector<TaskSegs> &segs)
+                              ExchangeBuffers &xb, std::vector<TaskSegs> &segs, bool local_failed = false)
 {
     const int nr = cm.nranks, me = cm.rank;
-    // 1. size matrix: every rank contributes its row, the sum is the full matrix
+    // 1. size matrix: every rank contributes its row, the sum is the full matrix (+ the ranks' status, see allreduce_with_status)
     std::vector<uint64_t> M((size_t)nr * ntasks * 3, 0);
-    for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)me * ntasks * 3 + i] = task_tot[i];
-    int rc = cm.allreduce_sum_u64(M.data(), M.size(), s, pool);
-    if (rc) return rc;
+    if (!local_failed) for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)me * ntasks * 3 + i] = task_tot[i];
+    int rc = cm.allreduce_with_status(M, RCCL_SUM, local_failed, s, pool);
+    if (rc) { if (rc > 0) cm.last_error = "a rank failed before the supermer exchange"; return rc; }
     ExchangePlan pl;
     plan_exchange(nr, me, ntasks, owner, order, M, task_base, pl, segs);
     xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);

@@ -301,16 +301,30 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
     u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
     SortScratch sc;
-    if (max_task) {
-        for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
-            DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
-            DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * NW * 8 + 64);   // xs: the chunk store of the first pass
-            if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
-        }
-        int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
-    }
     u64 *d_ghist_slot[2] = {nullptr, nullptr};
-    if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+    auto alloc_sort_buffers = [&]() -> int {
+        if (max_task) {
+            for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
+                DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
+                DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * NW * 8 + 64);   // xs: the chunk store of the first pass
+                if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
+            }
+            int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
+        }
+        if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
+        return HSK_OK;
+    };
+    {
+        const int arc = alloc_sort_buffers();
+        if (feeder && !feeder->st_all && c->comm.active()) {
+            // the largest allocations of the call are behind us: make sure EVERY rank got them before the first task group
+            // travels (a rank that gave up here alone would leave its peers blocked in their first send / receive)
+            std::vector<u64> none;
+            const int st_ = c->comm.allreduce_with_status(none, RCCL_MAX, arc != 0, c->stream, c->pool);
+            if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(status) failed: %d (%s)", st_, c->comm.last_error.c_str());
+            if (st_ > 0) return arc ? arc : fail(c, HSK_ERR_COMM, "another rank ran out of memory before the supermer exchange");
+        } else if (arc) return arc;
+    }
     u64 n_total = 0, pay_total = 0;
     // payload offsets are global over the owned tasks in ascending id: prefix of k-mer counts
     std::vector<u64> pay_before(ntasks, 0);
@@ -652,33 +666,43 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     std::vector<TaskOut> hlists;                         // this rank's {k-mer, count} lists of the heavy tasks
     std::vector<HeavyIn> hin;                            // heavy tasks this rank owns: the lists of all ranks
     bool any_heavy = false;
+    int place_rc = HSK_OK;
     pt.begin(PH_PARSE);
     {
         // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
         // before the storage order (tasks grouped by owner rank) is known, then parse_place lays the supermers out
         ParseJob job;
         int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, job);
-        if (rc) { parse_release(c, job); return rc; }
+        if (rc && nranks == 1) { parse_release(c, job); return rc; }
         if (nranks > 1) {
-            std::vector<u64> bytes(ntasks);
-            for (u32 t = 0; t < ntasks; ++t) bytes[t] = job.task_tot[3 * t + 1] + job.task_tot[3 * t] * (ext ? 9 : 1);
+            // Several ranks: a rank that fails must not return alone (its peers would wait for it in the next collective for
+            // ever).  Every all-reduce below carries the ranks' status as one more element; a failed rank keeps taking part
+            // (with zeros) until the next one, then all ranks return together.
+            Comm &cm = c->comm;
+            int local_rc = rc;                                   // first local failure since the last collective
+            auto together = [&](int st_, const char *what) -> int {      // result of an all-reduce with status -> return code of this rank
+                if (st_ == 0) return HSK_OK;
+                if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(%s) failed: %d (%s)", what, st_, cm.last_error.c_str());
+                return local_rc ? local_rc : fail(c, HSK_ERR_COMM, "another rank failed before the all-reduce of %s", what);
+            };
+            std::vector<u64> bytes(ntasks, 0);
+            if (!local_rc) for (u32 t = 0; t < ntasks; ++t) bytes[t] = job.task_tot[3 * t + 1] + job.task_tot[3 * t] * (ext ? 9 : 1);
             // heavy-hitter tasks (a8): classified on the global k-mer counts; every rank pre-aggregates its own share
             if (heavy_enabled(c, NW, nranks)) {
-                std::vector<u64> kg(ntasks); std::vector<int32_t> types(ntasks, 0);
-                for (u32 t = 0; t < ntasks; ++t) kg[t] = job.task_tot[3 * t + 2];
-                rc = c->comm.allreduce_sum_u64(kg.data(), ntasks, c->stream, c->pool);
-                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task k-mers) failed: %d", rc); }
+                std::vector<u64> kg(ntasks, 0); std::vector<int32_t> types(ntasks, 0);
+                if (!local_rc) for (u32 t = 0; t < ntasks; ++t) kg[t] = job.task_tot[3 * t + 2];
+                rc = together(cm.allreduce_with_status(kg, RCCL_SUM, local_rc != 0, c->stream, c->pool), "task k-mers");
+                if (rc) { parse_release(c, job); return rc; }
                 plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
                 for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
             }
             if (any_heavy) {
-                std::vector<u8> failed;
-                rc = heavy_preaggregate<NW>(c, job, d_packed, packed_bytes, is_heavy, hlists, failed);
+                std::vector<u8> failed(ntasks, 0);
+                local_rc = heavy_preaggregate<NW>(c, job, d_packed, packed_bytes, is_heavy, hlists, failed);
+                std::vector<u64> bad(ntasks, 0);
+                if (!local_rc) for (u32 t = 0; t < ntasks; ++t) bad[t] = failed[t];
+                rc = together(cm.allreduce_with_status(bad, RCCL_MAX, local_rc != 0, c->stream, c->pool), "heavy flags");     // a task one rank could not aggregate travels as supermers everywhere
                 if (rc) { parse_release(c, job); return rc; }
-                std::vector<u64> bad(ntasks);
-                for (u32 t = 0; t < ntasks; ++t) bad[t] = failed[t];
-                rc = c->comm.allreduce_max_u64(bad.data(), ntasks, c->stream, c->pool);     // a task one rank could not aggregate travels as supermers everywhere
-                if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(heavy flags) failed: %d", rc); }
                 any_heavy = false;
                 for (u32 t = 0; t < ntasks; ++t) {
                     if (!is_heavy[t]) continue;
@@ -687,15 +711,16 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
                     bytes[t] = hlists[t].n * (u64)(NW + 1) * 8;                               // ScatteredKmerList::get_size_bytes
                 }
             }
-            rc = c->comm.allreduce_sum_u64(bytes.data(), ntasks, c->stream, c->pool);
-            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_COMM, "allreduce(task sizes) failed: %d", rc); }
+            rc = together(cm.allreduce_with_status(bytes, RCCL_SUM, local_rc != 0, c->stream, c->pool), "task sizes");
+            if (rc) { parse_release(c, job); return rc; }
             rc = plan_dispatch(bytes.data(), (int)ntasks, nranks, c->cfg.plain_dispatcher != 0, c->cfg.dispatch_upper_coe, c->cfg.dispatch_step, owner.data());
-            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }
+            if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }      // (same input on every rank: all of them fail here)
             std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
         }
         rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr, nranks > 1);
         parse_release(c, job);
-        if (rc) return rc;
+        if (rc && nranks == 1) return rc;
+        place_rc = rc;                                           // several ranks: carried into the size-matrix all-reduce below
     }
     pt.end(PH_PARSE);
     tmark("parse enqueued (task totals read)");
@@ -710,18 +735,22 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     GroupFeeder feeder; bool fed = false;
     pt.begin(PH_EXCH);
     if (nranks > 1) {
-        int rc = pack_store_bytes(c, st, x_src, !overlap_enabled()); if (rc) return rc;
+        int local_rc = place_rc ? place_rc : pack_store_bytes(c, st, x_src, !overlap_enabled());
+        int rc;
         if (overlap_enabled()) {
-            // size matrix: every rank contributes its row, the sum is the full matrix
+            // size matrix: every rank contributes its row, the sum is the full matrix (+ the ranks' status: a rank whose
+            // placement or byte packing failed leaves together with its peers)
             std::vector<u64> M((size_t)nranks * ntasks * 3, 0);
-            for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)rank * ntasks * 3 + i] = st.task_tot[i];
-            rc = c->comm.allreduce_sum_u64(M.data(), M.size(), c->stream, c->pool);
-            if (rc) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", rc, c->comm.last_error.c_str());
+            if (!local_rc) for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)rank * ntasks * 3 + i] = st.task_tot[i];
+            const int st_ = c->comm.allreduce_with_status(M, RCCL_SUM, local_rc != 0, c->stream, c->pool);
+            if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", st_, c->comm.last_error.c_str());
+            if (st_ > 0) return local_rc ? local_rc : fail(c, HSK_ERR_COMM, "another rank failed before the supermer exchange");
             rc = feeder.plan(c, nranks, rank, ntasks, owner, order, M, st.task_base, segs); if (rc) return rc;
             feeder.st = &st; feeder.lazy_pack = true; fed = true;
         } else {
             rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
-                                    st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs);
+                                    st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs, local_rc != 0);
+            if (rc > 0 && local_rc) return local_rc;
             if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange failed: %d (%s)", rc, c->comm.last_error.c_str());
             x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
             x_src = source_from_bytes(xb.bytes, xb.nbytes);
@@ -743,13 +772,20 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         int rc = c->comm.allreduce_sum_u64(Hn.data(), Hn.size(), c->stream, c->pool);
         if (rc) return fail(c, HSK_ERR_COMM, "allreduce(heavy list sizes) failed: %d (%s)", rc, c->comm.last_error.c_str());
         const size_t ew = (size_t)(NW + 1) * 8;
+        bool oom = false;
         for (size_t i = 0; i < nh; ++i) {
             const u32 t = hv_tasks[i];
             if (owner[t] != rank) continue;
             HeavyIn hv; hv.task = t; hv.n = 0; hv.d_entries = nullptr;
             for (int p = 0; p < nranks; ++p) hv.n += Hn[(size_t)p * nh + i];
-            if (hv.n) DALLOC(c, hv.d_entries, u64 *, hv.n * ew);
+            if (hv.n && !oom) { hv.d_entries = (u64 *)c->pool.alloc(hv.n * ew); if (!hv.d_entries) oom = true; }
             hin.push_back(hv);
+        }
+        {   // every owner must have its receive buffers before anybody sends
+            std::vector<u64> none;
+            const int st_ = c->comm.allreduce_with_status(none, RCCL_MAX, oom, c->stream, c->pool);
+            if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(status) failed: %d (%s)", st_, c->comm.last_error.c_str());
+            if (st_ > 0) { for (auto &hv : hin) c->pool.release(hv.d_entries); hin.clear(); return oom ? fail(c, HSK_ERR_OOM, "heavy-hitter receive buffers") : fail(c, HSK_ERR_COMM, "another rank ran out of memory before the heavy-hitter exchange"); }
         }
         Comm &cm = c->comm;
         if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str());
