@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-div", type=int, default=20, help="cpu_baseline sample = workload / this")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (N = 1)")
+    ap.add_argument("--error-rate", type=float, default=0.0, help="substitution errors per base in the synthetic reads (informational runs; the headline workload is error-free)")
     ap.add_argument("--ext", type=int, default=0)
     ap.add_argument("--k", type=int, default=31, help="k-mer size (informational runs; the headline metric is K=31)")
     return ap.parse_args()
@@ -267,7 +268,7 @@ def main():
 
     ctx = H.Context(K=KK, M=M, L=L, U=U, EXT=a.ext, ntasks=a.ntasks, device=local, profile=True, keep_device=True)
     ctx.comm_init(comm)
-    dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed, first_read=rank * nreads)
+    dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed, first_read=rank * nreads, error_rate=a.error_rate)
 
     def barrier():
         torch.cuda.synchronize()
@@ -337,7 +338,7 @@ def main():
             "dtype": ("u64" if KK <= 32 else "u128") + ("" if not a.ext else "+u64 payload"), "data": "synthetic",
             "config": {"workload": "S-reads(G=%d bp x %d GPU, c=%d): %d x %d-bp reads per GPU = %.3g bp, %d k-mers per GPU" % (
                 int(GENOME_PER_GPU * a.scale), world, COVERAGE, nreads, READ_LEN, nreads * READ_LEN, nk_rank),
-                "K": KK, "M": M, "L": L, "U": U, "EXT": a.ext, "ntasks": info["ntasks"], "scale": a.scale,
+                "K": KK, "M": M, "L": L, "U": U, "EXT": a.ext, "ntasks": info["ntasks"], "scale": a.scale, "error_rate": a.error_rate,
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD; with the first pass fused into the expand this is the one remaining pass, over chunk tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

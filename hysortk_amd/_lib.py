@@ -56,7 +56,7 @@ SYMBOLS = [
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
     "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
     "hsk_comm_get_unique_id", "hsk_comm_init", "hsk_comm_destroy", "hsk_comm_selftest",
-    "hsk_synth_reads", "hsk_synth_free", "hsk_memcpy_d2h", "hsk_pack_fasta",
+    "hsk_synth_reads", "hsk_synth_reads_err", "hsk_synth_free", "hsk_memcpy_d2h", "hsk_pack_fasta",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def load():
     L.hsk_comm_selftest.argtypes = [vp]
     L.hsk_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.hsk_synth_reads_err.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hsk_synth_free.argtypes = [vp, vp, vp, vp]
     L.hsk_pack_fasta.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]

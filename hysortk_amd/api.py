@@ -425,10 +425,13 @@ class Context:
         return out[:m, :nw].copy(), out[:m, nw].copy()
 
     # ---- synthetic reads in HBM ------------------------------------------------------------------------
-    def synth_reads(self, genome_len, read_len, nreads, seed, first_read=0):
+    def synth_reads(self, genome_len, read_len, nreads, seed, first_read=0, error_rate=0.0):
         dp, do, dl = C.c_void_p(), C.c_void_p(), C.c_void_p()
         nb = C.c_uint64(0)
-        self._check(self.lib.hsk_synth_reads(self.h, genome_len, read_len, nreads, seed, first_read, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
+        if error_rate:
+            self._check(self.lib.hsk_synth_reads_err(self.h, genome_len, read_len, nreads, seed, first_read, float(error_rate), C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
+        else:
+            self._check(self.lib.hsk_synth_reads(self.h, genome_len, read_len, nreads, seed, first_read, C.byref(dp), C.byref(nb), C.byref(do), C.byref(dl)))
         return dp, int(nb.value), do, dl
 
     def synth_free(self, dp, do, dl):

@@ -31,8 +31,9 @@ constexpr int AG_MAX_PROBE = 48;
 constexpr u64 AG_EMPTY = ~0ULL;                   // never a canonical k-mer word (the all-T k-mer's twin, all-A, is smaller)
 constexpr int AG_LDS_HIST = 256;
 constexpr int AG_BATCH = 8;
-constexpr int AG_LOG2CAP_SMALL = 10;             // hash table slots: first try / retry
-constexpr int AG_LOG2CAP_LARGE = 12;
+constexpr int AG_LOG2CAP_SMALL = 10;             // hash table slots: 1024 (error-free reads at ~30x: ~120 distinct keys per bin) ...
+constexpr int AG_LOG2CAP_MEDIUM = 11;            // ... 2048 (reads with ~1 % errors: ~900) ...
+constexpr int AG_LOG2CAP_LARGE = 12;             // ... 4096 slots; a task with a bin beyond that takes the long way
 
 enum { AG_FLAG_OVERFLOW = 1 };
 
@@ -41,9 +42,30 @@ struct AggTask {
     u64 *bounds;                   // [nbins + 1] first record of every prefix bin (bin_bounds_kernel)
     u64 *scratch; u32 slot_shift;  // bin b writes entry e {key, count} to scratch[((bounds[b] >> slot_shift) + e) * 2 ..]
     u32 active;
-    u64 *bin_cnt;                  // [nbins (+1 for the scan total)] kept entries of each bin
-    u32 *flags;                    // out: AG_FLAG_*
+    u64 *bin_cnt;                  // [nbins] kept entries of each bin (written by whichever rung of the ladder took the bin)
+    u64 *bin_off;                  // [nbins + 1] agg_scan_kernel: exclusive scan of bin_cnt, total behind the last bin (may alias bin_cnt)
+    u32 *flags;                    // out: AG_FLAG_*; flags[AG_BATCH] (one word further per task): the most distinct keys any bin of the task held
+    // The table ladder works BIN BY BIN: a bin with more distinct keys than this launch's table holds is appended to ovf_list
+    // (a task's bins are heavy-tailed -- a bin is fed by few minimizers --, so nearly every task has a few outlier bins); the
+    // next launch, one table size up, takes only the listed bins (bin_list / bin_list_n).  ovf_list == null: last rung, an
+    // overflowing bin raises the task's AG_FLAG_OVERFLOW instead and the host sends the whole task the long way.
+    const u32 *bin_list; const u32 *bin_list_n;
+    u32 *ovf_list; u32 *ovf_n;
 };
+// the bin this workgroup works on (false: none) and what to do when it overflows
+__device__ __forceinline__ bool agg_pick_bin(const AggTask &t, u32 nbins, u32 &b)
+{
+    b = blockIdx.x;
+    if (t.bin_list) { if (b >= *t.bin_list_n || b >= nbins) return false; b = t.bin_list[b]; }
+    return b < nbins;                                   // (a list entry is a bin id: anything else would be a bug upstream, never an address)
+}
+__device__ __forceinline__ void agg_bin_overflow(const AggTask &t, u32 nbins, u32 b, u32 cap)
+{
+    if (t.ovf_list) { const u32 at = atomicAdd(t.ovf_n, 1u); if (at < nbins) t.ovf_list[at] = b; else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); }   // (a bin is listed once per rung: at < nbins)
+    else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW);
+    atomicMax(t.flags + AG_BATCH, cap);
+    t.bin_cnt[b] = 0;
+}
 struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
 
 // bounds[b] = index of the first key whose top bits are >= b (b = 0 .. AG_BINS); one thread per bound
@@ -84,13 +106,17 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 #endif
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
+    constexpr int NBKT = CAP / 2;   // buckets of the in-LDS counting sort that orders many distinct keys (one per slot of the idle half)
+    constexpr u32 MAX_LOAD = CAP - CAP / 8;          // distinct keys accepted: beyond 7/8 the probe sequences get long, the bin reports overflow at once
     __shared__ u64 s_key[CAP];      // hash table, then the distinct keys compacted, then sorted
     __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_bkt[NBKT];
     __shared__ u32 s_scr[8];
-    __shared__ u32 s_ovf;
+    __shared__ u32 s_ovf, s_ndist;
     const AggTask &t = a.t[blockIdx.y];
     if (!t.active) return;
-    const u32 b = blockIdx.x;
+    u32 b;
+    if (!agg_pick_bin(t, a.nbins, b)) return;
     const int tid = threadIdx.x;
     const u64 s = t.bounds[b], e = t.bounds[b + 1];
     if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
@@ -98,7 +124,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 
 #pragma unroll
     for (int j = 0; j < PER; ++j) { s_key[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
-    if (tid == 0) s_ovf = 0;
+    if (tid == 0) { s_ovf = 0; s_ndist = 0; }
     __syncthreads();
     AG_STAMP(1);                                        // table cleared
 
@@ -109,6 +135,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         u64 k[AG_UNROLL];
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+        u32 fresh = 0;
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
             if (k[u] == AG_EMPTY) continue;
@@ -116,17 +143,21 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
             bool done = false;
             for (int p = 0; p < AG_MAX_PROBE; ++p) {
                 u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
+                if (cur == AG_EMPTY) { cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]); fresh += cur == AG_EMPTY; }
                 if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_cnt[h], 1u); done = true; break; }
                 h = (h + 1) & (CAP - 1);
             }
             if (!done) s_ovf = 1;
         }
+        // a bin with more distinct keys than the table should hold gives up here (reads with sequencing errors: nearly every
+        // bin of the first-choice table) instead of grinding through ever longer probe sequences
+        if (fresh && atomicAdd(&s_ndist, fresh) + fresh > MAX_LOAD) s_ovf = 1;
+        if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
     __syncthreads();
     AG_STAMP(2);                                        // records loaded and counted
     if (s_ovf) {
-        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        if (tid == 0) agg_bin_overflow(t, a.nbins, b, (u32)CAP);
         return;
     }
 
@@ -142,6 +173,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
     __syncthreads();
     AG_STAMP(3);                                        // distinct keys compacted
+    if (tid == 0 && D > 256u) atomicMax(t.flags + AG_BATCH, D);      // (feedback for the host's choice of the first table; small bins are the common case and stay silent)
     if (D <= (u32)AG_THREADS) {
         // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
         u64 k = 0; u32 c = 0, r = 0;
@@ -153,22 +185,51 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; }
         __syncthreads();
     } else {
-        u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; }
+        // Hundreds to thousands of distinct keys (low coverage, reads with errors): counting sort on the key bits right below
+        // the bin prefix -- the keys of a bin are close to uniform there, about one per bucket --, then every key ranks itself
+        // inside its bucket: ~10 LDS operations per key instead of the ~log^2 of a sorting network; a bucket that collects
+        // many keys (a shared prefix) costs only its own square.  In place: every lane keeps its keys in registers across
+        // the barriers between "all read" and "all write".
+        constexpr int EPT = CAP / AG_THREADS;
+        constexpr int LOG2BKT = LOG2CAP - 1;
+        const int bshift = a.shift - LOG2BKT;              // (the prefix bits are equal inside a bin: masked off below)
+        for (int i = tid; i < NBKT; i += AG_THREADS) s_bkt[i] = 0;
         __syncthreads();
-        for (u32 kk = 2; kk <= P; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < P; i += AG_THREADS) {
-                    const u32 q = i ^ j;
-                    if (q > i) {
-                        const u64 x = s_key[i], y = s_key[q];
-                        const bool up = (i & kk) == 0;
-                        if ((x > y) == up) { const u32 cx = s_cnt[i], cy = s_cnt[q]; s_key[i] = y; s_key[q] = x; s_cnt[i] = cy; s_cnt[q] = cx; }
-                    }
-                }
-                __syncthreads();
-            }
+        u64 ek[EPT]; u32 ec[EPT], er[EPT];
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            const u32 i = x * AG_THREADS + tid;
+            ek[x] = AG_EMPTY; ec[x] = 0; er[x] = 0;
+            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)], 1u); }
         }
+        __syncthreads();
+        {
+            constexpr int BPT = NBKT / AG_THREADS;
+            u32 v[BPT], sum = 0;
+#pragma unroll
+            for (int x = 0; x < BPT; ++x) { v[x] = s_bkt[tid * BPT + x]; sum += v[x]; }
+            u32 ex = block_excl_scan_256<u32>(sum, s_scr, nullptr);
+#pragma unroll
+            for (int x = 0; x < BPT; ++x) { s_bkt[tid * BPT + x] = ex; ex += v[x]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x)
+            if (ek[x] != AG_EMPTY) s_key[s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)] + er[x]] = ek[x];        // bucket-major (counts follow below)
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            if (ek[x] == AG_EMPTY) continue;
+            const u32 bk = (u32)(ek[x] >> bshift) & (NBKT - 1);
+            const u32 b0 = s_bkt[bk], b1 = (bk + 1 < (u32)NBKT) ? s_bkt[bk + 1] : D;
+            u32 r = b0;
+            for (u32 q = b0; q < b1; ++q) r += s_key[q] < ek[x];
+            er[x] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) if (ek[x] != AG_EMPTY) { s_key[er[x]] = ek[x]; s_cnt[er[x]] = ec[x]; }
+        __syncthreads();
     }
     const u64 *sk = s_key; const u32 *sc = s_cnt;
     AG_STAMP(4);                                        // distinct keys ordered
@@ -221,7 +282,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
     if (!t.active) return;
-    const u32 b = blockIdx.x;
+    u32 b;
+    if (!agg_pick_bin(t, a.nbins, b)) return;
     const int tid = threadIdx.x;
     const u64 s = t.bounds[b], e = t.bounds[b + 1];
     if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
@@ -269,7 +331,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     }
     __syncthreads();
     if (s_ovf) {
-        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        if (tid == 0) agg_bin_overflow(t, a.nbins, b, (u32)CAP);
         return;
     }
 
@@ -571,7 +633,6 @@ constexpr int AGB_LOG2CAP = 13;
 constexpr int AGB_CAP = 1 << AGB_LOG2CAP;
 constexpr int AGB_MAX_LOAD = AGB_CAP * 3 / 4;      // distinct keys accepted (beyond that probes get long: overflow)
 constexpr int AGB_NBKT = 4096;                     // buckets of the in-LDS counting sort: the 12 key bits below the 8-bit bin prefix
-constexpr int AGB_BKT_SHIFT = 64 - 8 - 12;
 
 template <typename T>
 __device__ __forceinline__ T block_excl_scan_1024(T v, T *scratch /* >= 16 */, T *total)
@@ -599,8 +660,10 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
     if (!t.active) return;
-    const u32 b = blockIdx.x;
+    u32 b;
+    if (!agg_pick_bin(t, a.nbins, b)) return;
     const int tid = threadIdx.x;
+    const int bkt_shift = a.shift - 12;                 // the 12 key bits right below the bin prefix
     const u64 s = t.bounds[b], e = t.bounds[b + 1];
     if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
 #pragma unroll
@@ -651,7 +714,7 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
     }
     __syncthreads();
     if (s_ovf || D > (u32)AGB_MAX_LOAD) {
-        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        if (tid == 0) agg_bin_overflow(t, a.nbins, b, (u32)AGB_CAP);
         return;
     }
 
@@ -669,7 +732,7 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
         for (int x = 0; x < EPT; ++x) {
             const u32 i = x * AGB_THREADS + tid;
             ek[x] = AG_EMPTY; ec[x] = 0; er[x] = 0;
-            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_hist[(u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1)], 1u); }
+            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_hist[(u32)(ek[x] >> bkt_shift) & (AGB_NBKT - 1)], 1u); }
         }
         __syncthreads();
         {
@@ -684,12 +747,12 @@ __global__ __launch_bounds__(AGB_THREADS) void agg_big_kernel(AggArgs a)
         u64 *ok = s_key + CAP / 2; u32 *oc = s_cnt + CAP / 2;
 #pragma unroll
         for (int x = 0; x < EPT; ++x)
-            if (ek[x] != AG_EMPTY) { const u32 p = s_hist[(u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1)] + er[x]; ok[p] = ek[x]; oc[p] = ec[x]; }
+            if (ek[x] != AG_EMPTY) { const u32 p = s_hist[(u32)(ek[x] >> bkt_shift) & (AGB_NBKT - 1)] + er[x]; ok[p] = ek[x]; oc[p] = ec[x]; }
         __syncthreads();
 #pragma unroll
         for (int x = 0; x < EPT; ++x) {
             if (ek[x] == AG_EMPTY) continue;
-            const u32 bk = (u32)(ek[x] >> AGB_BKT_SHIFT) & (AGB_NBKT - 1);
+            const u32 bk = (u32)(ek[x] >> bkt_shift) & (AGB_NBKT - 1);
             const u32 b0 = s_hist[bk], b1 = (bk + 1 < (u32)AGB_NBKT) ? s_hist[bk + 1] : D;
             u32 r = b0;
             for (u32 q = b0; q < b1; ++q) r += ok[q] < ek[x];
@@ -754,12 +817,12 @@ __global__ __launch_bounds__(AG_THREADS) void agg_scan_kernel(AggArgs a)
         u64 tot;
         u64 ex = block_excl_scan_256<u64>(sum, s_scr, &tot) + s_carry;
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) { if (t0 + i < a.nbins) t.bin_cnt[t0 + i] = ex; ex += v[i]; }
+        for (int i = 0; i < IPT; ++i) { if (t0 + i < a.nbins) t.bin_off[t0 + i] = ex; ex += v[i]; }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) t.bin_cnt[a.nbins] = s_carry;
+    if (threadIdx.x == 0) t.bin_off[a.nbins] = s_carry;
 }
 
 // Moves the kept entries from the per-bin slots to their final place (bin_off = exclusive scan of bin_cnt,

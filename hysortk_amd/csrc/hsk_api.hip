@@ -683,8 +683,21 @@ extern "C" int hsk_comm_destroy(hsk_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // synthetic reads in HBM
 // ------------------------------------------------------------------------------------------------
+static int synth_reads_impl(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read, double error_rate,
+                            void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len);
 extern "C" int hsk_synth_reads(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read,
                                void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
+{
+    return synth_reads_impl(c, genome_len, read_len, nreads, seed, first_read, 0.0, d_packed, packed_bytes, d_off, d_len);
+}
+extern "C" int hsk_synth_reads_err(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read, double error_rate,
+                                   void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
+{
+    if (!(error_rate >= 0.0 && error_rate <= 0.5)) return HSK_ERR_INVALID_ARG;
+    return synth_reads_impl(c, genome_len, read_len, nreads, seed, first_read, error_rate, d_packed, packed_bytes, d_off, d_len);
+}
+static int synth_reads_impl(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read, double error_rate,
+                            void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
 {
     if (!c || !d_packed || !packed_bytes || !d_off || !d_len || read_len == 0 || genome_len < read_len) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -698,7 +711,8 @@ extern "C" int hsk_synth_reads(hsk_ctx *c, uint64_t genome_len, uint32_t read_le
     DALLOC(c, rlen, u32 *, (nreads + 1) * 4);
     hipLaunchKernelGGL(synth_genome_kernel, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, c->stream, gw, nwords, seed);
     const u64 seed2 = splitmix64(seed ^ 0xabcdef12345ULL);
-    if (bytes) hipLaunchKernelGGL(synth_reads_kernel, dim3((u32)((bytes + 255) / 256)), dim3(256), 0, c->stream, gw, genome_len, read_len, nreads, seed2 + first_read, pk);
+    const u32 err_thresh = (u32)std::min<double>(error_rate * 4294967296.0, 4294967295.0);
+    if (bytes) hipLaunchKernelGGL(synth_reads_kernel, dim3((u32)((bytes + 255) / 256)), dim3(256), 0, c->stream, gw, genome_len, read_len, nreads, seed2 + first_read, pk, err_thresh);
     hipLaunchKernelGGL(synth_index_kernel, dim3((u32)((nreads + 256) / 256)), dim3(256), 0, c->stream, roff, rlen, nreads, read_len);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -105,6 +105,8 @@ struct hsk_ctx {
     Comm comm;
     const u8 *zc_src = nullptr;        // hsk_count() with pinned input: device view of the caller's packed reads (scan_kernel reads them in place)
     bool index_unchecked = false;      // hsk_count(): the read index is validated on the device (index_check_kernel), the verdict is read with the task totals
+    int agg_first_cap = 10;            // log2 of the hash table the next aggregation starts with (AG_LOG2CAP_*): follows the fullest bin of the
+                                       // previous batch, so that reads with errors / low coverage do not pay for a table they overflow anyway
     bool xcd_batch_ok = true;          // hsk_init's census saw workgroups on all eight XCC ids (see xcc_census_kernel)
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };

@@ -209,38 +209,49 @@ static bool agg_enabled()
 // prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way;
 // prefix_bits = 8: bins of the top 8 bits (one scatter pass), agg_big_kernel; a task it cannot take is reported in
 // outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
-struct AggHostRead { u32 flags[AG_BATCH]; u32 pad[AG_BATCH]; u64 total[AG_BATCH]; };
+struct AggHostRead { u32 flags[AG_BATCH]; u32 maxd[AG_BATCH]; u32 ovf[2][AG_BATCH]; u64 total[AG_BATCH]; };   // mirrors the device control block (+ totals)
 struct AggPending {
     bool active = false;
     BatchTask bt[AG_BATCH];
     AggArgs a;
-    u64 *d_bounds = nullptr, *d_cnt = nullptr; u32 *d_flags = nullptr;
+    u64 *d_bounds = nullptr, *d_cnt = nullptr, *d_off = nullptr; u32 *d_flags = nullptr;     // d_flags: {flags[8], maxd[8], overflow-list lengths [2][8]}
+    u32 *d_list[2] = {nullptr, nullptr};                                    // [AG_BATCH][nbins] overflowing bins, ping-pong between the rungs
     bool own_scratch[AG_BATCH] = {false};
-    bool big = false, large_first = false;
+    bool big = false; int first_cap = AG_LOG2CAP_SMALL;
     u32 nbins = 0, slot_shift = 0; int K = 0; u64 ntot = 0;
     hipEvent_t ev = nullptr;
     AggHostRead *h = nullptr;                           // pinned
 };
+constexpr int AG_LOG2CAP_HUGE = 13;                     // last rung for one-word keys: agg_big_kernel (8192 slots, 1024 threads) on the listed bins
 
+// One rung of the ladder: the aggregation kernel with a 2^log2cap table over all bins (grid_x = nbins) or over the listed
+// bins (grid_x = the longest list).
 template <int NW>
-static int agg_launch_run(hsk_ctx *c, AggPending &p, int log2cap)
+static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u64 records)
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
-    const AggArgs &a = p.a; const u32 nbins = p.nbins;
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = p.ntot; ep.bytes = p.ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+    const AggArgs &a = p.a;
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = records; ep.bytes = records * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
     if (NW == 2) {
-        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else
-    if (p.big) hipLaunchKernelGGL(agg_big_kernel, dim3(nbins, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
-    else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    if (p.big || log2cap == AG_LOG2CAP_HUGE) hipLaunchKernelGGL(agg_big_kernel, dim3(grid_x, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
+    else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-    hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(p.h->flags, p.d_flags, sizeof p.h->flags, hipMemcpyDeviceToHost, c->stream));
+    return HSK_OK;
+}
+// bin-count scan + read-back of the control block and the totals (asynchronous: the caller waits)
+static int agg_launch_scan(hsk_ctx *c, AggPending &p)
+{
+    hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, p.a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(p.h->flags, p.d_flags, 4 * sizeof(u32) * AG_BATCH, hipMemcpyDeviceToHost, c->stream));
     // the eight totals sit behind the last bin of every task's count row: one strided copy
-    HIPCHK(c, hipMemcpy2DAsync(p.h->total, 8, p.d_cnt + nbins, ((size_t)nbins + 8) * 8, 8, AG_BATCH, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(p.h->total, 8, p.d_off + p.nbins, ((size_t)p.nbins + 8) * 8, 8, AG_BATCH, hipMemcpyDeviceToHost, c->stream));
     return HSK_OK;
 }
 
@@ -261,8 +272,10 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     const size_t per = (size_t)nbins + 8;
     DALLOC(c, p.d_bounds, u64 *, per * 8 * AG_BATCH);
     DALLOC(c, p.d_cnt, u64 *, per * 8 * AG_BATCH);
+    DALLOC(c, p.d_off, u64 *, per * 8 * AG_BATCH);          // (the counts stay as they are: later rungs of the ladder fill in their bins and the scan runs again)
     DALLOC(c, p.d_flags, u32 *, 256);
-    HIPCHK(c, hipMemsetAsync(p.d_flags, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(p.d_flags, 0, 256, c->stream));
+    if (!p.big) for (int x = 0; x < 2; ++x) DALLOC(c, p.d_list[x], u32 *, (size_t)nbins * 4 * AG_BATCH);
     AggArgs &a = p.a; memset(&a, 0, sizeof a);
     a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
     u64 nmax = 0;
@@ -271,8 +284,9 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
         p.bt[i] = bt[i];
         if (bt[i].n == 0) continue;
         u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
-        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = p.d_bounds + per * i; t.bin_cnt = p.d_cnt + per * i; t.flags = p.d_flags + i;
+        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = p.d_bounds + per * i; t.bin_cnt = p.d_cnt + per * i; t.bin_off = p.d_off + per * i; t.flags = p.d_flags + i;
         t.slot_shift = p.slot_shift; t.active = 1; p.ntot += bt[i].n; nmax = std::max(nmax, bt[i].n);
+        if (!p.big) { t.ovf_list = p.d_list[0] + (size_t)nbins * i; t.ovf_n = p.d_flags + 2 * AG_BATCH + i; }      // first rung: all bins, overflowing ones listed
         if (p.slot_shift) t.scratch = other;             // the idle ping-pong buffer: n / 2 entries
         else {
             t.scratch = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); p.own_scratch[i] = true;
@@ -280,9 +294,13 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
         }
     }
     hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    // bins of 6144 records and more on average (tasks far above 2^28 k-mers) rarely fit the small table: start with the large one
-    p.large_first = !p.big && nmax / nbins >= 6144;
-    int rc = agg_launch_run<NW>(c, p, p.large_first ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL); if (rc) return rc;
+    // First table: what the bins of the previous batches needed (hsk_ctx::agg_first_cap: error-free reads at ~30x stay on 1024
+    // slots, reads with ~1 % errors move to 2048 after their first batch); bins of 6144 records and more on average (tasks far
+    // above 2^28 k-mers) start on the large table.  Two-word keys: small / large only.
+    p.first_cap = p.big ? AG_LOG2CAP_SMALL : std::max(c->agg_first_cap, nmax / nbins >= 6144 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL);
+    if (NW == 2 && p.first_cap == AG_LOG2CAP_MEDIUM) p.first_cap = AG_LOG2CAP_LARGE;
+    int rc = agg_launch_rung<NW>(c, p, p.first_cap, nbins, p.ntot); if (rc) return rc;
+    rc = agg_launch_scan(c, p); if (rc) return rc;
     p.ev = ev_get(c);
     HIPCHK(c, hipEventRecord(p.ev, c->stream));
     p.active = true;
@@ -301,21 +319,53 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     HIPCHK(c, hipEventSynchronize(p.ev));
     ev_put(c, p.ev); p.ev = nullptr;
     AggHostRead &h = *p.h;
-    bool retry = false, done[AG_BATCH];
-    u64 total[AG_BATCH];
-    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
-    int rc = HSK_OK;
-    if (retry && !big && !p.large_first) {
-        // second chance with the large table for the tasks that overflowed (rare: the wait below is a plain one)
-        AggArgs keep = a;
-        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
-        HIPCHK(c, hipMemsetAsync(p.d_flags, 0, 64, c->stream));
-        memset(&h, 0, sizeof h);
-        rc = agg_launch_run<NW>(c, p, AG_LOG2CAP_LARGE); if (rc) return rc;
-        HIPCHK(c, hsk_sync(c, c->stream));
-        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
-        a = keep;
+    bool done[AG_BATCH];
+    int rc = HSK_OK, nact = 0;
+    u64 ovf_bins = 0;
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; if (bt[i].n) { ++nact; ovf_bins += h.ovf[0][i]; } }
+    if (!big && NW == 1 && !c->forbid_long_way && nact) {
+        // next batch (and next call): one table size up when more than one bin in twenty did not fit this one (each of them is
+        // read twice), one size down again when nothing overflowed and no bin came anywhere near this size's limit
+        u32 maxd = 0; for (int i = 0; i < AG_BATCH; ++i) if (bt[i].n) maxd = std::max(maxd, h.maxd[i]);
+        if (ovf_bins * 20 > (u64)nact * nbins) c->agg_first_cap = std::min(p.first_cap + 1, (int)AG_LOG2CAP_LARGE);
+        else if (ovf_bins == 0 && p.first_cap > AG_LOG2CAP_SMALL && maxd < (1u << (p.first_cap - 1)) * 3 / 4) c->agg_first_cap = p.first_cap - 1;
     }
+    // ---- the ladder, bin by bin: the listed bins again one table size up, until no bin is left or the rungs are ----------------
+    if (!big && ovf_bins) {
+        AggArgs keep = a;
+        int cap = p.first_cap, cur = 0;
+        u32 n_cur[AG_BATCH]; for (int i = 0; i < AG_BATCH; ++i) n_cur[i] = bt[i].n ? h.ovf[0][i] : 0;
+        for (;;) {
+            u32 longest = 0; u64 nb = 0; for (int i = 0; i < AG_BATCH; ++i) { longest = std::max(longest, n_cur[i]); nb += n_cur[i]; }
+            if (!longest) break;
+            static const int max_rung = getenv("HSK_AGG_MAXRUNG") ? atoi(getenv("HSK_AGG_MAXRUNG")) : AG_LOG2CAP_HUGE;     // (tests: stop the ladder early, the listed bins' tasks take the long way)
+            int next = (NW == 2) ? (cap < AG_LOG2CAP_LARGE ? AG_LOG2CAP_LARGE : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
+            if (next > max_rung) next = 0;
+            if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
+            cap = next;
+            const bool last = (NW == 2) || cap == AG_LOG2CAP_HUGE;
+            HIPCHK(c, hipMemsetAsync(p.d_flags + (2 + (cur ^ 1)) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));
+            for (int i = 0; i < AG_BATCH; ++i) {
+                AggTask &t = a.t[i];
+                t.active = (keep.t[i].active && n_cur[i]) ? 1 : 0;
+                if (t.active) c->stats.agg_retried_tasks++;
+                t.bin_list = p.d_list[cur] + (size_t)nbins * i; t.bin_list_n = p.d_flags + (2 + cur) * AG_BATCH + i;
+                t.ovf_list = last ? nullptr : p.d_list[cur ^ 1] + (size_t)nbins * i; t.ovf_n = p.d_flags + (2 + (cur ^ 1)) * AG_BATCH + i;
+            }
+            rc = agg_launch_rung<NW>(c, p, cap, longest, nb * (p.ntot / ((u64)nact * nbins) + 1)); if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(p.h->flags, p.d_flags, 4 * sizeof(u32) * AG_BATCH, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hsk_sync(c, c->stream));
+            if (last) { for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active && h.flags[i]) done[i] = false; break; }
+            cur ^= 1;
+            for (int i = 0; i < AG_BATCH; ++i) n_cur[i] = a.t[i].active ? h.ovf[cur][i] : 0;
+        }
+        a = keep;
+        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].bin_list = nullptr; a.t[i].bin_list_n = nullptr; }
+        rc = agg_launch_scan(c, p); if (rc) return rc;        // the bin counts are complete now: offsets and totals again
+        HIPCHK(c, hsk_sync(c, c->stream));
+    }
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) total[i] = h.total[i];
     AggCompactArgs ca; memset(&ca, 0, sizeof ca);
     ca.slot_shift = p.slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
     bool any = false;
@@ -326,7 +376,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         if (outs[i].n) {
             outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * EW * 8);
             if (!outs[i].entries) { rc = fail(c, HSK_ERR_OOM, "task output of %llu bytes", (unsigned long long)(outs[i].n * EW * 8)); break; }
-            ca.scratch[i] = a.t[i].scratch; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt; ca.entries[i] = outs[i].entries;
+            ca.scratch[i] = a.t[i].scratch; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_off; ca.entries[i] = outs[i].entries;
             any = true;
         }
     }
@@ -347,7 +397,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     // no wait here: the scratch (the batch's idle ping-pong buffers, or pool blocks) is next touched by work that is
     // enqueued on this stream after the compaction
     for (int i = 0; i < AG_BATCH; ++i) if (p.own_scratch[i]) c->pool.release(a.t[i].scratch);
-    c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_flags);
+    c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_off); c->pool.release(p.d_flags); c->pool.release(p.d_list[0]); c->pool.release(p.d_list[1]);
     p.active = false;
     return rc;
 }
@@ -398,7 +448,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         outs[i].npay = bt[i].n;
         DALLOC(c, outs[i].pos, u32 *, bt[i].n * 4); DALLOC(c, outs[i].rid, int32_t *, bt[i].n * 4);
         t.pos = outs[i].pos; t.rid = outs[i].rid;
-        sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].active = 1;
+        sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].bin_off = t.bin_cnt; sa.t[i].active = 1;       // (in place: this path scans once)
     }
     struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto run = [&](int log2cap) -> int {

@@ -17,7 +17,9 @@ __global__ void synth_genome_kernel(u64 *gw, u64 nwords, u64 seed)
 __device__ __forceinline__ u32 genome_base(const u64 *gw, u64 i) { return (u32)(gw[i >> 5] >> (2 * (i & 31))) & 3u; }
 
 // one thread per output byte; read r occupies bytes [r*nb, (r+1)*nb)
-__global__ void synth_reads_kernel(const u64 *gw, u64 genome_len, u32 read_len, u64 nreads, u64 seed2, u8 *packed)
+// err_thresh: substitution errors, one per base with probability err_thresh / 2^32 (a base is replaced by one of the other
+// three: sequencing errors make most erroneous k-mers singletons, which is what stresses the aggregation's hash tables)
+__global__ void synth_reads_kernel(const u64 *gw, u64 genome_len, u32 read_len, u64 nreads, u64 seed2, u8 *packed, u32 err_thresh = 0)
 {
     const u32 nb = (read_len + 3) >> 2;
     const u64 byte = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,7 +33,11 @@ __global__ void synth_reads_kernel(const u64 *gw, u64 genome_len, u32 read_len, 
     for (u32 b = 0; b < 4; ++b) {
         const u32 j = jb * 4 + b;
         if (j >= read_len) break;
-        const u32 base = rc ? (3u - genome_base(gw, start + read_len - 1 - j)) : genome_base(gw, start + j);
+        u32 base = rc ? (3u - genome_base(gw, start + read_len - 1 - j)) : genome_base(gw, start + j);
+        if (err_thresh) {
+            const u64 e = splitmix64((h ^ 0x5bd1e995ULL) + (u64)j * 0x9e3779b97f4a7c15ULL);
+            if ((u32)e < err_thresh) base = (base + 1u + (u32)((e >> 32) % 3u)) & 3u;
+        }
         out |= base << (6 - 2 * b);
     }
     packed[byte] = (u8)out;

@@ -336,6 +336,27 @@ def test_count_synth_vs_oracle(H, O, variant, EXT):
         assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
 
 
+def test_count_reads_with_errors_vs_oracle(H, O):
+    """1 % substitution errors (hsk_synth_reads_err): most erroneous k-mers are singletons, prefix bins hold several times
+    more distinct keys than with error-free reads, so the aggregation's small table overflows in places and the retry with
+    the large table (or the long way) takes over; the list must still be the oracle's."""
+    G, RL, NR = 400000, 150, 80000                              # 30x
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=8) as c:
+        dp, nb, do, dl = c.synth_reads(G, RL, NR, 13, error_rate=0.01)
+        packed = c.d2h(dp, nb)
+        res = c.count_device(dp, nb, do, dl, NR)
+        c.synth_free(dp, do, dl)
+        st = c.stats()
+    from hysortk_amd import synth
+    clean, off, lens = synth.packed_reads(G, RL, NR, 13)
+    diff = np.unpackbits(packed ^ clean).reshape(-1, 2).any(axis=1).mean()
+    assert 0.007 < diff < 0.013                                  # about one base in a hundred differs from the error-free twin
+    ores = O.count(packed, off, lens, k=31, m=17, L=1, U=65535, ntasks=8, fast=True)
+    assert st["fused_tasks"] + st["redone_tasks"] == 8
+    assert np.array_equal(res.task_off, ores.task_off) and np.array_equal(res.kmers, ores.keys) and np.array_equal(res.cnt, ores.cnt)
+    assert int(res.histo[1]) > 5 * int(res.histo[2])             # the error tail: singletons dominate
+
+
 # ---------------------------------------------------------------------------------------------------
 # size-independent properties at a size the oracle does not run in seconds
 # ---------------------------------------------------------------------------------------------------
