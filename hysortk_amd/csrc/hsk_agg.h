@@ -27,7 +27,7 @@ constexpr int AG_THREADS = 256;
 constexpr int AG_PREFIX_BITS = 16;
 constexpr int AG_SHIFT = 64 - AG_PREFIX_BITS;
 constexpr u32 AG_BINS = 1u << AG_PREFIX_BITS;
-constexpr int AG_MAX_PROBE = 48;
+constexpr int AG_MAX_PROBE = 32;
 constexpr u64 AG_EMPTY = ~0ULL;                   // never a canonical k-mer word (the all-T k-mer's twin, all-A, is smaller)
 constexpr int AG_LDS_HIST = 256;
 constexpr int AG_BATCH = 8;
@@ -107,12 +107,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
     constexpr int NBKT = CAP / 2;   // buckets of the in-LDS counting sort that orders many distinct keys (one per slot of the idle half)
-    constexpr u32 MAX_LOAD = CAP - CAP / 8;          // distinct keys accepted: beyond 7/8 the probe sequences get long, the bin reports overflow at once
     __shared__ u64 s_key[CAP];      // hash table, then the distinct keys compacted, then sorted
     __shared__ u32 s_cnt[CAP];
     __shared__ u32 s_bkt[NBKT];
     __shared__ u32 s_scr[8];
-    __shared__ u32 s_ovf, s_ndist;
+    __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
     if (!t.active) return;
     u32 b;
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 
 #pragma unroll
     for (int j = 0; j < PER; ++j) { s_key[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
-    if (tid == 0) { s_ovf = 0; s_ndist = 0; }
+    if (tid == 0) s_ovf = 0;
     __syncthreads();
     AG_STAMP(1);                                        // table cleared
 
@@ -135,7 +134,6 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         u64 k[AG_UNROLL];
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
-        u32 fresh = 0;
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
             if (k[u] == AG_EMPTY) continue;
@@ -143,15 +141,14 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
             bool done = false;
             for (int p = 0; p < AG_MAX_PROBE; ++p) {
                 u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == AG_EMPTY) { cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]); fresh += cur == AG_EMPTY; }
+                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
                 if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_cnt[h], 1u); done = true; break; }
                 h = (h + 1) & (CAP - 1);
             }
             if (!done) s_ovf = 1;
         }
-        // a bin with more distinct keys than the table should hold gives up here (reads with sequencing errors: nearly every
-        // bin of the first-choice table) instead of grinding through ever longer probe sequences
-        if (fresh && atomicAdd(&s_ndist, fresh) + fresh > MAX_LOAD) s_ovf = 1;
+        // a bin with more distinct keys than the table takes (a probe sequence ran past AG_MAX_PROBE slots: with linear probing
+        // that starts at a load of ~0.8) gives up here instead of grinding through the rest of its records
         if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
     __syncthreads();
