@@ -3,20 +3,25 @@
 // src/dnabuffer.cpp:7-31): every read starts on a byte boundary, reads are stored back to back,
 // the (bufsize, numreads, buf, readlens) constructor ADOPTS `buf` (released with delete[]), the
 // copy constructor deep-copies.
+//
+// Buffers of 16 MB and more that the class allocates itself live in pinned host memory (hsk_host_alloc, include/hsk.h): the
+// GPU then reads the packed reads in place while it hashes them (hsk_count's zero-copy ingest) instead of waiting for a
+// staged copy.  Smaller buffers, adopted buffers and machines without a GPU use plain new[] as the reference does.
 #pragma once
 #include <cassert>
 #include <cstring>
 #include <numeric>
 #include <vector>
+#include "../hsk.h"
 #include "dnaseq.hpp"
 
 namespace hysortk {
 
 class DnaBuffer {
 public:
-    explicit DnaBuffer(size_t bufsize) : head_(0), cap_(bufsize), buf_(new uint8_t[bufsize ? bufsize : 1]) {}
+    explicit DnaBuffer(size_t bufsize) : head_(0), cap_(bufsize), buf_(allocate(bufsize, pinned_)) {}
 
-    DnaBuffer(size_t bufsize, size_t numreads, uint8_t *buf, const size_t *readlens) : head_(0), cap_(bufsize), buf_(buf)
+    DnaBuffer(size_t bufsize, size_t numreads, uint8_t *buf, const size_t *readlens) : head_(0), cap_(bufsize), pinned_(false), buf_(buf)
     {
         seqs_.reserve(numreads);
         for (size_t i = 0; i < numreads; ++i) {
@@ -25,7 +30,7 @@ public:
         }
     }
 
-    DnaBuffer(const DnaBuffer &o) : head_(o.head_), cap_(o.cap_), buf_(new uint8_t[o.cap_ ? o.cap_ : 1])
+    DnaBuffer(const DnaBuffer &o) : head_(o.head_), cap_(o.cap_), buf_(allocate(o.cap_, pinned_))
     {
         std::memcpy(buf_, o.buf_, o.cap_);
         seqs_.reserve(o.size());
@@ -33,7 +38,8 @@ public:
         for (size_t i = 0; i < o.size(); ++i) { seqs_.emplace_back(o[i].size(), buf_ + off); off += o[i].numbytes(); }
     }
     DnaBuffer &operator=(const DnaBuffer &) = delete;
-    ~DnaBuffer() { delete[] buf_; }
+    ~DnaBuffer() { if (pinned_) hsk_host_free(buf_); else delete[] buf_; }
+    bool pinned() const { return pinned_; }
 
     void push_back(const char *s, size_t len)
     {
@@ -64,8 +70,15 @@ public:
     }
 
 private:
+    static uint8_t *allocate(size_t n, bool &pinned)
+    {
+        pinned = false;
+        if (n >= (size_t(16) << 20)) { void *p = hsk_host_alloc(n); if (p) { pinned = true; return static_cast<uint8_t *>(p); } }
+        return new uint8_t[n ? n : 1];
+    }
     size_t head_;
     const size_t cap_;
+    bool pinned_ = false;            // (declared before buf_: allocate() sets it)
     uint8_t *buf_;
     std::vector<DnaSeq> seqs_;
 };
