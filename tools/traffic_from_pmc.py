@@ -27,7 +27,10 @@ if dom:
 # whole counting path (one step; the PMC passes run bench.py --steps 1 --warmup 0): everything but the synthetic-read generator
 path = 0.0
 for k, d in res.items():
-    if k.startswith("synth_"):
+    # not part of the counting path: the synthetic-read generator, and bench.py's own device-to-device copies (the measured
+    # copy peak: torch copies of 2 x 4 GiB run as __amd_rocclr_copyBuffer / at::native kernels; the path's own copyBuffer
+    # traffic, a 0.5 GB read-index copy per step, is dropped with them)
+    if k.startswith("synth_") or "at::native" in k or k.startswith("__amd_rocclr_copyBuffer"):
         continue
     path += d["launches"] * (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
 o["path_bytes_per_step"] = path
