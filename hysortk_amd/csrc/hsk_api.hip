@@ -216,12 +216,19 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
                              int64_t rid_base, hsk_result *out)
 {
     int rc;
+    const std::vector<void *> before = c->pool.snapshot();
     switch (c->nw) {
     case 1: rc = run_pipeline<1>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     case 2: rc = run_pipeline<2>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     default: rc = run_pipeline<3>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     }
-    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); hsk_result_free(c, out); }
+    if (rc != HSK_OK) {
+        // the failed call's kernels are drained, its result is dropped, and every device block it still holds goes back to the pool
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream);
+        hsk_result_free(c, out);
+        c->pool.release_all_but(before);
+        (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+    }
     return rc;
 }
 
@@ -366,6 +373,7 @@ extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *
     }
     u32 ntasks = 0;
     std::vector<int32_t> owner(HSK_MAX_TASKS, 0);
+    const std::vector<void *> before = c->pool.snapshot();
     if (rc == HSK_OK) {
         switch (c->nw) {
         case 1: rc = run_loopback<1>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
@@ -375,7 +383,12 @@ extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *
     }
     if (rc == HSK_OK && owner_out) { if ((u32)owner_capacity < ntasks) rc = HSK_ERR_INVALID_ARG; else memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks); }
     for (auto &d : in) free_input(c, d);
-    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); for (int r = 0; r < nranks; ++r) hsk_result_free(c, &outs[r]); }
+    if (rc != HSK_OK) {
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream);
+        for (int r = 0; r < nranks; ++r) hsk_result_free(c, &outs[r]);
+        c->pool.release_all_but(before);
+        (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+    }
     return rc;
 }
 

@@ -50,6 +50,15 @@ struct DevPool {
         for (auto &kv : live) (void)hipFree(kv.first);
         live.clear(); bytes_live = 0;
     }
+    // Error paths return early (DALLOC / HIPCHK) without releasing what the call had allocated so far: the entry points take
+    // a snapshot of the live blocks and, when the call fails, hand everything allocated since back to the pool.
+    std::vector<void *> snapshot() const { std::vector<void *> v; v.reserve(live.size()); for (auto &kv : live) v.push_back(kv.first); return v; }
+    void release_all_but(const std::vector<void *> &keep)        // keep: sorted (map order)
+    {
+        std::vector<void *> drop;
+        for (auto &kv : live) if (!std::binary_search(keep.begin(), keep.end(), kv.first)) drop.push_back(kv.first);
+        for (void *p : drop) release(p);
+    }
 };
 
 // pinned host memory for results (hipHostMalloc of gigabytes takes longer than counting them: freed result blocks are kept)
