@@ -2,7 +2,7 @@
 # bench at several task counts: tools/gpu_ntasks.sh 24 32 40 ...
 export TMPDIR=/tmp
 for nt in "$@"; do
-  python bench.py --steps 2 --warmup 1 --no-cpu --ntasks $nt 2>&1 | tail -1 > /tmp/ab.json
+  python bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --ntasks $nt 2>/dev/null | tail -1 > /tmp/ab.json
   python - "$nt" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab.json").read())
