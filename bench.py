@@ -229,7 +229,8 @@ def e2e_host_leg(H, KK, ext, ntasks, local, genome_len, nreads, seed, steps):
     nk = nreads * (READ_LEN - KK + 1)
     mean = sum(secs) / len(secs)
     return {"value": nk / mean, "unit": "k-mers/s", "ms_per_step": mean * 1e3, "steps": steps, "L": L, "U": U, "entries": n_entries,
-            "input": "DnaBuffer in pinned host memory (hsk_host_alloc): packed reads read in place over PCIe by the minimizer scan, read index copied ahead",
+            "input": "DnaBuffer in pinned host memory (hsk_host_alloc): packed reads read in place over PCIe by the minimizer scan; of the read index only the lengths travel "
+                     "(offsets derived on the device, the caller's offsets checked against them by host threads while the GPU scans)",
             "output": "KmerListS entries + histogram in pinned host memory; batches copied while later batches are counted",
             "h2d_bytes_per_step": st["h2d_bytes"] / steps, "d2h_bytes_per_step": st["d2h_bytes"] / steps,
             "h2d_ms": st["h2d_ms"] / steps, "d2h_ms": st["d2h_ms"] / steps,

@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
             if not force and not needs_build():          # somebody else built it while we waited
                 return LIB
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp,
+            cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", tmp,
                    os.path.join(SRC_DIR, "hsk_api.hip"), "-ldl"]
             if verbose:
                 print(" ".join(cmd))

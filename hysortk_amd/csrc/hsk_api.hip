@@ -19,8 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hsk.h"
@@ -300,6 +302,32 @@ static int check_host_index(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *o
     return HSK_OK;
 }
 
+// read_byte_off[r] == sum of (read_len + 3) / 4 over the reads before r?  (what DnaBuffer guarantees, reference src/dnabuffer.cpp:24-31)
+// Four threads: segment sums, then every segment is checked against its base.  Runs beside the GPU's scan.
+static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint64_t nreads)
+{
+    constexpr int NT = 4;
+    uint64_t seg[NT + 1], sum[NT];
+    for (int t = 0; t <= NT; ++t) seg[t] = nreads * (uint64_t)t / NT;
+    {
+        std::thread th[NT];
+        for (int t = 0; t < NT; ++t) th[t] = std::thread([&, t]() { uint64_t s = 0; for (uint64_t r = seg[t]; r < seg[t + 1]; ++r) s += ((uint64_t)len[r] + 3) >> 2; sum[t] = s; });
+        for (auto &x : th) x.join();
+    }
+    uint64_t base[NT]; { uint64_t b = 0; for (int t = 0; t < NT; ++t) { base[t] = b; b += sum[t]; } }
+    bool ok[NT];
+    {
+        std::thread th[NT];
+        for (int t = 0; t < NT; ++t) th[t] = std::thread([&, t]() {
+            uint64_t b = base[t]; bool good = true;
+            for (uint64_t r = seg[t]; r < seg[t + 1]; ++r) { good &= off[r] == b; b += ((uint64_t)len[r] + 3) >> 2; }
+            ok[t] = good; });
+        for (auto &x : th) x.join();
+    }
+    bool all = true; for (int t = 0; t < NT; ++t) all &= ok[t];
+    return all;
+}
+
 // Inputs in pinned host memory (hsk_host_alloc, hipHostMalloc, hipHostRegister) are not copied first: scan_kernel reads the
 // packed reads in place over PCIe -- once, while it hashes them -- and leaves the copy the later stages need in HBM, so the
 // transfer hides behind the VALU-bound scan; only the read index (12 bytes per read) travels ahead of it.  Pageable inputs
@@ -325,20 +353,43 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
         else (void)hipGetLastError();
     }
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    static const bool derive_enabled = !(getenv("HSK_DERIVE_OFFSETS") && atoi(getenv("HSK_DERIVE_OFFSETS")) == 0);
+    const bool derive = zc != nullptr && device_check && derive_enabled;       // only the read lengths travel ahead of the scan (see roff_tilesum_kernel)
     DevInput d;
+    u64 *d_given = nullptr, *d_tsum = nullptr;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 5; (void)hipEventRecord(ep.a, c->stream); }
-    rc = upload_input(c, zc ? nullptr : packed, packed_bytes, off, len, nreads, d, false);
+    if (!derive) rc = upload_input(c, zc ? nullptr : packed, packed_bytes, off, len, nreads, d, false);
+    else {
+        const u64 ntl = (nreads + ROFF_TILE - 1) / ROFF_TILE;
+        DALLOC(c, d.packed, u8 *, packed_bytes + 64);
+        DALLOC(c, d.roff, u64 *, (nreads + 1) * 8);
+        DALLOC(c, d.rlen, u32 *, (nreads + 1) * 4);
+        DALLOC(c, d_given, u64 *, (nreads + 1) * 8);
+        DALLOC(c, d_tsum, u64 *, ntl * 8 + 64);
+        u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
+        *stage = packed_bytes;
+        HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(roff_tilesum_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum);
+        hipLaunchKernelGGL(roff_tilescan_kernel, dim3(1), dim3(PARSE_THREADS), 0, c->stream, d_tsum, ntl);
+        hipLaunchKernelGGL(roff_write_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum, d.roff);
+        HIPCHK(c, hipMemcpyAsync(d.roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
+        // the caller's offsets stay on the host: four threads check them against the back-to-back layout while the GPU scans
+        c->roff_given = d_given; c->roff_host = off;
+        c->roff_check = std::async(std::launch::async, offsets_back_to_back, off, len, nreads);
+    }
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     c->stats.h2d_bytes += packed_bytes + nreads * 12;
-    if (rc == HSK_OK && device_check) {
+    if (rc == HSK_OK && device_check && !derive) {
         hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, d.roff, d.rlen, nreads, packed_bytes, c->d_err);
         c->index_unchecked = true;
     }
     c->zc_src = zc;
-    tmark(zc ? "input enqueued (zero-copy packed)" : "input enqueued (copies)");
+    tmark(zc ? (derive ? "input enqueued (zero-copy packed, offsets derived from the lengths)" : "input enqueued (zero-copy packed)") : "input enqueued (copies)");
     if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
     tmark("pipeline returned");
-    c->zc_src = nullptr; c->index_unchecked = false;
+    c->zc_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr;
+    if (c->roff_check.valid()) (void)c->roff_check.get();          // (the pipeline failed before it collected the verdict)
+    c->pool.release(d_given); c->pool.release(d_tsum);
     free_input(c, d);
     return rc;
 }

@@ -113,6 +113,12 @@ struct hsk_ctx {
     u32 *d_err = nullptr;
     Comm comm;
     const u8 *zc_src = nullptr;        // hsk_count() with pinned input: device view of the caller's packed reads (scan_kernel reads them in place)
+    // hsk_count() with derived read offsets: host threads compare the caller's offsets with the back-to-back layout while the GPU
+    // scans (result collected with the task totals); roff_host / roff_given: the caller's array and a device buffer for it, used
+    // only when the comparison fails (a buffer with gaps)
+    std::future<bool> roff_check;
+    const uint64_t *roff_host = nullptr;
+    u64 *roff_given = nullptr;
     bool index_unchecked = false;      // hsk_count(): the read index is validated on the device (index_check_kernel), the verdict is read with the task totals
     int agg_first_cap = 10;            // log2 of the hash table the next aggregation starts with (AG_LOG2CAP_*): follows the fullest bin of the
                                        // previous batch, so that reads with errors / low coverage do not pay for a table they overflow anyway

@@ -153,6 +153,19 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
+        if (c->roff_check.valid() && !c->roff_check.get()) {
+            // the buffer's reads do not lie back to back (the host threads found a gap while the GPU scanned): everything again
+            // with the caller's offsets, copied now and validated on the device
+            u64 *given = c->roff_given;
+            c->pool.release(d_task_tot);
+            parse_release(c, j);
+            HIPCHK(c, hipMemcpyAsync(given, c->roff_host, nreads * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(given + nreads, d_roff + nreads, 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, given, d_rlen, nreads, packed_bytes, c->d_err);
+            c->index_unchecked = true;
+            c->stats.h2d_bytes += nreads * 8;
+            return parse_count(c, d_packed, packed_bytes, given, d_rlen, nreads, rid_base, ntasks, j);
+        }
         if (c->index_unchecked) {
             c->index_unchecked = false;
             if (h_ovf[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }

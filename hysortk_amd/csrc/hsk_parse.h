@@ -966,6 +966,55 @@ __global__ void index_check_kernel(const u64 *roff, const u32 *rlen, u64 nreads,
     if (bad) atomicOr(err, 32u);
 }
 
+// ---- read offsets derived from the read lengths (hsk_count with a pinned DnaBuffer) ----------------------------------------
+// A DnaBuffer stores its reads back to back, every read on a byte boundary (reference src/dnabuffer.cpp:24-31), so
+// read_byte_off[r] = sum of (len + 3) / 4 over the reads before r.  Only the lengths (4 B per read) are copied ahead of the
+// scan; the caller's offsets (8 B per read) do not travel at all: host threads compare them with the same prefix sums while
+// the GPU scans (hsk_api.hip: offsets_back_to_back).  A buffer with gaps between its reads is counted again with the caller's offsets.
+constexpr int ROFF_TILE = PARSE_THREADS * 8;
+__global__ __launch_bounds__(PARSE_THREADS) void roff_tilesum_kernel(const u32 *rlen, u64 nreads, u64 *tile_sum)
+{
+    __shared__ u64 s_scr[8];
+    const u64 base = (u64)blockIdx.x * ROFF_TILE + (u64)threadIdx.x * 8;
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (base + i < nreads) sum += ((u64)rlen[base + i] + 3) >> 2;
+    u64 tot;
+    (void)block_excl_scan_256<u64>(sum, s_scr, &tot);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+// exclusive scan of the tile sums in place; one workgroup, 8 tiles per lane and step
+__global__ __launch_bounds__(PARSE_THREADS) void roff_tilescan_kernel(u64 *tile_sum, u64 ntiles)
+{
+    __shared__ u64 s_scr[8];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < ntiles; base += (u64)PARSE_THREADS * 8) {
+        const u64 t0 = base + (u64)threadIdx.x * 8;
+        u64 v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = t0 + i < ntiles ? tile_sum[t0 + i] : 0; sum += v[i]; }
+        u64 tot;
+        u64 ex = block_excl_scan_256<u64>(sum, s_scr, &tot) + s_carry;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { if (t0 + i < ntiles) tile_sum[t0 + i] = ex; ex += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(PARSE_THREADS) void roff_write_kernel(const u32 *rlen, u64 nreads, const u64 *tile_off, u64 *roff)
+{
+    __shared__ u64 s_scr[8];
+    const u64 base = (u64)blockIdx.x * ROFF_TILE + (u64)threadIdx.x * 8;
+    u64 nb[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { nb[i] = base + i < nreads ? ((u64)rlen[base + i] + 3) >> 2 : 0; sum += nb[i]; }
+    u64 ex = block_excl_scan_256<u64>(sum, s_scr, nullptr) + tile_off[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (base + i < nreads) roff[base + i] = ex; ex += nb[i]; }
+}
 // column sums of the COUNT matrix for task t; eight rows are requested before the first is added (one thread walks
 // ~1000 rows: a load per step would be a memory latency per row)
 __device__ __forceinline__ void col_sums(const u64 *blk_cnt, u32 nblocks, u32 ntasks, u32 t, u64 &s, u64 &b, u64 &k)

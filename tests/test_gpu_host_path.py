@@ -47,3 +47,32 @@ def test_invalid_read_index_is_rejected_on_the_device():
             c.count((packed, off, bad))
         again = c.count((packed, off, lens))                   # the context stays usable
     assert np.array_equal(good.kmers, again.kmers) and np.array_equal(good.cnt, again.cnt)
+
+
+def test_pinned_input_with_gaps_between_reads():
+    """hsk_count() on a pinned buffer derives the read offsets from the read lengths on the device (only the lengths travel ahead of
+    the scan) and compares them with the caller's offsets afterwards; a buffer whose reads do NOT lie back to back (the C ABI allows
+    gaps) must be noticed and counted with the caller's offsets -- same list as the gap-free buffer."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 5000                                       # >= 2^20 reads: device-side index handling
+    packed, off, lens = synth.packed_reads(2000000, 150, n, 21)            # 38 bytes per read: 40 MB
+    nb = 38
+    gap_at, gap = n // 3, 24
+    packed_g = np.concatenate([packed[:gap_at * nb], np.full(gap, 0xFF, np.uint8), packed[gap_at * nb:]])
+    off_g = off.copy(); off_g[gap_at:] += np.uint64(gap)
+    arrs = []
+    for pk, of in ((packed, off), (packed_g, off_g)):
+        pp, po, pl = H.pinned_empty(pk.size, np.uint8), H.pinned_empty(of.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+        pp[:] = pk; po[:] = of; pl[:] = lens
+        arrs.append((pp, po, pl))
+    with H.Context(K=31, M=17, L=2, U=200, ntasks=16) as c:
+        a = c.count(arrs[0])
+        b = c.count(arrs[1])
+        ref = c.count((packed, off, lens))                     # pageable: plain copies, host-side... device-side index check
+    for x in arrs:
+        for y in x:
+            H.pinned_free(y)
+    assert len(ref) > 100000
+    for x in (a, b):
+        assert np.array_equal(ref.kmers, x.kmers) and np.array_equal(ref.cnt, x.cnt) and np.array_equal(ref.task_off, x.task_off)

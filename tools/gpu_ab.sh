@@ -1,11 +1,10 @@
 #!/bin/bash
-# A/B of environment switches on the full-size bench: tools/gpu_ab.sh "VAR=a" "VAR=b" ...
+# A/B of alternative builds of libhsk.so (HSK_LIB): tools/gpu_ab.sh <lib-or-"default"> ...
 export TMPDIR=/tmp
-for kv in "$@"; do
-  env $kv python bench.py --steps 2 --warmup 1 --no-cpu 2>&1 | tail -1 > /tmp/ab.json
-  python - "$kv" <<'PY'
-import json, sys
-d = json.loads(open("/tmp/ab.json").read())
-print("%-40s %.3f G k-mers/s  %.1f ms/step  %s ntasks %s %s" % (sys.argv[1], d["value"] / 1e9, d["ms_per_step"], {k[3:]: round(v, 1) for k, v in d["phases_ms_per_step"].items() if k not in ("ms_d2h", "ms_exchange")}, d["config"]["ntasks"], d.get("path_stats")))
-PY
+for lib in "$@"; do
+  if [ "$lib" = "default" ]; then unset HSK_LIB; else export HSK_LIB=$PWD/$lib; fi
+  python bench.py --steps 3 --warmup 1 --no-cpu --no-e2e 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%-40s %.2f G  %.1f ms ' % ('$lib', d['value']/1e9, d['ms_per_step']), [(k['kernel'][:14], round(k['ms_per_step'],2)) for k in d['kernels']])"
 done
