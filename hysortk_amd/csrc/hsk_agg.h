@@ -90,6 +90,108 @@ __device__ __forceinline__ u32 agg_slot(u64 k)
     return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
 }
 
+// Steps 2 and 3 of the aggregation for one bin whose records have been counted into the table {s_key, s_cnt} (CAP slots):
+// compact the distinct keys, order them, filter [L, U], write the entries to the bin's slots, publish the count.
+// Called by all threads of the workgroup (barriers inside).
+template <int LOG2CAP>
+__device__ __forceinline__ void agg_emit_bin(const AggArgs &a, const AggTask &t, u32 b, u64 s, u64 *s_key, u32 *s_cnt, u32 *s_bkt, u32 *s_scr)
+{
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    constexpr int NBKT = CAP / 2;
+    const int tid = threadIdx.x;
+    // ---- 2. compact the occupied slots (in place: every lane holds its PER slots in registers across the
+    //         barrier), sort the distinct keys ---------------------------------------------------------------
+    u64 mk[PER]; u32 mc[PER];
+    u32 occ = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { mk[j] = s_key[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
+    u32 D;
+    u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);      // (two barriers inside: all slots are read before any is rewritten)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
+    __syncthreads();
+    if (tid == 0 && D > 256u) atomicMax(t.flags + AG_BATCH, D);      // (feedback for the host's choice of the first table; small bins are the common case and stay silent)
+    if (D <= (u32)AG_THREADS) {
+        // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
+        u64 k = 0; u32 c = 0, r = 0;
+        if ((u32)tid < D) {
+            k = s_key[tid]; c = s_cnt[tid];
+            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
+        }
+        __syncthreads();
+        if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; }
+        __syncthreads();
+    } else {
+        // Hundreds to thousands of distinct keys (low coverage, reads with errors): counting sort on the key bits right below
+        // the bin prefix -- the keys of a bin are close to uniform there, about one per bucket --, then every key ranks itself
+        // inside its bucket: ~10 LDS operations per key instead of the ~log^2 of a sorting network; a bucket that collects
+        // many keys (a shared prefix) costs only its own square.  In place: every lane keeps its keys in registers across
+        // the barriers between "all read" and "all write".
+        constexpr int EPT = CAP / AG_THREADS;
+        constexpr int LOG2BKT = LOG2CAP - 1;
+        const int bshift = a.shift - LOG2BKT;              // (the prefix bits are equal inside a bin: masked off below)
+        for (int i = tid; i < NBKT; i += AG_THREADS) s_bkt[i] = 0;
+        __syncthreads();
+        u64 ek[EPT]; u32 ec[EPT], er[EPT];
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            const u32 i = x * AG_THREADS + tid;
+            ek[x] = AG_EMPTY; ec[x] = 0; er[x] = 0;
+            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)], 1u); }
+        }
+        __syncthreads();
+        {
+            constexpr int BPT = NBKT / AG_THREADS;
+            u32 v[BPT], sum = 0;
+#pragma unroll
+            for (int x = 0; x < BPT; ++x) { v[x] = s_bkt[tid * BPT + x]; sum += v[x]; }
+            u32 ex = block_excl_scan_256<u32>(sum, s_scr, nullptr);
+#pragma unroll
+            for (int x = 0; x < BPT; ++x) { s_bkt[tid * BPT + x] = ex; ex += v[x]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x)
+            if (ek[x] != AG_EMPTY) s_key[s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)] + er[x]] = ek[x];        // bucket-major (counts follow below)
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) {
+            if (ek[x] == AG_EMPTY) continue;
+            const u32 bk = (u32)(ek[x] >> bshift) & (NBKT - 1);
+            const u32 b0 = s_bkt[bk], b1 = (bk + 1 < (u32)NBKT) ? s_bkt[bk + 1] : D;
+            u32 r = b0;
+            for (u32 q = b0; q < b1; ++q) r += s_key[q] < ek[x];
+            er[x] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPT; ++x) if (ek[x] != AG_EMPTY) { s_key[er[x]] = ek[x]; s_cnt[er[x]] = ec[x]; }
+        __syncthreads();
+    }
+    const u64 *sk = s_key; const u32 *sc = s_cnt;
+
+    // ---- 3. filter, entries in key order to the bin's slots --------------------------------------------------
+    u32 kept = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) { const u32 c = sc[i]; kept += (c >= a.lower && c <= a.upper); }
+    }
+    u32 tot;
+    u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);
+    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 2;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) {
+            const u32 c = sc[i];
+            if (c >= a.lower && c <= a.upper) { dst[0] = sk[i]; dst[1] = (u64)c; dst += 2; }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+}
+
 // Diagnostic build only (-DHSK_DIAG): shader-clock sums per phase of agg_finish_kernel, stamped by thread 0 of every workgroup
 #ifdef HSK_DIAG
 __device__ unsigned long long g_agg_diag[16];
@@ -158,101 +260,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         return;
     }
 
-    // ---- 2. compact the occupied slots (in place: every lane holds its PER slots in registers across the
-    //         barrier), sort the distinct keys ---------------------------------------------------------------
-    u64 mk[PER]; u32 mc[PER];
-    u32 occ = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { mk[j] = s_key[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
-    u32 D;
-    u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);      // (two barriers inside: all slots are read before any is rewritten)
-#pragma unroll
-    for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
-    __syncthreads();
-    AG_STAMP(3);                                        // distinct keys compacted
-    if (tid == 0 && D > 256u) atomicMax(t.flags + AG_BATCH, D);      // (feedback for the host's choice of the first table; small bins are the common case and stay silent)
-    if (D <= (u32)AG_THREADS) {
-        // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
-        u64 k = 0; u32 c = 0, r = 0;
-        if ((u32)tid < D) {
-            k = s_key[tid]; c = s_cnt[tid];
-            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
-        }
-        __syncthreads();
-        if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; }
-        __syncthreads();
-    } else {
-        // Hundreds to thousands of distinct keys (low coverage, reads with errors): counting sort on the key bits right below
-        // the bin prefix -- the keys of a bin are close to uniform there, about one per bucket --, then every key ranks itself
-        // inside its bucket: ~10 LDS operations per key instead of the ~log^2 of a sorting network; a bucket that collects
-        // many keys (a shared prefix) costs only its own square.  In place: every lane keeps its keys in registers across
-        // the barriers between "all read" and "all write".
-        constexpr int EPT = CAP / AG_THREADS;
-        constexpr int LOG2BKT = LOG2CAP - 1;
-        const int bshift = a.shift - LOG2BKT;              // (the prefix bits are equal inside a bin: masked off below)
-        for (int i = tid; i < NBKT; i += AG_THREADS) s_bkt[i] = 0;
-        __syncthreads();
-        u64 ek[EPT]; u32 ec[EPT], er[EPT];
-#pragma unroll
-        for (int x = 0; x < EPT; ++x) {
-            const u32 i = x * AG_THREADS + tid;
-            ek[x] = AG_EMPTY; ec[x] = 0; er[x] = 0;
-            if (i < D) { ek[x] = s_key[i]; ec[x] = s_cnt[i]; er[x] = atomicAdd(&s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)], 1u); }
-        }
-        __syncthreads();
-        {
-            constexpr int BPT = NBKT / AG_THREADS;
-            u32 v[BPT], sum = 0;
-#pragma unroll
-            for (int x = 0; x < BPT; ++x) { v[x] = s_bkt[tid * BPT + x]; sum += v[x]; }
-            u32 ex = block_excl_scan_256<u32>(sum, s_scr, nullptr);
-#pragma unroll
-            for (int x = 0; x < BPT; ++x) { s_bkt[tid * BPT + x] = ex; ex += v[x]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < EPT; ++x)
-            if (ek[x] != AG_EMPTY) s_key[s_bkt[(u32)(ek[x] >> bshift) & (NBKT - 1)] + er[x]] = ek[x];        // bucket-major (counts follow below)
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < EPT; ++x) {
-            if (ek[x] == AG_EMPTY) continue;
-            const u32 bk = (u32)(ek[x] >> bshift) & (NBKT - 1);
-            const u32 b0 = s_bkt[bk], b1 = (bk + 1 < (u32)NBKT) ? s_bkt[bk + 1] : D;
-            u32 r = b0;
-            for (u32 q = b0; q < b1; ++q) r += s_key[q] < ek[x];
-            er[x] = r;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < EPT; ++x) if (ek[x] != AG_EMPTY) { s_key[er[x]] = ek[x]; s_cnt[er[x]] = ec[x]; }
-        __syncthreads();
-    }
-    const u64 *sk = s_key; const u32 *sc = s_cnt;
-    AG_STAMP(4);                                        // distinct keys ordered
-
-    // ---- 3. filter, entries in key order to the bin's slots --------------------------------------------------
-    u32 kept = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const u32 i = tid * PER + j;
-        if (i < D) { const u32 c = sc[i]; kept += (c >= a.lower && c <= a.upper); }
-    }
-    u32 tot;
-    u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);
-    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 2;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const u32 i = tid * PER + j;
-        if (i < D) {
-            const u32 c = sc[i];
-            if (c >= a.lower && c <= a.upper) { dst[0] = sk[i]; dst[1] = (u64)c; dst += 2; }
-        }
-    }
-    if (tid == 0) t.bin_cnt[b] = tot;
+    // ---- 2, 3. distinct keys compacted, ordered, filtered, written -------------------------------------------
+    agg_emit_bin<LOG2CAP>(a, t, b, s, s_key, s_cnt, s_bkt, s_scr);
     AG_STAMP(5);                                        // filtered and written
 #ifdef HSK_DIAG
-    if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_agg_diag[i], ag_acc[i]); atomicAdd(&g_agg_diag[8], 1ULL); atomicAdd(&g_agg_diag[9], (unsigned long long)(e - s)); atomicAdd(&g_agg_diag[10], (unsigned long long)D); }
+    if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_agg_diag[i], ag_acc[i]); atomicAdd(&g_agg_diag[8], 1ULL); atomicAdd(&g_agg_diag[9], (unsigned long long)(e - s)); }
 #endif
 }
 

@@ -145,7 +145,9 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
-        hipLaunchKernelGGL(scan_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;      // (tests: the default (k, m) through the generic instance)
+        if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         a.packed = d_packed; a.packed_copy = nullptr; c->zc_src = nullptr;                                  // everything after the scan reads the copy in HBM
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);

@@ -92,8 +92,10 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     // beside the sort of the previous batch (second stream): HSK_SCATTER_SHARE percent of the resident workgroups
     static const int share_pct = getenv("HSK_SCATTER_SHARE") ? atoi(getenv("HSK_SCATTER_SHARE")) : 100;
     const u32 grid = (stream != c->stream) ? std::max(8u, (u32)occ * 256u * (u32)share_pct / 100u) : (u32)occ * 256u;
+    static const bool xs_generic = getenv("HSK_SCATTER_GENERIC") && atoi(getenv("HSK_SCATTER_GENERIC")) != 0;        // (tests: the default k through the generic instance)
     if constexpr (NW == 1) {
         if (ext) hipLaunchKernelGGL((expand_scatter_kernel<1, true>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+        else if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56 && !xs_generic) hipLaunchKernelGGL((expand_scatter_kernel<1, false, 31>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
         else hipLaunchKernelGGL((expand_scatter_kernel<1, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
     } else hipLaunchKernelGGL((expand_scatter_kernel<NW, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }

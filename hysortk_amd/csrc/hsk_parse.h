@@ -489,6 +489,9 @@ __device__ __forceinline__ int scan_hidx(int p) { return (p & 7) * SCAN_HSTRIDE 
 #ifdef HSK_DIAG
 __device__ unsigned long long g_scan_diag[16];
 #endif
+// KT, MT: k and m as compile-time constants (0: taken from the arguments).  The reference fixes both at compile time
+// (KMER_SIZE, MINIMIZER_SIZE); here the default pair gets its own instance: shifts, masks and the window loop fold.
+template <int KT, int MT>
 __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     extern __shared__ __attribute__((aligned(16))) u64 s_cur[];          // [task] {supermers << 40 | k-mers, bytes}
 
     const int tid = threadIdx.x;
-    const int K = a.k, M = a.m, W = K - M + 1;
+    const int K = KT ? KT : a.k, M = MT ? MT : a.m, W = K - M + 1;
     const u64 mmask = ~0ULL << (64 - 2 * M);
     for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
     const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
@@ -587,12 +590,13 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         u64 h[PARSE_PPT];
         {
             const u64 w0 = bits64_be32(s_words, 16u * (u32)tid);       // 32 bases from position p0
-            const u64 cw = ~w0;
-            u64 rc = twin1(w0 & mmask, M);
+            // reverse complement of the whole window: the twin of the m-mer at offset i is its bases [32 - M - i, 32 - i)
+            // (i + M <= 32: SCAN_MAX_M), one shift per position instead of a rolled state
+            const u64 rw = ~rev2(w0);
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 const u64 fw = (w0 << (2 * i)) & mmask;
-                if (i > 0) rc = ((rc >> 2) | ((cw << (2 * (i - 1 + M))) & (3ULL << 62))) & mmask;   // base p0+i-1+M enters the reverse strand
+                const u64 rc = (rw << (2 * (32 - M - i))) & mmask;
                 h[i] = murmur64_8(rc < fw ? rc : fw);
             }
 #pragma unroll
@@ -652,16 +656,19 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 const long long cnt = (long long)rend - (long long)K - (long long)g0 + 1;
                 vmask = cnt <= 0 ? 0u : (cnt >= PARSE_PPT ? 0xFFu : ((1u << (u32)cnt) - 1u));
             } else {
-#pragma unroll
-                for (int i = 0; i < PARSE_PPT; ++i) {
-                    const u64 g = g0 + i;
-                    while (g >= nxt) {
-                        ++r; rstart = nxt;
-                        if (fast) { const u32 j = (u32)(r - rb); rend = rstart + s_rlen[j]; nxt = (r + 1 < a.nreads) ? s_roff[j + 1] * 4 : ~0ULL; }
-                        else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
-                    }
-                    if (g + (u64)K <= rend) vmask |= 1u << i;
-                }
+                // a read ends under this lane.  Reads start on bytes (4 positions) and g0 is a multiple of 8: the next read starts
+                // at g0 + 4 exactly, positions 0-3 belong to read r and positions 4-7 to the LAST read that starts at g0 + 4 (reads
+                // without bases share their offset with their successor); nothing else can start before g0 + 8.
+                static_assert(PARSE_PPT == 8, "two bytes of bases per lane");
+                const long long cnt_lo = (long long)rend - (long long)K - (long long)g0 + 1;
+                vmask = cnt_lo <= 0 ? 0u : (cnt_lo >= 4 ? 0xFu : ((1u << (u32)cnt_lo) - 1u));
+                do {
+                    ++r; rstart = nxt;
+                    if (fast) { const u32 j = (u32)(r - rb); rend = rstart + s_rlen[j]; nxt = (r + 1 < a.nreads) ? s_roff[j + 1] * 4 : ~0ULL; }
+                    else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
+                } while (nxt <= g0 + 4);
+                const long long cnt_hi = (long long)rend - (long long)K - (long long)(g0 + 4) + 1;
+                vmask |= (cnt_hi <= 0 ? 0u : (cnt_hi >= 4 ? 0xFu : ((1u << (u32)cnt_hi) - 1u))) << 4;
             }
         }
         s_last[tid] = mn[PARSE_PPT - 1];

@@ -103,7 +103,9 @@ __device__ unsigned long long g_xs_diag[16];
 
 // EXT: every k-mer carries pos | rid << 32 (reference include/kmer.hpp:350-360) = its item's base value + the round; the stage
 // keeps (lane, round) per slot and the lanes' base values sit in LDS, so the payload is rebuilt when the run is written.
-template <int NW, bool EXT>
+// KT: k as a compile-time constant with the two digits in the top 16 key bits (0: k and the digit shifts come from the
+// arguments).  The reference fixes k at compile time (KMER_SIZE); here the default k gets its own instance.
+template <int NW, bool EXT, int KT = 0>
 __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
 {
     constexpr int XS_RUN = XsCfg<NW>::RUN, XS_MAX_ITEMS = XsCfg<NW>::MAX_ITEMS, XS_CHUNK = XsCfg<NW>::CHUNK;
@@ -130,10 +132,10 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
     const ScatterTask &t = a.t[xcc];
     if (t.ntiles == 0) return;
-    const int k = a.k;
+    const int k = KT ? KT : a.k;
     const int low = 64 * NW - 2 * k;                       // unused low bits of the last word
     const u64 lastmask = ~0ULL << low;
-    const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u;
+    const u32 sh0 = KT ? 16u : (u32)a.shift0 - 32u, sh1 = KT ? 24u : (u32)a.shift1 - 32u;
     const int nseg = t.nseg;
     const bool single = nseg == 1;                         // one GPU: one segment, kept in scalar registers
     const bool segs_lds = nseg <= XS_MAXSEG;               // the next tile's inputs are prefetched
