@@ -180,9 +180,23 @@ __host__ __device__ __forceinline__ u32 fastmod64(u64 x, const FastMod &f)
 // ---- wave / block scans ------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
 
+// 32-bit sums: six adds whose operand comes through the data-parallel-primitive path of the VALU (row shifts inside the four
+// rows of 16 lanes, then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3): no LDS permutes, no selects
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v)
+{
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1 (lanes without a source add the `old` operand: 0)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15, rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31, rows 2 and 3
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v)
 {
+    if constexpr (sizeof(T) == 4 && (T)(-1) > (T)0) return (T)wave_incl_scan_dpp((u32)v);
     const int lane = lane_id();
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {

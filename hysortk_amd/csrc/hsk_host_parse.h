@@ -147,6 +147,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
         static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;      // (tests: the default (k, m) through the generic instance)
         if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         a.packed = d_packed; a.packed_copy = nullptr; c->zc_src = nullptr;                                  // everything after the scan reads the copy in HBM

@@ -97,7 +97,8 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         if (ext) hipLaunchKernelGGL((expand_scatter_kernel<1, true>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
         else if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56 && !xs_generic) hipLaunchKernelGGL((expand_scatter_kernel<1, false, 31>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
         else hipLaunchKernelGGL((expand_scatter_kernel<1, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
-    } else hipLaunchKernelGGL((expand_scatter_kernel<NW, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    } else if (NW == 2 && a.k == 51 && a.shift0 == 48 && a.shift1 == 56 && !xs_generic) hipLaunchKernelGGL((expand_scatter_kernel<NW, false, NW == 2 ? 51 : 0>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((expand_scatter_kernel<NW, false>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     sb.active = true;

@@ -618,6 +618,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         u64 mn[PARSE_PPT];
         if (W >= PARSE_PPT) {
             u64 c = h[PARSE_PPT - 1];
+#pragma unroll 8
             for (int j = PARSE_PPT; j <= W - 1; ++j) { const u64 v = s_hash[scan_hidx(p0 + j)]; c = v < c ? v : c; }
             mn[PARSE_PPT - 1] = c;
             u64 suf = ~0ULL;
