@@ -682,18 +682,17 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         // ---- 4. boundaries, supermer starts, compaction ---------------------------------------------------
         u32 start8 = 0;
         {
+            // a supermer cannot continue across position i if i holds no k-mer, is a forced cut, follows a position without
+            // k-mer or has another window minimum than its predecessor: all but the last as byte masks of the lane's 8 positions
             u64 pm = tid ? s_last[tid - 1] : 0;
-            bool pv = tid ? ((s_v8[tid - 1] >> 7) & 1) != 0 : false;
-            u32 bnd8 = 0;
+            const u32 pv = tid ? (u32)(s_v8[tid - 1] >> 7) : 0u;
+            u32 neq8 = 0;
 #pragma unroll
-            for (int i = 0; i < PARSE_PPT; ++i) {
-                const bool v = (vmask >> i) & 1;
-                const bool cut = (i == 0) && ((tid & (SUPERMER_CUT / PARSE_PPT - 1)) == 0);
-                const bool bnd = !v || cut || !pv || (mn[i] != pm);
-                bnd8 |= (bnd ? 1u : 0u) << i;
-                start8 |= ((v && bnd) ? 1u : 0u) << i;
-                pm = mn[i]; pv = v;
-            }
+            for (int i = 0; i < PARSE_PPT; ++i) { neq8 |= (mn[i] != pm ? 1u : 0u) << i; pm = mn[i]; }
+            const u32 cut8 = ((tid & (SUPERMER_CUT / PARSE_PPT - 1)) == 0) ? 1u : 0u;
+            const u32 prev8 = (vmask << 1) | pv;                         // bit i: position i - 1 holds a k-mer
+            const u32 bnd8 = (~vmask | cut8 | ~prev8 | neq8) & 0xFFu;
+            start8 = vmask & bnd8;
             s_bnd8[tid] = (u8)bnd8;
         }
         u32 nrec;

@@ -51,6 +51,7 @@ template <int NW> struct XsCfg {
     static constexpr int MAX_ITEMS = XS_TILE * (128 / RUN);
     static constexpr int CHUNK = SortTile<NW>::TILE;
     static_assert(XS_THREADS * RUN <= (XS_SPAN - 1) * CHUNK, "a reservation touches at most XS_SPAN chunks of a digit");
+    static_assert(2 * (RUN - 1) < 32, "the k-mers of an item start inside the first 32 bits of its window (funnel_left)");
     static_assert((CHUNK & (CHUNK - 1)) == 0, "chunk size is a power of two");
 };
 static_assert(XS_THREADS == XS_TILE, "one supermer per thread in the tile prologue");
@@ -93,6 +94,13 @@ __device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 *
     return base + inc - v;
 }
 
+// bits [c, c + 64) of the 128-bit string a:b, 0 < c < 32
+__device__ __forceinline__ u64 funnel_left(u64 a, u64 b, int c)
+{
+    const u32 ah = (u32)(a >> 32), al = (u32)a, bh = (u32)(b >> 32);
+    return ((u64)__builtin_amdgcn_alignbit(ah, al, 32 - c) << 32) | (u64)__builtin_amdgcn_alignbit(al, bh, 32 - c);
+}
+
 // Diagnostic build only (-DHSK_DIAG): shader-clock sums per phase of a flush, stamped by thread 0 of every workgroup
 #ifdef HSK_DIAG
 __device__ unsigned long long g_xs_diag[16];
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
     __shared__ u64 s_stage[XS_CHUNK * NW];
     __shared__ u64 s_vb[EXT ? XS_THREADS : 1];
     __shared__ u16 s_src[EXT ? XS_CHUNK : 1];
-    __shared__ u32 s_cnt[256], s_start[256], s_split[256], s_hist[256];
-    __shared__ u32 s_dl[XS_SPAN][256];                                  // staged slot + s_dl[j][d] = slot in the chunk store (j-th chunk of the reservation)
+    __shared__ u32 s_cnt[256], s_start[256], s_hist[256];
+    __shared__ uint4 s_dl[256];                                         // per digit {split, d0, d1, d2}: staged slot g goes to g + d0 (g < split), g + d1 (g < split + chunk), else g + d2
     __shared__ u32 s_scr[XS_WAVES];
     __shared__ u32 s_blk[2];
     __shared__ u64 s_seg[4][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile, first byte} of the task's segments
@@ -287,12 +295,10 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
 #pragma unroll
             for (int r = 0; r < XS_RUN; ++r) {
                 if (r > 0) {
-                    // one base further: window left by 2 bits; twin right by 2 bits, complement of the entering base on top
+                    // one base further: the k-mer at bit 2r of the window (two funnel shifts per word, the window itself stays);
+                    // twin right by 2 bits, complement of the entering base on top
 #pragma unroll
-                    for (int x = 0; x < NW; ++x) win[x] = (win[x] << 2) | (win[x + 1] >> 62);
-                    win[NW] <<= 2;
-#pragma unroll
-                    for (int x = 0; x < NW; ++x) fw.w[x] = win[x];
+                    for (int x = 0; x < NW; ++x) fw.w[x] = funnel_left(win[x], win[x + 1], 2 * r);
                     fw.w[NW - 1] &= lastmask;
                     const u64 nbase = (fw.w[NW - 1] >> low) & 3;
 #pragma unroll
@@ -363,10 +369,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                     }
                 }
                 const u32 split = st + ((u32)XS_CHUNK - off0);         // first slot (in the sorted order of the flush) in the second chunk
-                s_split[tid] = split;
-                s_dl[0][tid] = (ph[0] - 1) * (u32)XS_CHUNK + off0 - st;
-                s_dl[1][tid] = ((ph[1] ? ph[1] : 1u) - 1) * (u32)XS_CHUNK - split;
-                s_dl[2][tid] = ((ph[2] ? ph[2] : 1u) - 1) * (u32)XS_CHUNK - (split + (u32)XS_CHUNK);
+                s_dl[tid] = make_uint4(split, (ph[0] - 1) * (u32)XS_CHUNK + off0 - st, ((ph[1] ? ph[1] : 1u) - 1) * (u32)XS_CHUNK - split,
+                                       ((ph[2] ? ph[2] : 1u) - 1) * (u32)XS_CHUNK - (split + (u32)XS_CHUNK));
             }
             XS_STAMP(5);                                              // reservation returned, chunk resolved
             for (u32 w0 = 0; w0 < tot; w0 += XS_CHUNK) {
@@ -386,8 +390,9 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
 #pragma unroll
                     for (int x = 0; x < NW; ++x) kw[x] = s_stage[i * NW + x];
                     const u32 d = ((u32)(kw[NW - 1] >> 32) >> sh0) & 255u;
-                    const u32 g = w0 + i, sp = s_split[d];
-                    const u32 o = g + (g < sp ? s_dl[0][d] : (g < sp + (u32)XS_CHUNK ? s_dl[1][d] : s_dl[2][d]));   // (mod 2^32)
+                    const u32 g = w0 + i;
+                    const uint4 dl = s_dl[d];
+                    const u32 o = g + (g < dl.x ? dl.y : (g < dl.x + (u32)XS_CHUNK ? dl.z : dl.w));   // (mod 2^32)
                     if (NW == 2) *reinterpret_cast<ulonglong2 *>(t.chunks + (u64)o * 2) = make_ulonglong2(kw[0], kw[NW - 1]);
                     else {
 #pragma unroll
