@@ -90,6 +90,57 @@ __device__ __forceinline__ u32 agg_slot(u64 k)
     return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
 }
 
+// Counts one key per lane of `act` (a lane mask) in the LDS table: the probe sequence of section 1 of agg_finish_kernel as a
+// loop of the WAVE.  Per probe the slot of every lane still in `act` is read, an empty slot is claimed with the lane's key
+// (compare-and-swap), lanes that found their key or claimed the slot add one to its counter and leave `act`; the others move
+// to the next slot.  Returns the lanes that ran out of probes (0: all counted).
+// Written in assembly because the scalar unit is what this kernel runs out of (8 more scalar instructions per probe cost
+// 14 % of its time): the compiler spends ~25 scalar instructions per probe on execution-mask bookkeeping for the equivalent
+// if / break structure, this loop 7 (9 when a slot is claimed, 3 more per further probe).
+//   key_base / cnt_base: LDS byte addresses of the key and count arrays; h: first slot (CAP = MASK + 1 slots)
+template <u32 MASK>
+__device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_base, u32 h, u64 k)
+{
+    u64 save, t, cur;
+    u32 ka, ca, p;
+    const u64 empty = AG_EMPTY;
+    const u32 one = 1u;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_movk_i32 %[p], %[maxp]\n"
+        "0:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "v_lshl_add_u32 %[ka], %[h], 3, %[kb]\n\t"
+        "v_lshl_add_u32 %[ca], %[h], 2, %[cb]\n\t"
+        "ds_read_b64 %[cur], %[ka]\n\t"
+        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_and_b32 %[h], %[mask], %[h]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
+        "s_cbranch_vccz 1f\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_cmpst_rtn_b64 %[cur], %[ka], %[emp], %[k]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "1:\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
+        "v_cmp_eq_u64 %[t], %[cur], %[k]\n\t"
+        "s_or_b64 vcc, vcc, %[t]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[ca], %[one]\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_sub_u32 %[p], %[p], 1\n\t"
+        "s_cmp_lg_u32 %[p], 0\n\t"
+        "s_cbranch_scc1 0b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [act] "+s"(act), [h] "+v"(h), [save] "=&s"(save), [t] "=&s"(t), [p] "=&s"(p), [cur] "=&v"(cur), [ka] "=&v"(ka), [ca] "=&v"(ca)
+        : [kb] "s"(key_base), [cb] "s"(cnt_base), [k] "v"(k), [emp] "v"(empty), [one] "v"(one), [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE)
+        : "vcc", "scc", "memory");
+    return act;
+}
+
 // Steps 2 and 3 of the aggregation for one bin whose records have been counted into the table {s_key, s_cnt} (CAP slots):
 // compact the distinct keys, order them, filter [L, U], write the entries to the bin's slots, publish the count.
 // Called by all threads of the workgroup (barriers inside).
@@ -232,12 +283,18 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     // ---- 1. count the records of the bin in the table ------------------------------------------------------
     // 16 loads per lane are issued before the first insert: a typical bin (4096 records) costs one memory latency
     constexpr int AG_UNROLL = 16;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_key, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;     // LDS byte addresses of the two arrays
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * AG_UNROLL) {
         u64 k[AG_UNROLL];
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
+#ifndef HSK_AGG_NOASM
+            const u64 act = __ballot(k[u] != AG_EMPTY);
+            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, agg_slot<LOG2CAP>(k[u]), k[u]) != 0) s_ovf = 1;      // (uniform)
+#else
             if (k[u] == AG_EMPTY) continue;
             u32 h = agg_slot<LOG2CAP>(k[u]);
             bool done = false;
@@ -248,6 +305,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
                 h = (h + 1) & (CAP - 1);
             }
             if (!done) s_ovf = 1;
+#endif
         }
         // a bin with more distinct keys than the table takes (a probe sequence ran past AG_MAX_PROBE slots: with linear probing
         // that starts at a load of ~0.8) gives up here instead of grinding through the rest of its records
