@@ -93,13 +93,13 @@ __device__ __forceinline__ u32 agg_slot(u64 k)
 // Counts one key per lane of `act` (a lane mask) in the LDS table: the probe sequence of section 1 of agg_finish_kernel as a
 // loop of the WAVE.  Per probe the slot of every lane still in `act` is read, an empty slot is claimed with the lane's key
 // (compare-and-swap), lanes that found their key or claimed the slot add one to its counter and leave `act`; the others move
-// to the next slot.  Returns the lanes that ran out of probes (0: all counted).
+// to the next slot.  Returns the lanes that ran out of probes (0: all counted); h leaves as the slot the lane's key was counted in.
 // Written in assembly because the scalar unit is what this kernel runs out of (8 more scalar instructions per probe cost
 // 14 % of its time): the compiler spends ~25 scalar instructions per probe on execution-mask bookkeeping for the equivalent
-// if / break structure, this loop 7 (9 when a slot is claimed, 3 more per further probe).
+// if / break structure, this loop 6 (9 when a slot is claimed, 4 more per further probe).
 //   key_base / cnt_base: LDS byte addresses of the key and count arrays; h: first slot (CAP = MASK + 1 slots)
 template <u32 MASK>
-__device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_base, u32 h, u64 k)
+__device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_base, u32 &h, u64 k)
 {
     u64 save, t, cur;
     u32 ka, ca, p;
@@ -107,29 +107,33 @@ __device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_bas
     const u32 one = 1u;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
-        "s_movk_i32 %[p], %[maxp]\n"
+        "s_movk_i32 %[p], %[maxp]\n\t"
+        "s_mov_b64 exec, %[act]\n"
         "0:\n\t"
-        "s_mov_b64 exec, %[act]\n\t"
         "v_lshl_add_u32 %[ka], %[h], 3, %[kb]\n\t"
-        "v_lshl_add_u32 %[ca], %[h], 2, %[cb]\n\t"
         "ds_read_b64 %[cur], %[ka]\n\t"
-        "v_add_u32 %[h], 1, %[h]\n\t"
-        "v_and_b32 %[h], %[mask], %[h]\n\t"
+        "v_lshl_add_u32 %[ca], %[h], 2, %[cb]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
-        "s_cbranch_vccz 1f\n\t"
+        "s_cbranch_vccz 1f\n\t"                              // no empty slot among the lanes: nothing to claim
         "s_mov_b64 exec, vcc\n\t"
         "ds_cmpst_rtn_b64 %[cur], %[ka], %[emp], %[k]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[act]\n"
-        "1:\n\t"
-        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
-        "v_cmp_eq_u64 %[t], %[cur], %[k]\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"                   // claimed ...
+        "v_cmp_eq_u64 %[t], %[cur], %[k]\n\t"                // ... or found
         "s_or_b64 vcc, vcc, %[t]\n\t"
+        "s_branch 3f\n"
+        "1:\n\t"
+        "v_cmp_eq_u64 vcc, %[cur], %[k]\n"
+        "3:\n\t"
         "s_mov_b64 exec, vcc\n\t"
         "ds_add_u32 %[ca], %[one]\n\t"
-        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"               // (scc: lanes left)
         "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_and_b32 %[h], %[mask], %[h]\n\t"
         "s_sub_u32 %[p], %[p], 1\n\t"
         "s_cmp_lg_u32 %[p], 0\n\t"
         "s_cbranch_scc1 0b\n"
@@ -159,6 +163,7 @@ __device__ __forceinline__ void agg_emit_bin(const AggArgs &a, const AggTask &t,
     for (int j = 0; j < PER; ++j) { mk[j] = s_key[tid * PER + j]; mc[j] = s_cnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
     u32 D;
     u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);      // (two barriers inside: all slots are read before any is rewritten)
+    D = (u32)__builtin_amdgcn_readfirstlane((int)D);        // (the same in every lane: loops and branches on it are the wave's, scalar)
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; ++o; }
     __syncthreads();
@@ -166,9 +171,15 @@ __device__ __forceinline__ void agg_emit_bin(const AggArgs &a, const AggTask &t,
     if (D <= (u32)AG_THREADS) {
         // rank by counting: keys are distinct, so ranks are a permutation; s_key[j] is a broadcast read
         u64 k = 0; u32 c = 0, r = 0;
-        if ((u32)tid < D) {
-            k = s_key[tid]; c = s_cnt[tid];
-            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
+        if ((u32)(tid & ~(WAVE - 1)) < D) {                // (whole waves: the loop below is scalar, lanes past D rank an empty key and drop it)
+            const bool mine = (u32)tid < D;
+            k = mine ? s_key[tid] : AG_EMPTY; c = mine ? s_cnt[tid] : 0;
+            u32 j = 0;
+            for (; j + 4 <= D; j += 4) {                   // four broadcast reads per step
+                const u64 k0 = s_key[j], k1 = s_key[j + 1], k2 = s_key[j + 2], k3 = s_key[j + 3];
+                r += (k0 < k ? 1u : 0u) + (k1 < k ? 1u : 0u) + (k2 < k ? 1u : 0u) + (k3 < k ? 1u : 0u);
+            }
+            for (; j < D; ++j) r += s_key[j] < k;
         }
         __syncthreads();
         if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; }
@@ -291,21 +302,9 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
-#ifndef HSK_AGG_NOASM
             const u64 act = __ballot(k[u] != AG_EMPTY);
-            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, agg_slot<LOG2CAP>(k[u]), k[u]) != 0) s_ovf = 1;      // (uniform)
-#else
-            if (k[u] == AG_EMPTY) continue;
             u32 h = agg_slot<LOG2CAP>(k[u]);
-            bool done = false;
-            for (int p = 0; p < AG_MAX_PROBE; ++p) {
-                u64 cur = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_key[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
-                if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_cnt[h], 1u); done = true; break; }
-                h = (h + 1) & (CAP - 1);
-            }
-            if (!done) s_ovf = 1;
-#endif
+            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u]) != 0) s_ovf = 1;      // (uniform)
         }
         // a bin with more distinct keys than the table takes (a probe sequence ran past AG_MAX_PROBE slots: with linear probing
         // that starts at a load of ~0.8) gives up here instead of grinding through the rest of its records
@@ -472,8 +471,12 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 // pos/rid, reference src/kmerops.cpp:1430-1437).  Two sweeps over the bin instead of ordering its records:
 //   1. count the distinct keys in the LDS table (as above), order them, prefix-sum the counts in key order:
 //      group g of the bin starts at record offset goff[g] of the bin's range;
-//   2. read the records again (they are in L2), find each record's group through the table and give it the next free
-//      place of the group (LDS atomic): pos / rid are written straight to their final arrays.  The order of the
+//   2. every record's place is goff[group] + (records of its key counted before it).  Bins of up to 4096 records -- all
+//      but the outliers -- keep {slot, earlier records} of every record in registers from the first sweep (the returning
+//      add of the count), so the second sweep is one pass over the payloads: they go to their places in an LDS stage,
+//      window by window, and leave as contiguous pos / rid stores (scattered 4-byte stores straight to the arrays cost
+//      74 of this kernel's 117 ms per benchmark step).  Larger bins read their records again, find the group through
+//      the table, take the next free place of the group with an LDS atomic and store directly.  The order of the
 //      payloads inside one k-mer is free (the reference's sorts are not stable either).
 // Entries {key, count} and their payload offsets go to per-bin slots and are compacted afterwards.
 // ------------------------------------------------------------------------------------------------------------
@@ -486,6 +489,9 @@ struct AggExtTask {
     u32 *pos; int32_t *rid;        // [n] payloads grouped by key, bins in order
     u64 payoff_add;                // offset of this task's payload range in the rank's payload arrays
     u32 *flags;
+    // the table ladder bin by bin, as in AggTask: bins that overflow this launch's table are listed for the next one
+    const u32 *bin_list; const u32 *bin_list_n;
+    u32 *ovf_list; u32 *ovf_n;
 };
 struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; };
 
@@ -508,50 +514,70 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
 {
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
+    constexpr int UNR = 16, NBAT = 2, REGS = UNR * NBAT;  // records per lane whose slots stay in registers: bins of up to 8192 records
+                                                          // (the bins of prefixes that start with A hold twice the average: canonical k-mers)
+    constexpr u32 STAGE = (u32)CAP * 14u / 8u;            // payloads per window of the stage
     __shared__ u64 s_tkey[CAP];     // the table: stays as it is for the second sweep
-    __shared__ u32 s_tcnt[CAP];
-    __shared__ u16 s_trank[CAP];    // slot -> index of its key in key order
-    __shared__ u64 s_key[CAP];      // distinct keys compacted, then in key order
-    __shared__ u32 s_cnt[CAP];
-    __shared__ u16 s_slot[CAP];     // origin slot of s_key[i]
-    __shared__ u32 s_goff[CAP];     // first record of group i inside the bin
-    __shared__ u32 s_cur[CAP];      // next free place of group i
+    __shared__ u32 s_soff[CAP];     // slot -> first record (inside the bin) of the group of the slot's key
+    __shared__ u32 s_tcnt[CAP];     // records per slot; the second sweep counts them down again: a record's place inside its group
+    // 14 bytes per slot: the distinct keys compacted / ordered with their counts and origin slots; once the entries are
+    // written, the payload stage
+    __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
+    u64 *s_key = s_raw;
+    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + CAP);
+    u16 *s_slot = reinterpret_cast<u16 *>(s_cnt + CAP);
     const AggExtTask &t = a.t[blockIdx.y];
     if (!t.active) return;
-    const u32 b = blockIdx.x;
+    u32 b = blockIdx.x;
+    if (t.bin_list) { if (b >= *t.bin_list_n || b >= a.nbins) return; b = t.bin_list[b]; if (b >= a.nbins) return; }
     const int tid = threadIdx.x;
     const u64 s = t.bounds[b], e = t.bounds[b + 1];
     if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+    const bool in_regs = e - s <= (u64)AG_THREADS * REGS;              // (uniform)
+    const u32 nrec = in_regs ? (u32)(e - s) : 0u;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) { s_tkey[j * AG_THREADS + tid] = AG_EMPTY; s_tcnt[j * AG_THREADS + tid] = 0; s_cur[j * AG_THREADS + tid] = 0; }
+    for (int j = 0; j < PER; ++j) { s_tkey[j * AG_THREADS + tid] = AG_EMPTY; s_tcnt[j * AG_THREADS + tid] = 0; }
     if (tid == 0) s_ovf = 0;
     __syncthreads();
 
     // ---- 1. first sweep: count ----------------------------------------------------------------------------------
-    constexpr int UNR = 8;
-    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_tkey, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_tcnt;
+    u32 where[REGS];                                      // in_regs: the slot every record of this lane was counted in
+#pragma unroll
+    for (int u = 0; u < REGS; ++u) where[u] = 0;
+    auto count_batch = [&](u64 i, u32 *wh) {
         u64 k[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            if (k[u] == AG_EMPTY) continue;
+            const u64 act = __ballot(k[u] != AG_EMPTY);
+            if (act == 0) continue;                       // (uniform)
             u32 h = agg_slot<LOG2CAP>(k[u]);
-            bool done = false;
-            for (int p = 0; p < AG_MAX_PROBE; ++p) {
-                u64 cur = __hip_atomic_load(&s_tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_tkey[h], (unsigned long long)AG_EMPTY, (unsigned long long)k[u]);
-                if (cur == AG_EMPTY || cur == k[u]) { atomicAdd(&s_tcnt[h], 1u); done = true; break; }
-                h = (h + 1) & (CAP - 1);
-            }
-            if (!done) s_ovf = 1;
+            if (agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u]) != 0) s_ovf = 1;
+            if (wh) wh[u] = h;
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int bt_ = 0; bt_ < NBAT; ++bt_)
+            if (s + (u64)bt_ * AG_THREADS * UNR < e) count_batch(s + tid + (u64)bt_ * AG_THREADS * UNR, where + bt_ * UNR);      // (uniform)
+    } else {
+        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+            count_batch(i, nullptr);
+            if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
     }
     __syncthreads();
     if (s_ovf) {
-        if (tid == 0) { atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); t.bin_cnt[b] = 0; }
+        if (tid == 0) {
+            if (t.ovf_list) { const u32 at = atomicAdd(t.ovf_n, 1u); if (at < a.nbins) t.ovf_list[at] = b; else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); }
+            else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW);
+            t.bin_cnt[b] = 0;
+        }
         return;
     }
 
@@ -559,17 +585,16 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     u32 D;
     {
         u32 occ = 0;
+        u64 mk[PER]; u32 mc[PER];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) occ += s_tkey[tid * PER + j] != AG_EMPTY;
-        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+        for (int j = 0; j < PER; ++j) { mk[j] = s_tkey[tid * PER + j]; mc[j] = s_tcnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
+        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);             // (barriers inside: the counts are in registers before s_cnt / s_slot are written)
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const u32 sl = tid * PER + j;
-            const u64 kk = s_tkey[sl];
-            if (kk != AG_EMPTY) { s_key[o] = kk; s_cnt[o] = s_tcnt[sl]; s_slot[o] = (u16)sl; ++o; }
-        }
+        for (int j = 0; j < PER; ++j)
+            if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; s_slot[o] = (u16)(tid * PER + j); ++o; }
     }
     __syncthreads();
+    D = (u32)__builtin_amdgcn_readfirstlane((int)D);
     if (D <= (u32)AG_THREADS) {
         u64 k = 0; u32 c = 0, r = 0; u16 sl = 0;
         if ((u32)tid < D) {
@@ -600,7 +625,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
             }
         }
     }
-    u32 kept = 0;
+    u32 kept = 0, gof[PER];
     {
         u32 csum = 0, cv[PER];
 #pragma unroll
@@ -614,12 +639,13 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const u32 i = tid * PER + j;
-            if (i < D) { s_goff[i] = go; s_trank[s_slot[i]] = (u16)i; }
+            gof[j] = go;
+            if (i < D) s_soff[s_slot[i]] = go;
             go += cv[j];
         }
     }
     u32 tot;
-    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);      // (barriers inside: s_goff / s_trank are complete for the second sweep)
+    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);      // (barriers inside: s_soff is complete for the second sweep)
     {
         const u64 slot0 = (s >> t.slot_shift) + w;
         u64 *de = t.scratch_e + slot0 * 2; u64 *dp = t.scratch_p + slot0;
@@ -628,25 +654,52 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
             const u32 i = tid * PER + j;
             if (i < D) {
                 const u32 c = s_cnt[i];
-                if (c >= a.lower && c <= a.upper) { de[0] = s_key[i]; de[1] = (u64)c; dp[0] = t.payoff_add + s + s_goff[i]; de += 2; ++dp; }
+                if (c >= a.lower && c <= a.upper) { de[0] = s_key[i]; de[1] = (u64)c; dp[0] = t.payoff_add + s + gof[j]; de += 2; ++dp; }
             }
         }
     }
     if (tid == 0) t.bin_cnt[b] = tot;
+    __syncthreads();                                                // the ordered keys and counts have been read: s_raw is free
 
-    // ---- 3. second sweep: every record to the next free place of its group -----------------------------------------
-    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
-        u64 k[UNR], v[UNR];
+    // ---- 3. second sweep: every payload to its place ---------------------------------------------------------------
+    if (in_regs) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; const bool ok = idx < e; k[u] = ok ? t.keys[idx] : AG_EMPTY; v[u] = ok ? t.vals[idx] : 0; }
+        for (int u = 0; u < REGS; ++u) {                  // where[u] becomes the record's place in the bin (inside a group in any order)
+            const u32 r = (u32)tid + (u32)u * AG_THREADS;
+            where[u] = r < nrec ? s_soff[where[u]] + atomicSub(&s_tcnt[where[u]], 1u) - 1u : ~0u;
+        }
+        for (u32 w0 = 0; w0 < nrec; w0 += STAGE) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (k[u] == AG_EMPTY) continue;
-            u32 h = agg_slot<LOG2CAP>(k[u]);
-            while (s_tkey[h] != k[u]) h = (h + 1) & (CAP - 1);             // present: the first sweep put it there
-            const u32 g = s_trank[h];
-            const u64 o = s + s_goff[g] + atomicAdd(&s_cur[g], 1u);
-            t.pos[o] = (u32)v[u]; t.rid[o] = (int32_t)(v[u] >> 32);
+            for (int bt_ = 0; bt_ < NBAT; ++bt_) {
+                if ((u32)bt_ * AG_THREADS * UNR >= nrec) continue;                                  // (uniform)
+                u64 v[UNR];                                // (read again for every window: the bin's payloads stay in L2)
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { const u32 r = (u32)tid + (u32)(bt_ * UNR + u) * AG_THREADS; v[u] = t.vals[s + (r < nrec ? r : 0u)]; }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { const u32 o = where[bt_ * UNR + u]; if (o - w0 < STAGE) s_raw[o - w0] = v[u]; }      // (places before the window wrap to huge values, ~0 stays out of every window)
+            }
+            __syncthreads();
+            const u32 n = nrec - w0 < STAGE ? nrec - w0 : STAGE;
+            for (u32 i = tid; i < n; i += AG_THREADS) {
+                const u64 x = s_raw[i];
+                t.pos[s + w0 + i] = (u32)x; t.rid[s + w0 + i] = (int32_t)(x >> 32);
+            }
+            __syncthreads();
+        }
+    } else {
+        constexpr int UNR2 = 8;
+        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR2) {
+            u64 k[UNR2], v[UNR2];
+#pragma unroll
+            for (int u = 0; u < UNR2; ++u) { const u64 idx = i + (u64)u * AG_THREADS; const bool ok = idx < e; k[u] = ok ? t.keys[idx] : AG_EMPTY; v[u] = ok ? t.vals[idx] : 0; }
+#pragma unroll
+            for (int u = 0; u < UNR2; ++u) {
+                if (k[u] == AG_EMPTY) continue;
+                u32 h = agg_slot<LOG2CAP>(k[u]);
+                while (s_tkey[h] != k[u]) h = (h + 1) & (CAP - 1);             // present: the first sweep put it there
+                const u64 o = s + s_soff[h] + atomicSub(&s_tcnt[h], 1u) - 1u;
+                t.pos[o] = (u32)v[u]; t.rid[o] = (int32_t)(v[u] >> 32);
+            }
         }
     }
 }

@@ -450,35 +450,46 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         t.pos = outs[i].pos; t.rid = outs[i].rid;
         sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].bin_off = t.bin_cnt; sa.t[i].active = 1;       // (in place: this path scans once)
     }
-    struct { u32 flags[AG_BATCH]; u64 total[AG_BATCH]; } h;
-    auto run = [&](int log2cap) -> int {
-        for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
+    // The table ladder, bin by bin (as agg_stage1 / agg_stage2 do for keys without payload: nearly every task has a few outlier
+    // bins, a task-wide retry would run everything on the large table's one workgroup per CU): the small table over all bins,
+    // the bins it could not hold listed; the large table over the listed bins; a bin beyond that sends its task the long way.
+    u32 *d_list; DALLOC(c, d_list, u32 *, (size_t)nbins * 4 * AG_BATCH);
+    struct { u32 flags[2 * AG_BATCH]; u64 total[AG_BATCH]; } h;
+    auto launch = [&](int log2cap, u32 grid_x) {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
-        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(nbins, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-        hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
-        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hsk_sync(c, c->stream));
-        return HSK_OK;
     };
     memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_ext_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    int rc = run(AG_LOG2CAP_SMALL); if (rc) return rc;
-    bool retry = false, done[AG_BATCH];
-    u64 total[AG_BATCH];
-    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; if (!done[i]) retry = true; }
-    if (retry) {
+    for (int i = 0; i < AG_BATCH; ++i) { a.t[i].ovf_list = d_list + (size_t)nbins * i; a.t[i].ovf_n = d_flags + AG_BATCH + i; }
+    launch(AG_LOG2CAP_SMALL, nbins);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
+    u32 longest = 0;
+    for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) longest = std::max(longest, std::min(h.flags[AG_BATCH + i], nbins));
+    if (longest) {
         AggExtArgs keep = a;
-        for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && !done[i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
-        HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
-        memset(&h, 0, sizeof h);
-        rc = run(AG_LOG2CAP_LARGE); if (rc) return rc;
-        for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) { done[i] = !h.flags[i]; total[i] = h.total[i]; }
+        for (int i = 0; i < AG_BATCH; ++i) {
+            AggExtTask &t = a.t[i];
+            t.active = (keep.t[i].active && h.flags[AG_BATCH + i]) ? 1 : 0; c->stats.agg_retried_tasks += t.active;
+            t.bin_list = t.ovf_list; t.bin_list_n = t.ovf_n; t.ovf_list = nullptr; t.ovf_n = nullptr;
+        }
+        launch(AG_LOG2CAP_LARGE, longest);
         a = keep;
     }
+    for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
+    hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) HIPCHK(c, hipMemcpyAsync(&h.total[i], a.t[i].bin_cnt + nbins, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
+    int rc = HSK_OK;
+    bool done[AG_BATCH];
+    u64 total[AG_BATCH];
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; }
     AggExtCompactArgs ca; memset(&ca, 0, sizeof ca);
     ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
     bool any = false;
@@ -513,6 +524,6 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hsk_sync(c, c->stream));
     for (int i = 0; i < AG_BATCH; ++i) if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); }
-    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags);
+    c->pool.release(d_bounds); c->pool.release(d_cnt); c->pool.release(d_flags); c->pool.release(d_list);
     return rc;
 }
