@@ -334,6 +334,78 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 // ~0 is no valid word 0: a canonical k-mer that starts with 32 T needs a reverse complement that starts with 32 T
 // too, i.e. a k-mer whose last 32 bases are A, impossible for K < 64 next to 32 leading T.
 // ------------------------------------------------------------------------------------------------------------
+// agg_count_keys for two-word keys: a slot is claimed on word 1 (compare-and-swap), the claimer publishes word 0 and counts
+// itself; a lane that finds its word 1 in the slot reads word 0 until it is there (claimers of the same wave have issued
+// their store before -- the LDS executes a wave's operations in order --, claimers of other waves never wait for anything
+// between the claim and the store) and counts itself if it is its own.  Returns the lanes that ran out of probes; timed_out:
+// a word 0 never appeared (cannot happen; the bin is then redone on the next rung like an overflowing one).
+template <u32 MASK>
+__device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base, u32 cnt_base, u32 h, u64 w1, u64 w0, u32 &timed_out)
+{
+    u64 save, cur, v;
+    u32 ka1, ka0, ca, p, spin, tmo = 0;
+    const u64 empty = AG_EMPTY;
+    const u32 one = 1u;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_movk_i32 %[p], %[maxp]\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "0:\n\t"
+        "v_lshl_add_u32 %[ka1], %[h], 3, %[k1b]\n\t"
+        "ds_read_b64 %[cur], %[ka1]\n\t"
+        "v_lshl_add_u32 %[ka0], %[h], 3, %[k0b]\n\t"
+        "v_lshl_add_u32 %[ca], %[h], 2, %[cb]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
+        "s_cbranch_vccz 1f\n\t"                               // no empty slot among the lanes
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_cmpst_rtn_b64 %[cur], %[ka1], %[emp], %[w1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"                    // claimed: publish word 0, count
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b64 %[ka0], %[w0]\n\t"
+        "ds_add_u32 %[ca], %[one]\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "1:\n\t"
+        "v_cmp_eq_u64 vcc, %[cur], %[w1]\n\t"                 // word 1 is there: is word 0 mine?
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "s_movk_i32 %[spin], 0x7fff\n"
+        "5:\n\t"
+        "ds_read_b64 %[v], %[ka0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[v]\n\t"                      // not published yet
+        "s_cbranch_vccz 6f\n\t"
+        "s_sub_u32 %[spin], %[spin], 1\n\t"
+        "s_cmp_lg_u32 %[spin], 0\n\t"
+        "s_cbranch_scc1 5b\n\t"
+        "s_mov_b32 %[tmo], 1\n"
+        "6:\n\t"
+        "v_cmp_eq_u64 vcc, %[v], %[w0]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[ca], %[one]\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "4:\n\t"
+        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_and_b32 %[h], %[mask], %[h]\n\t"
+        "s_sub_u32 %[p], %[p], 1\n\t"
+        "s_cmp_lg_u32 %[p], 0\n\t"
+        "s_cbranch_scc1 0b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [act] "+s"(act), [h] "+v"(h), [tmo] "+s"(tmo), [save] "=&s"(save), [p] "=&s"(p), [spin] "=&s"(spin),
+          [cur] "=&v"(cur), [v] "=&v"(v), [ka1] "=&v"(ka1), [ka0] "=&v"(ka0), [ca] "=&v"(ca)
+        : [k1b] "s"(k1_base), [k0b] "s"(k0_base), [cb] "s"(cnt_base), [w1] "v"(w1), [w0] "v"(w0), [emp] "v"(empty), [one] "v"(one),
+          [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE)
+        : "vcc", "scc", "memory");
+    timed_out |= tmo;
+    return act;
+}
+
 __device__ __forceinline__ bool key2_less(u64 a1, u64 a0, u64 b1, u64 b0) { return a1 < b1 || (a1 == b1 && a0 < b0); }
 
 template <int LOG2CAP>
@@ -359,6 +431,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     __syncthreads();
 
     constexpr int UNR = 8;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
     const ulonglong2 *recs = reinterpret_cast<const ulonglong2 *>(t.keys);       // {word 0, word 1}
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
         ulonglong2 k[UNR];
@@ -367,33 +441,14 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const u64 w0 = k[u].x, w1 = k[u].y;
-            if (w1 == AG_EMPTY) continue;
+            const u64 act = __ballot(w1 != AG_EMPTY);
+            if (act == 0) continue;                       // (uniform)
             const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
             const u32 x = (u32)(m >> 32) ^ (u32)m;
-            u32 h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
-            bool done = false;
-            for (int p = 0; p < AG_MAX_PROBE && !done; ++p) {
-                u64 cur = __hip_atomic_load(&s_k1[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == AG_EMPTY) cur = atomicCAS((unsigned long long *)&s_k1[h], (unsigned long long)AG_EMPTY, (unsigned long long)w1);
-                const bool claimed = cur == AG_EMPTY;
-                if (claimed) {                                   // publish word 0 (before any lane of this wave starts to wait)
-                    __hip_atomic_store(&s_k0[h], w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    atomicAdd(&s_cnt[h], 1u); done = true;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                if (!claimed && cur == w1) {
-                    u64 v = AG_EMPTY;
-                    for (u32 spin = 0; spin < (1u << 22); ++spin) {
-                        v = __hip_atomic_load(&s_k0[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (v != AG_EMPTY) break;
-                    }
-                    if (v == AG_EMPTY) { s_ovf = 1; done = true; }          // (never: the claimer does not wait for anyone)
-                    else if (v == w0) { atomicAdd(&s_cnt[h], 1u); done = true; }
-                }
-                h = (h + 1) & (CAP - 1);
-            }
-            if (!done) s_ovf = 1;
+            u32 tmo = 0;
+            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, (x * 0x9E3779B1u) >> (32 - LOG2CAP), w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
         }
+        if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
     __syncthreads();
     if (s_ovf) {
