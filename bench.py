@@ -323,11 +323,11 @@ def main():
             return d
         kernels = [
             kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
-                 "minimizer hashes + supermer records: ~108 VALU instructions per base position, 70 of them MurmurHash3; algorithmic bytes = packed reads + 4-byte supermer records"),
+                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: ~90 VALU instructions per base position, 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records"),
             kern("expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins"),
             kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
-            kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"], "lds-issue", "per-prefix-bin LDS hash aggregation: reads every record once; bound by divergent LDS probes, not by HBM"),
+            kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"], "lds-issue", "per-prefix-bin LDS hash aggregation: reads every record once; bound by instruction issue around the LDS probes (scalar unit + LDS queue; the probe loop is hand-written assembly for that reason), not by HBM"),
             kern("place_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 13.0, "hbm-scattered",
                  "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
         ]
