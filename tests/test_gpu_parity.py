@@ -630,6 +630,7 @@ def test_extension_grouping_aggregation(H, O, L, U):
     pre = "ACGTTGCAAGGCTTAACCGG"
     seqs += [pre + "".join(rng.choice(list("ACGT"), 40)) for _ in range(2500)]
     seqs += ["AC" * 75] * 30 + [("ACGGTCATTGCA" * 13)[:150]] * 200
+    seqs += ["A" * 150] * 100                      # one bin of 12 000 records: more than the second sweep keeps in registers (8192)
     dna = H.DnaBuffer.from_sequences(seqs)
     packed, off, lens = dna.arrays()
     ores = O.count(packed, off, lens, k=31, m=17, L=L, U=U, ext=1, ntasks=16, rid_base=1000, fast=True)
