@@ -323,7 +323,7 @@ def main():
             return d
         kernels = [
             kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
-                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: ~90 VALU instructions per base position, 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records"),
+                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: 97 VALU instructions per base position by the SQ counters (116 at the start of round 2), 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records"),
             kern("expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins"),
             kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
