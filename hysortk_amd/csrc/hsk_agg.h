@@ -571,18 +571,19 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     constexpr int PER = CAP / AG_THREADS;
     constexpr int UNR = 16, NBAT = 2, REGS = UNR * NBAT;  // records per lane whose slots stay in registers: bins of up to 8192 records
                                                           // (the bins of prefixes that start with A hold twice the average: canonical k-mers)
-    constexpr u32 STAGE = (u32)CAP * 14u / 8u;            // payloads per window of the stage
-    __shared__ u64 s_tkey[CAP];     // the table: stays as it is for the second sweep
+    constexpr u32 STAGE = (u32)CAP * 22u / 8u;            // payloads per window of the stage
     __shared__ u32 s_soff[CAP];     // slot -> first record (inside the bin) of the group of the slot's key
     __shared__ u32 s_tcnt[CAP];     // records per slot; the second sweep counts them down again: a record's place inside its group
-    // 14 bytes per slot: the distinct keys compacted / ordered with their counts and origin slots; once the entries are
-    // written, the payload stage
+    // 22 bytes per slot: the distinct keys compacted / ordered, their counts and origin slots, and the table's keys (needed
+    // again only by the second sweep of a bin too large for registers); for a bin in registers all of it is, once the entries
+    // are written, the payload stage
     __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
     u64 *s_key = s_raw;
     u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + CAP);
     u16 *s_slot = reinterpret_cast<u16 *>(s_cnt + CAP);
+    u64 *s_tkey = s_raw + (size_t)CAP * 14 / 8;
     const AggExtTask &t = a.t[blockIdx.y];
     if (!t.active) return;
     u32 b = blockIdx.x;
