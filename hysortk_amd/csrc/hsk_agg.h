@@ -571,12 +571,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     constexpr int PER = CAP / AG_THREADS;
     constexpr int UNR = 16, NBAT = 2, REGS = UNR * NBAT;  // records per lane whose slots stay in registers: bins of up to 8192 records
                                                           // (the bins of prefixes that start with A hold twice the average: canonical k-mers)
-    constexpr u32 STAGE = (u32)CAP * 22u / 8u;            // payloads per window of the stage
-    __shared__ u32 s_soff[CAP];     // slot -> first record (inside the bin) of the group of the slot's key
-    __shared__ u32 s_tcnt[CAP];     // records per slot; the second sweep counts them down again: a record's place inside its group
-    // 22 bytes per slot: the distinct keys compacted / ordered, their counts and origin slots, and the table's keys (needed
-    // again only by the second sweep of a bin too large for registers); for a bin in registers all of it is, once the entries
-    // are written, the payload stage
+    constexpr u32 STAGE = (u32)CAP * 30u / 8u;            // payloads per window of the stage
+    // 30 bytes per slot, everything the kernel keeps per slot: the distinct keys compacted / ordered, their counts and origin
+    // slots; the table's keys (needed again only by the second sweep of a bin too large for registers); slot -> first record
+    // (inside the bin) of the group of the slot's key; records per slot (the second sweep counts them down again: a record's
+    // place inside its group).  For a bin in registers all of it is, once every record knows its place, the payload stage.
     __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
@@ -584,6 +583,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + CAP);
     u16 *s_slot = reinterpret_cast<u16 *>(s_cnt + CAP);
     u64 *s_tkey = s_raw + (size_t)CAP * 14 / 8;
+    u32 *s_soff = reinterpret_cast<u32 *>(s_tkey + CAP);
+    u32 *s_tcnt = s_soff + CAP;
     const AggExtTask &t = a.t[blockIdx.y];
     if (!t.active) return;
     u32 b = blockIdx.x;
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
             const u32 r = (u32)tid + (u32)u * AG_THREADS;
             where[u] = r < nrec ? s_soff[where[u]] + atomicSub(&s_tcnt[where[u]], 1u) - 1u : ~0u;
         }
+        __syncthreads();                                   // (the offsets and counts have been read: they are stage now)
         for (u32 w0 = 0; w0 < nrec; w0 += STAGE) {
 #pragma unroll
             for (int bt_ = 0; bt_ < NBAT; ++bt_) {
