@@ -521,6 +521,219 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Three-word keys (72 <= K <= 95: the most significant word carries at least the 16 prefix bits): the same plan as for two
+// words -- a slot is claimed with a compare-and-swap on the most significant word, then words 1 and 0 are stored --, but
+// "published" cannot be a marker value of word 0 any more (a canonical k-mer of 64 bases and more can begin with 32 T and
+// end with 32 A, so every value of word 0 occurs): the slot's COUNT is the flag.  The claimer stores the two words and
+// then counts itself (0 -> 1); a lane that finds its word 2 in a slot waits until the count is non-zero (the claimer never
+// waits for anything in between; the LDS executes a wave's operations in order) and compares words 1 and 0.  Word 2 holds
+// K - 64 <= 31 bases left-aligned, so ~0 is never a word 2 and marks the empty slot.  Records and entries: {word 0, word 1,
+// word 2[, count]}.  Before this kernel existed these keys took 20 full LSD passes over 24-byte records (K=77: 580 of 740 ms).
+// ------------------------------------------------------------------------------------------------------------
+// The probe loop of three-word keys (protocol above), a loop of the wave like agg_count_keys / agg2_count_keys.  In assembly
+// for the scalar unit's sake and because the ORDER matters: within one wave the claimers must have stored and counted before
+// the lanes that found their word 2 start to wait -- written as two `if` blocks the compiler is free to run the waiting lanes
+// first (it did: every waiter timed out).  Returns the lanes that ran out of probes; timed_out: a count never appeared.
+template <u32 MASK>
+__device__ __forceinline__ u64 agg3_count_keys(u64 act, u32 k2_base, u32 k1_base, u32 k0_base, u32 cnt_base, u32 h, u64 w2, u64 w1, u64 w0, u32 &timed_out)
+{
+    u64 save, t, cur, v1, v0;
+    u32 ka2, ka1, ka0, ca, cv, p, spin, tmo = 0;
+    const u64 empty = AG_EMPTY;
+    const u32 one = 1u;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_movk_i32 %[p], %[maxp]\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "0:\n\t"
+        "v_lshl_add_u32 %[ka2], %[h], 3, %[k2b]\n\t"
+        "ds_read_b64 %[cur], %[ka2]\n\t"
+        "v_lshl_add_u32 %[ka1], %[h], 3, %[k1b]\n\t"
+        "v_lshl_add_u32 %[ka0], %[h], 3, %[k0b]\n\t"
+        "v_lshl_add_u32 %[ca], %[h], 2, %[cb]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"
+        "s_cbranch_vccz 1f\n\t"                               // no empty slot among the lanes
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_cmpst_rtn_b64 %[cur], %[ka2], %[emp], %[w2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, -1, %[cur]\n\t"                    // claimed: words 1 and 0, then the count that publishes them
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b64 %[ka1], %[w1]\n\t"
+        "ds_write_b64 %[ka0], %[w0]\n\t"
+        "ds_add_u32 %[ca], %[one]\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "1:\n\t"
+        "v_cmp_eq_u64 vcc, %[cur], %[w2]\n\t"                 // word 2 is there: wait for the count, compare words 1 and 0
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "s_movk_i32 %[spin], 0x7fff\n"
+        "5:\n\t"
+        "ds_read_b32 %[cv], %[ca]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[cv]\n\t"                      // not published yet
+        "s_cbranch_vccz 6f\n\t"
+        "s_sub_u32 %[spin], %[spin], 1\n\t"
+        "s_cmp_lg_u32 %[spin], 0\n\t"
+        "s_cbranch_scc1 5b\n\t"
+        "s_mov_b32 %[tmo], 1\n"
+        "6:\n\t"
+        "ds_read_b64 %[v1], %[ka1]\n\t"
+        "ds_read_b64 %[v0], %[ka0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[v1], %[w1]\n\t"
+        "v_cmp_eq_u64 %[t], %[v0], %[w0]\n\t"
+        "s_and_b64 vcc, vcc, %[t]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[ca], %[one]\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[act]\n"
+        "4:\n\t"
+        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_and_b32 %[h], %[mask], %[h]\n\t"
+        "s_sub_u32 %[p], %[p], 1\n\t"
+        "s_cmp_lg_u32 %[p], 0\n\t"
+        "s_cbranch_scc1 0b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [act] "+s"(act), [h] "+v"(h), [tmo] "+s"(tmo), [save] "=&s"(save), [t] "=&s"(t), [p] "=&s"(p), [spin] "=&s"(spin),
+          [cur] "=&v"(cur), [v1] "=&v"(v1), [v0] "=&v"(v0), [cv] "=&v"(cv), [ka2] "=&v"(ka2), [ka1] "=&v"(ka1), [ka0] "=&v"(ka0), [ca] "=&v"(ca)
+        : [k2b] "s"(k2_base), [k1b] "s"(k1_base), [k0b] "s"(k0_base), [cb] "s"(cnt_base), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0),
+          [emp] "v"(empty), [one] "v"(one), [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE)
+        : "vcc", "scc", "memory");
+    timed_out |= tmo;
+    return act;
+}
+
+__device__ __forceinline__ bool key3_less(u64 a2, u64 a1, u64 a0, u64 b2, u64 b1, u64 b0)
+{
+    return a2 < b2 || (a2 == b2 && (a1 < b1 || (a1 == b1 && a0 < b0)));
+}
+
+template <int LOG2CAP>
+__global__ __launch_bounds__(AG_THREADS) void agg3_finish_kernel(AggArgs a)
+{
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    __shared__ u64 s_k2[CAP];
+    __shared__ u64 s_k1[CAP];
+    __shared__ u64 s_k0[CAP];
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_ovf;
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    u32 b;
+    if (!agg_pick_bin(t, a.nbins, b)) return;
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_k2[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    constexpr int UNR = 4;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 k2_lds = (u32)(uintptr_t)(LdsPtr)s_k2, k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
+    for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+        u64 k0[UNR], k1[UNR], k2[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const u64 idx = i + (u64)u * AG_THREADS;
+            const bool ok = idx < e;
+            k0[u] = ok ? t.keys[idx * 3] : 0; k1[u] = ok ? t.keys[idx * 3 + 1] : 0; k2[u] = ok ? t.keys[idx * 3 + 2] : AG_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const u64 w0 = k0[u], w1 = k1[u], w2 = k2[u];
+            const u64 act = __ballot(w2 != AG_EMPTY);
+            if (act == 0) continue;                       // (uniform)
+            const u64 m = w0 ^ (w1 >> 7) ^ (w1 << 23) ^ (w2 >> 9) ^ (w2 << 21);
+            const u32 x = (u32)(m >> 32) ^ (u32)m;
+            u32 tmo = 0;
+            if (agg3_count_keys<(u32)CAP - 1u>(act, k2_lds, k1_lds, k0_lds, cnt_lds, (x * 0x9E3779B1u) >> (32 - LOG2CAP), w2, w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
+        }
+        if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+    }
+    __syncthreads();
+    if (s_ovf) {
+        if (tid == 0) agg_bin_overflow(t, a.nbins, b, (u32)CAP);
+        return;
+    }
+
+    // ---- compact, order by (word 2, word 1, word 0) ------------------------------------------------------------------
+    u32 D;
+    {
+        u64 m2[PER], m1[PER], m0[PER]; u32 mc[PER];
+        u32 occ = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int sl = tid * PER + j;
+            m2[j] = s_k2[sl]; m1[j] = s_k1[sl]; m0[j] = s_k0[sl]; mc[j] = s_cnt[sl]; occ += m2[j] != AG_EMPTY;
+        }
+        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (m2[j] != AG_EMPTY) { s_k2[o] = m2[j]; s_k1[o] = m1[j]; s_k0[o] = m0[j]; s_cnt[o] = mc[j]; ++o; }
+    }
+    __syncthreads();
+    D = (u32)__builtin_amdgcn_readfirstlane((int)D);
+    if (D <= (u32)AG_THREADS) {
+        u64 k2 = 0, k1 = 0, k0 = 0; u32 c = 0, r = 0;
+        if ((u32)tid < D) {
+            k2 = s_k2[tid]; k1 = s_k1[tid]; k0 = s_k0[tid]; c = s_cnt[tid];
+            for (u32 j = 0; j < D; ++j) r += key3_less(s_k2[j], s_k1[j], s_k0[j], k2, k1, k0);
+        }
+        __syncthreads();
+        if ((u32)tid < D) { s_k2[r] = k2; s_k1[r] = k1; s_k0[r] = k0; s_cnt[r] = c; }
+        __syncthreads();
+    } else {
+        u32 P = 512; while (P < D) P <<= 1;
+        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_k2[i] = AG_EMPTY; s_k1[i] = AG_EMPTY; s_k0[i] = AG_EMPTY; s_cnt[i] = 0; }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < P; i += AG_THREADS) {
+                    const u32 q = i ^ j;
+                    if (q > i) {
+                        const u64 x2 = s_k2[i], x1 = s_k1[i], x0 = s_k0[i], y2 = s_k2[q], y1 = s_k1[q], y0 = s_k0[q];
+                        const bool up = (i & kk) == 0;
+                        if (key3_less(y2, y1, y0, x2, x1, x0) == up) {
+                            const u32 cx = s_cnt[i], cy = s_cnt[q];
+                            s_k2[i] = y2; s_k1[i] = y1; s_k0[i] = y0; s_cnt[i] = cy; s_k2[q] = x2; s_k1[q] = x1; s_k0[q] = x0; s_cnt[q] = cx;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- filter, entries {word 0, word 1, word 2, count} in key order to the bin's slots -----------------------------
+    u32 kept = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) { const u32 c = s_cnt[i]; kept += (c >= a.lower && c <= a.upper); }
+    }
+    u32 tot;
+    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);
+    u64 *dst = t.scratch + ((s >> t.slot_shift) + w) * 4;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid * PER + j;
+        if (i < D) {
+            const u32 c = s_cnt[i];
+            if (c >= a.lower && c <= a.upper) { dst[0] = s_k0[i]; dst[1] = s_k1[i]; dst[2] = s_k2[i]; dst[3] = (u64)c; dst += 4; }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // EXTENSION (every k-mer carries (PosInRead, ReadId)): the same 16-bit prefix bins, but the records must come out
 // GROUPED by key, because an entry owns a slice of the task's payload array (count_sorted_kmers copies the run's
 // pos/rid, reference src/kmerops.cpp:1430-1437).  Two sweeps over the bin instead of ordering its records:

@@ -232,7 +232,10 @@ static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const AggArgs &a = p.a;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = records; ep.bytes = records * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
-    if (NW == 2) {
+    if (NW == 3) {
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    } else if (NW == 2) {
         if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else
@@ -259,7 +262,7 @@ static int agg_launch_scan(hsk_ctx *c, AggPending &p)
 template <int NW>
 static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, int slot, AggPending &p)
 {
-    static_assert(NW <= 2, "the aggregating finish handles one- and two-word keys");
+    static_assert(NW <= 3, "the aggregating finish handles keys of one to three words");
     constexpr u32 EW = NW + 1;                          // words per entry
     p = AggPending();
     const u32 L = (u32)c->cfg.lower_freq;
@@ -298,7 +301,7 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     // slots, reads with ~1 % errors move to 2048 after their first batch); bins of 6144 records and more on average (tasks far
     // above 2^28 k-mers) start on the large table.  Two-word keys: small / large only.
     p.first_cap = p.big ? AG_LOG2CAP_SMALL : std::max(c->agg_first_cap, nmax / nbins >= 6144 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL);
-    if (NW == 2 && p.first_cap == AG_LOG2CAP_MEDIUM) p.first_cap = AG_LOG2CAP_LARGE;
+    if (NW >= 2 && p.first_cap == AG_LOG2CAP_MEDIUM) p.first_cap = AG_LOG2CAP_LARGE;
     int rc = agg_launch_rung<NW>(c, p, p.first_cap, nbins, p.ntot); if (rc) return rc;
     rc = agg_launch_scan(c, p); if (rc) return rc;
     p.ev = ev_get(c);
@@ -339,11 +342,11 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             u32 longest = 0; u64 nb = 0; for (int i = 0; i < AG_BATCH; ++i) { longest = std::max(longest, n_cur[i]); nb += n_cur[i]; }
             if (!longest) break;
             static const int max_rung = getenv("HSK_AGG_MAXRUNG") ? atoi(getenv("HSK_AGG_MAXRUNG")) : AG_LOG2CAP_HUGE;     // (tests: stop the ladder early, the listed bins' tasks take the long way)
-            int next = (NW == 2) ? (cap < AG_LOG2CAP_LARGE ? AG_LOG2CAP_LARGE : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
+            int next = (NW >= 2) ? (cap < AG_LOG2CAP_LARGE ? AG_LOG2CAP_LARGE : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
             if (next > max_rung) next = 0;
             if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
             cap = next;
-            const bool last = (NW == 2) || cap == AG_LOG2CAP_HUGE;
+            const bool last = (NW >= 2) || cap == AG_LOG2CAP_HUGE;
             HIPCHK(c, hipMemsetAsync(p.d_flags + (2 + (cur ^ 1)) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));
             for (int i = 0; i < AG_BATCH; ++i) {
                 AggTask &t = a.t[i];

@@ -271,7 +271,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool batch = batch_enabled && mine.size() >= (size_t)XCD_BATCH;
     const int nsets = batch ? XCD_BATCH : 1;
     // fused finish: one-word keys (aggregating or tile finish), two-word keys with K >= 40 (aggregating finish only)
-    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW == 2 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
+    const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW <= 3 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
     const bool agg = fused && agg_enabled();
     // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
     const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
@@ -404,7 +404,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     AggPending pend[2]; size_t pend_pos[2] = {0, 0};
     // second stage of the aggregating finish of the batch in slot sl: totals -> outputs -> compaction -> result copy
     auto finish_stage2 = [&](int sl, bool covered) -> int {
-        if constexpr (NW <= 2) {
+        if constexpr (NW <= 3) {
             TaskOut fo[XCD_BATCH];
             pt.begin(PH_COUNT);
             int rc = agg_stage2<NW>(c, pend[sl], d_histo, histo_len, fo, covered);
@@ -445,7 +445,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 pt.end(PH_COUNT);
             }
         } else if (agg) {
-            if constexpr (NW <= 2) {
+            if constexpr (NW <= 3) {
                 // the previous batch first: this batch's expand and scatter pass are queued behind its aggregation, so the
                 // wait for its totals does not idle the GPU, and its compaction (and result copy) starts one kernel earlier
                 // (stage 2 of the previous batch BEFORE this batch's stage 1 would start its result copy one kernel earlier, but a

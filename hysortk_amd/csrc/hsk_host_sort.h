@@ -35,11 +35,11 @@ static bool hybrid_enabled()
     static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
     return on;
 }
-// Two-word keys take the prefix plan when the aggregating finish follows and the most significant word carries at
-// least the 16 prefix bits (K >= 40)
+// Two- and three-word keys take the prefix plan when the aggregating finish follows and the most significant word carries at
+// least the 16 prefix bits (40 <= K < 64, 72 <= K <= 95)
 template <int NW> static bool prefix_plan_ok(int K, bool finish_follows)
 {
-    return hybrid_enabled() && (NW == 1 || (NW == 2 && finish_follows && K - 32 >= 8));
+    return hybrid_enabled() && (NW == 1 || (NW <= 3 && finish_follows && K - 32 * (NW - 1) >= 8));
 }
 
 // tasks of 2^30 keys and more use 64-bit look-back words; HSK_WIDE_LOOKBACK=1 forces them (tests: such tasks do not fit a test)

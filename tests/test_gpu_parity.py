@@ -619,6 +619,40 @@ def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
 
 
+@pytest.mark.parametrize("K,L,U", [(77, 1, 65535), (77, 2, 50), (72, 2, 50), (95, 1, 65535), (69, 2, 50)])
+def test_three_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
+    """64 < K <= 95: two scatter passes on the top 16 bits of the most significant word + aggregation of 192-bit keys in LDS
+    (slot claimed on word 2, words 1 and 0 published through the slot's count).  Variants that share the last bases (word 2 and
+    the bin) and differ in the first, variants that share the first, k-mers that begin with 32 T and end with 32 A (every value of
+    word 0 is a real one), repeats; K=69 (fewer than 16 prefix bits in word 2) takes the full-width passes."""
+    rng = np.random.default_rng(K)
+    g = "".join(rng.choice(list("ACGT"), 30000))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 4000)]
+    suffix = "".join(rng.choice(list("ACGT"), 100))
+    prefix = "".join(rng.choice(list("ACGT"), 100))
+    for v in range(1500):
+        reads.append("".join(rng.choice(list("ACGT"), 30)) + suffix)          # same last bases, different first
+        reads.append(prefix + "".join(rng.choice(list("ACGT"), 30)))          # same first bases, different last
+    reads += reads[-300:]
+    for v in range(200):
+        reads.append("T" * 32 + "".join(rng.choice(list("ACGT"), K - 64 + 10)) + "A" * 32)
+    reads += ["AC" * 75] * 40 + ["A" * 150] * 20
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=17, L=L, U=U, ntasks=16, fast=True)
+    with H.Context(K=K, M=17, L=L, U=U, ntasks=16) as c:
+        res = c.count(dna)
+        st = c.stats()
+    if K >= 72:
+        assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
+    else:
+        assert st["fused_tasks"] == 0, st
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+
+
 @pytest.mark.parametrize("L,U", [(1, 65535), (2, 40)])
 def test_extension_grouping_aggregation(H, O, L, U):
     """EXTENSION=1 through the batch path (>= 8 tasks): two passes on the top 16 bits with the payload carried, then
