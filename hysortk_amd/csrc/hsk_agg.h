@@ -66,7 +66,15 @@ __device__ __forceinline__ void agg_bin_overflow(const AggTask &t, u32 nbins, u3
     atomicMax(t.flags + AG_BATCH, cap);
     t.bin_cnt[b] = 0;
 }
-struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
+struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
+// top_bits (multi-word keys): how many of the 16 prefix bits the most significant word holds (0 or 16: all); the rest are the top
+// bits of the word below
+__device__ __forceinline__ u32 agg_bin_of(const AggArgs &a, const u64 *rec)
+{
+    if (a.top_bits > 0 && a.top_bits < 16)
+        return ((u32)(rec[a.nw - 1] >> (64 - a.top_bits)) << (16 - a.top_bits)) | (u32)(rec[a.nw - 2] >> (48 + a.top_bits));
+    return (u32)(rec[a.nw - 1] >> a.shift);
+}
 
 // bounds[b] = index of the first key whose top bits are >= b (b = 0 .. AG_BINS); one thread per bound
 __global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(AG_THREADS) void bin_bounds_kernel(AggArgs a)
     if (b == a.nbins) lo = t.n;
     else while (lo < hi) {
         const u64 mid = lo + ((hi - lo) >> 1);
-        if ((u32)(t.keys[mid * a.nw + (a.nw - 1)] >> a.shift) < b) lo = mid + 1; else hi = mid;    // the most significant word
+        if (agg_bin_of(a, t.keys + mid * a.nw) < b) lo = mid + 1; else hi = mid;    // (the prefix sits in the most significant word, or continues in the one below)
     }
     t.bounds[b] = lo;
 }
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Three-word keys (72 <= K <= 95: the most significant word carries at least the 16 prefix bits): the same plan as for two
+// Three-word keys (64 < K <= 95): the same plan as for two
 // words -- a slot is claimed with a compare-and-swap on the most significant word, then words 1 and 0 are stored --, but
 // "published" cannot be a marker value of word 0 any more (a canonical k-mer of 64 bases and more can begin with 32 T and
 // end with 32 A, so every value of word 0 occurs): the slot's COUNT is the flag.  The claimer stores the two words and

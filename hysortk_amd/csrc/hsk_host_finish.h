@@ -281,6 +281,7 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     if (!p.big) for (int x = 0; x < 2; ++x) DALLOC(c, p.d_list[x], u32 *, (size_t)nbins * 4 * AG_BATCH);
     AggArgs &a = p.a; memset(&a, 0, sizeof a);
     a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
+    a.top_bits = (NW >= 2 && prefix_bits == 16) ? prefix_top_bits(K, NW) : 0;
     u64 nmax = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
         AggTask &t = a.t[i];

@@ -294,7 +294,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     static const bool xs_ext_enabled = !(getenv("HSK_FUSED_SCATTER_EXT") && atoi(getenv("HSK_FUSED_SCATTER_EXT")) == 0);
     static const bool xs_wide_enabled = !(getenv("HSK_FUSED_SCATTER_WIDE") && atoi(getenv("HSK_FUSED_SCATTER_WIDE")) == 0);      // two-word keys
     constexpr int XS_CH = XsCfg<(NW <= 2 ? NW : 1)>::CHUNK;
-    const bool xs = batch && (NW == 1 ? (!ext || xs_ext_enabled) : (NW == 2 && !ext && xs_wide_enabled)) && scatter_enabled() &&
+    const bool xs = batch && (NW == 1 ? (!ext || xs_ext_enabled) : (NW == 2 && !ext && xs_wide_enabled && prefix_top_bits(K, NW) == 16)) && scatter_enabled() &&
                     scatter_store_keys(max_task, XS_CH) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
     ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];

@@ -35,11 +35,24 @@ static bool hybrid_enabled()
     static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
     return on;
 }
-// Two- and three-word keys take the prefix plan when the aggregating finish follows and the most significant word carries at
-// least the 16 prefix bits (40 <= K < 64, 72 <= K <= 95)
+// Two- and three-word keys take the prefix plan when the aggregating finish follows.  Where the most significant word carries
+// fewer than the 16 prefix bits (K - 32 (NW - 1) < 8 bases), the prefix continues in the top bits of the word below it
+// (make_split_prefix_plan).
 template <int NW> static bool prefix_plan_ok(int K, bool finish_follows)
 {
-    return hybrid_enabled() && (NW == 1 || (NW <= 3 && finish_follows && K - 32 * (NW - 1) >= 8));
+    return hybrid_enabled() && (NW == 1 || (NW <= 3 && finish_follows));
+}
+// bits of the 16-bit prefix that the most significant word holds (16: all of them)
+static int prefix_top_bits(int K, int nw) { return std::min(16, 2 * (K - 32 * (nw - 1))); }
+// The 16-bit prefix of a key whose most significant word has only `top` < 16 significant bits: those, then the top 16 - top
+// bits of the word below.  LSD passes, least significant digit first, no digit across a word boundary or wider than 8 bits.
+static int make_split_prefix_plan(PassDesc *out, int top, int nw)
+{
+    int np = 0;
+    const int low = 16 - top;                            // bits taken from word nw - 2
+    for (int lo = 64 - low; lo < 64; ) { const int bits = std::min(8, 64 - lo); out[np++] = PassDesc{nw - 2, lo, bits}; lo += bits; }
+    for (int lo = 64 - top; lo < 64; ) { const int bits = std::min(8, 64 - lo); out[np++] = PassDesc{nw - 1, lo, bits}; lo += bits; }
+    return np;
 }
 
 // tasks of 2^30 keys and more use 64-bit look-back words; HSK_WIDE_LOOKBACK=1 forces them (tests: such tasks do not fit a test)
@@ -172,6 +185,7 @@ template <int NW>
 static int batch_pass_plan(hsk_ctx *c, int K, bool finish_follows, int prefix_bits, PassDesc *plan)
 {
     const bool hybrid = prefix_plan_ok<NW>(K, finish_follows);
+    if (hybrid && finish_follows && NW >= 2 && prefix_top_bits(K, NW) < 16 && prefix_bits == 16) return make_split_prefix_plan(plan, prefix_top_bits(K, NW), NW);
     return hybrid ? make_hybrid_plan(plan, finish_follows ? prefix_bits : 64 - HYBRID_SHIFT, NW - 1) : make_pass_plan(K, NW, c->cfg.radix_bits, plan);
 }
 

@@ -588,11 +588,11 @@ def test_fused_finish_equals_two_pass_path(H):
     assert int(outs[0][1]) > 100000
 
 
-@pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 50), (41, 2, 50), (63, 1, 65535), (35, 2, 50)])
+@pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 50), (41, 2, 50), (63, 1, 65535), (35, 2, 50), (33, 1, 65535), (36, 2, 50), (39, 2, 50)])
 def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     """32 < K < 64: two scatter passes on the top 16 bits of the most significant word + aggregation of 128-bit keys in LDS
     (slot claimed on word 1, word 0 published by the claimer).  Many k-mers here share word 1 and differ only in word 0
-    (variants of one 40-base suffix), others share word 0; K=35 (fewer than 16 prefix bits in word 1) takes the full-width passes."""
+    (variants of one 40-base suffix), others share word 0; K=35, 33, 39 (fewer than 16 prefix bits in word 1): the prefix continues in word 0."""
     rng = np.random.default_rng(K)
     g = "".join(rng.choice(list("ACGT"), 30000))
     reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 4000)]
@@ -609,22 +609,19 @@ def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     with H.Context(K=K, M=17, L=L, U=U, ntasks=16) as c:
         res = c.count(dna)
         st = c.stats()
-    if K >= 40:
-        assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
-    else:
-        assert st["fused_tasks"] == 0, st
+    assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
     assert np.array_equal(res.task_off, ores.task_off)
     assert np.array_equal(res.kmers, ores.keys)
     assert np.array_equal(res.cnt, ores.cnt)
     assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
 
 
-@pytest.mark.parametrize("K,L,U", [(77, 1, 65535), (77, 2, 50), (72, 2, 50), (95, 1, 65535), (69, 2, 50)])
+@pytest.mark.parametrize("K,L,U", [(77, 1, 65535), (77, 2, 50), (72, 2, 50), (95, 1, 65535), (69, 2, 50), (65, 1, 65535), (71, 2, 50)])
 def test_three_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     """64 < K <= 95: two scatter passes on the top 16 bits of the most significant word + aggregation of 192-bit keys in LDS
     (slot claimed on word 2, words 1 and 0 published through the slot's count).  Variants that share the last bases (word 2 and
     the bin) and differ in the first, variants that share the first, k-mers that begin with 32 T and end with 32 A (every value of
-    word 0 is a real one), repeats; K=69 (fewer than 16 prefix bits in word 2) takes the full-width passes."""
+    word 0 is a real one), repeats; K=69, 65, 71 (fewer than 16 prefix bits in word 2): the prefix continues in word 1."""
     rng = np.random.default_rng(K)
     g = "".join(rng.choice(list("ACGT"), 30000))
     reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 4000)]
@@ -643,10 +640,7 @@ def test_three_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     with H.Context(K=K, M=17, L=L, U=U, ntasks=16) as c:
         res = c.count(dna)
         st = c.stats()
-    if K >= 72:
-        assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
-    else:
-        assert st["fused_tasks"] == 0, st
+    assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
     assert np.array_equal(res.task_off, ores.task_off)
     assert np.array_equal(res.kmers, ores.keys)
     assert np.array_equal(res.cnt, ores.cnt)
