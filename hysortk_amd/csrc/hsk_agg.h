@@ -348,7 +348,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 // between the claim and the store) and counts itself if it is its own.  Returns the lanes that ran out of probes; timed_out:
 // a word 0 never appeared (cannot happen; the bin is then redone on the next rung like an overflowing one).
 template <u32 MASK>
-__device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base, u32 cnt_base, u32 h, u64 w1, u64 w0, u32 &timed_out)
+__device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base, u32 cnt_base, u32 &h, u64 w1, u64 w0, u32 &timed_out)
 {
     u64 save, cur, v;
     u32 ka1, ka0, ca, p, spin, tmo = 0;
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
             if (act == 0) continue;                       // (uniform)
             const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
             const u32 x = (u32)(m >> 32) ^ (u32)m;
-            u32 tmo = 0;
-            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, (x * 0x9E3779B1u) >> (32 - LOG2CAP), w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
+            u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
+            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
         }
         if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 // the lanes that found their word 2 start to wait -- written as two `if` blocks the compiler is free to run the waiting lanes
 // first (it did: every waiter timed out).  Returns the lanes that ran out of probes; timed_out: a count never appeared.
 template <u32 MASK>
-__device__ __forceinline__ u64 agg3_count_keys(u64 act, u32 k2_base, u32 k1_base, u32 k0_base, u32 cnt_base, u32 h, u64 w2, u64 w1, u64 w0, u32 &timed_out)
+__device__ __forceinline__ u64 agg3_count_keys(u64 act, u32 k2_base, u32 k1_base, u32 k0_base, u32 cnt_base, u32 &h, u64 w2, u64 w1, u64 w0, u32 &timed_out)
 {
     u64 save, t, cur, v1, v0;
     u32 ka2, ka1, ka0, ca, cv, p, spin, tmo = 0;
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg3_finish_kernel(AggArgs a)
             if (act == 0) continue;                       // (uniform)
             const u64 m = w0 ^ (w1 >> 7) ^ (w1 << 23) ^ (w2 >> 9) ^ (w2 << 21);
             const u32 x = (u32)(m >> 32) ^ (u32)m;
-            u32 tmo = 0;
-            if (agg3_count_keys<(u32)CAP - 1u>(act, k2_lds, k1_lds, k0_lds, cnt_lds, (x * 0x9E3779B1u) >> (32 - LOG2CAP), w2, w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
+            u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
+            if (agg3_count_keys<(u32)CAP - 1u>(act, k2_lds, k1_lds, k0_lds, cnt_lds, h, w2, w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
         }
         if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
@@ -769,7 +769,7 @@ struct AggExtTask {
     const u32 *bin_list; const u32 *bin_list_n;
     u32 *ovf_list; u32 *ovf_n;
 };
-struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; };
+struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; };     // nw, top_bits: as in AggArgs (nw = 0 reads as 1)
 
 __global__ __launch_bounds__(AG_THREADS) void bin_bounds_ext_kernel(AggExtArgs a)
 {
@@ -780,7 +780,11 @@ __global__ __launch_bounds__(AG_THREADS) void bin_bounds_ext_kernel(AggExtArgs a
     if (b == a.nbins) lo = t.n;
     else while (lo < hi) {
         const u64 mid = lo + ((hi - lo) >> 1);
-        if ((u32)(t.keys[mid] >> a.shift) < b) lo = mid + 1; else hi = mid;
+        const int nw = a.nw ? a.nw : 1;
+        const u64 *rec = t.keys + mid * nw;
+        const u32 bin = (a.top_bits > 0 && a.top_bits < 16) ? (((u32)(rec[nw - 1] >> (64 - a.top_bits)) << (16 - a.top_bits)) | (u32)(rec[nw - 2] >> (48 + a.top_bits)))
+                                                             : (u32)(rec[nw - 1] >> a.shift);
+        if (bin < b) lo = mid + 1; else hi = mid;
     }
     t.bounds[b] = lo;
 }
@@ -983,9 +987,266 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     }
 }
 
+// The same for keys of two and three words (K > 32 with EXTENSION; until round 2 these took 13 - 20 full LSD passes over
+// records of 24 - 32 bytes): the table and the ordered keys hold NW words per slot (14 + 16 NW bytes of LDS per slot: tables of 1024
+// and 2048 slots), slots are claimed with agg2_count_keys / agg3_count_keys, everything else is agg_ext_kernel's.  Records
+// {word 0 .. word NW-1}, entries {words, count}.
+template <int NW> __device__ __forceinline__ bool keyw_less(const u64 (&x)[NW], const u64 (&y)[NW])
+{
+#pragma unroll
+    for (int w = NW - 1; w > 0; --w) if (x[w] != y[w]) return x[w] < y[w];
+    return x[0] < y[0];
+}
+template <int LOG2CAP, int NW>
+__global__ __launch_bounds__(AG_THREADS) void aggw_ext_kernel(AggExtArgs a)
+{
+    static_assert(NW == 2 || NW == 3, "one-word keys: agg_ext_kernel");
+    constexpr int CAP = 1 << LOG2CAP;
+    constexpr int PER = CAP / AG_THREADS;
+    constexpr int UNR = 8, NBAT = 4, REGS = UNR * NBAT;
+    constexpr u32 STAGE = (u32)CAP * (14u + 16u * NW) / 8u;
+    __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_ovf;
+    // raw: [ordered keys NW x CAP x 8][counts CAP x 4][origin slots CAP x 2][table keys NW x CAP x 8][group offsets CAP x 4][table counts CAP x 4]
+    u64 *s_k = s_raw;                                                   // word w of entry i: s_k[w * CAP + i]
+    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + (size_t)NW * CAP);
+    u16 *s_slot = reinterpret_cast<u16 *>(s_cnt + CAP);
+    u64 *s_tk = reinterpret_cast<u64 *>(s_slot + CAP);                  // (CAP x 6 bytes behind 8-byte aligned data: CAP is a multiple of 4)
+    u32 *s_soff = reinterpret_cast<u32 *>(s_tk + (size_t)NW * CAP);
+    u32 *s_tcnt = s_soff + CAP;
+    const AggExtTask &t = a.t[blockIdx.y];
+    if (!t.active) return;
+    u32 b = blockIdx.x;
+    if (t.bin_list) { if (b >= *t.bin_list_n || b >= a.nbins) return; b = t.bin_list[b]; if (b >= a.nbins) return; }
+    const int tid = threadIdx.x;
+    const u64 s = t.bounds[b], e = t.bounds[b + 1];
+    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
+    const bool in_regs = e - s <= (u64)AG_THREADS * REGS;              // (uniform)
+    const u32 nrec = in_regs ? (u32)(e - s) : 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int sl = j * AG_THREADS + tid;
+        s_tk[(NW - 1) * CAP + sl] = AG_EMPTY; s_tcnt[sl] = 0;
+        if (NW == 2) s_tk[sl] = AG_EMPTY;                               // (two words: word 0 doubles as the publication flag, agg2_count_keys)
+    }
+    if (tid == 0) s_ovf = 0;
+    __syncthreads();
+
+    // ---- 1. first sweep: count ----------------------------------------------------------------------------------
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 tk_lds = (u32)(uintptr_t)(LdsPtr)s_tk, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_tcnt;
+    u32 where[REGS];
+#pragma unroll
+    for (int u = 0; u < REGS; ++u) where[u] = 0;
+    auto slot_of = [&](const u64 (&k)[NW]) -> u32 {
+        const u64 m = NW == 2 ? (k[0] ^ (k[1] >> 9) ^ (k[1] << 21)) : (k[0] ^ (k[1] >> 7) ^ (k[1] << 23) ^ (k[NW - 1] >> 9) ^ (k[NW - 1] << 21));
+        const u32 x = (u32)(m >> 32) ^ (u32)m;
+        return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
+    };
+    auto count_batch = [&](u64 i, u32 *wh) {
+        u64 k[UNR][NW];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const u64 idx = i + (u64)u * AG_THREADS;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) k[u][w] = idx < e ? t.keys[idx * NW + w] : (w == NW - 1 ? AG_EMPTY : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const u64 act = __ballot(k[u][NW - 1] != AG_EMPTY);
+            if (act == 0) continue;                       // (uniform)
+            u32 h = slot_of(k[u]), tmo = 0;
+            u64 left;
+            if (NW == 2) left = agg2_count_keys<(u32)CAP - 1u>(act, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][0], tmo);
+            else left = agg3_count_keys<(u32)CAP - 1u>(act, tk_lds + 2u * (u32)CAP * 8u, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][NW == 3 ? 1 : 0], k[u][0], tmo);
+            if (left != 0 || tmo) s_ovf = 1;
+            if (wh) wh[u] = h;
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int bt_ = 0; bt_ < NBAT; ++bt_)
+            if (s + (u64)bt_ * AG_THREADS * UNR < e) count_batch(s + tid + (u64)bt_ * AG_THREADS * UNR, where + bt_ * UNR);      // (uniform)
+    } else {
+        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+            count_batch(i, nullptr);
+            if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+    }
+    __syncthreads();
+    if (s_ovf) {
+        if (tid == 0) {
+            if (t.ovf_list) { const u32 at = atomicAdd(t.ovf_n, 1u); if (at < a.nbins) t.ovf_list[at] = b; else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); }
+            else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW);
+            t.bin_cnt[b] = 0;
+        }
+        return;
+    }
+
+    // ---- 2. distinct keys in key order, group offsets --------------------------------------------------------------
+    u32 D;
+    {
+        u32 occ = 0;
+        u64 mk[PER][NW]; u32 mc[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int sl = tid * PER + j;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mk[j][w] = s_tk[w * CAP + sl];
+            mc[j] = s_tcnt[sl]; occ += mk[j][NW - 1] != AG_EMPTY;
+        }
+        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (mk[j][NW - 1] != AG_EMPTY) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s_k[w * CAP + o] = mk[j][w];
+                s_cnt[o] = mc[j]; s_slot[o] = (u16)(tid * PER + j); ++o;
+            }
+    }
+    __syncthreads();
+    D = (u32)__builtin_amdgcn_readfirstlane((int)D);
+    if (D <= (u32)AG_THREADS) {
+        u64 k[NW]; u32 c = 0, r = 0; u16 sl = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = 0;
+        if ((u32)tid < D) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) k[w] = s_k[w * CAP + tid];
+            c = s_cnt[tid]; sl = s_slot[tid];
+            for (u32 j = 0; j < D; ++j) {
+                u64 o[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) o[w] = s_k[w * CAP + j];
+                r += keyw_less<NW>(o, k);
+            }
+        }
+        __syncthreads();
+        if ((u32)tid < D) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s_k[w * CAP + r] = k[w];
+            s_cnt[r] = c; s_slot[r] = sl;
+        }
+        __syncthreads();
+    } else {
+        u32 P = 512; while (P < D) P <<= 1;
+        for (u32 i = D + tid; i < P; i += AG_THREADS) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s_k[w * CAP + i] = AG_EMPTY;
+            s_cnt[i] = 0; s_slot[i] = 0;
+        }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < P; i += AG_THREADS) {
+                    const u32 q = i ^ j;
+                    if (q > i) {
+                        u64 x[NW], y[NW];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) { x[w] = s_k[w * CAP + i]; y[w] = s_k[w * CAP + q]; }
+                        const bool up = (i & kk) == 0;
+                        if (keyw_less<NW>(y, x) == up) {
+                            const u32 cx = s_cnt[i], cy = s_cnt[q]; const u16 sx = s_slot[i], sy = s_slot[q];
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) { s_k[w * CAP + i] = y[w]; s_k[w * CAP + q] = x[w]; }
+                            s_cnt[i] = cy; s_cnt[q] = cx; s_slot[i] = sy; s_slot[q] = sx;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    u32 kept = 0, gof[PER];
+    {
+        u32 csum = 0, cv[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            cv[j] = i < D ? s_cnt[i] : 0;
+            csum += cv[j];
+            kept += (i < D && cv[j] >= a.lower && cv[j] <= a.upper);
+        }
+        u32 go = block_excl_scan_256<u32>(csum, s_scr, nullptr);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            gof[j] = go;
+            if (i < D) s_soff[s_slot[i]] = go;
+            go += cv[j];
+        }
+    }
+    u32 tot;
+    const u32 w_ = block_excl_scan_256<u32>(kept, s_scr, &tot);
+    {
+        const u64 slot0 = (s >> t.slot_shift) + w_;
+        u64 *de = t.scratch_e + slot0 * (NW + 1); u64 *dp = t.scratch_p + slot0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid * PER + j;
+            if (i < D) {
+                const u32 c = s_cnt[i];
+                if (c >= a.lower && c <= a.upper) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) de[w] = s_k[w * CAP + i];
+                    de[NW] = (u64)c; dp[0] = t.payoff_add + s + gof[j]; de += NW + 1; ++dp;
+                }
+            }
+        }
+    }
+    if (tid == 0) t.bin_cnt[b] = tot;
+    __syncthreads();
+
+    // ---- 3. second sweep: every payload to its place ---------------------------------------------------------------
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < REGS; ++u) {
+            const u32 r = (u32)tid + (u32)u * AG_THREADS;
+            where[u] = r < nrec ? s_soff[where[u]] + atomicSub(&s_tcnt[where[u]], 1u) - 1u : ~0u;
+        }
+        __syncthreads();
+        for (u32 w0 = 0; w0 < nrec; w0 += STAGE) {
+#pragma unroll
+            for (int bt_ = 0; bt_ < NBAT; ++bt_) {
+                if ((u32)bt_ * AG_THREADS * UNR >= nrec) continue;                                  // (uniform)
+                u64 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { const u32 r = (u32)tid + (u32)(bt_ * UNR + u) * AG_THREADS; v[u] = t.vals[s + (r < nrec ? r : 0u)]; }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { const u32 o = where[bt_ * UNR + u]; if (o - w0 < STAGE) s_raw[o - w0] = v[u]; }
+            }
+            __syncthreads();
+            const u32 n = nrec - w0 < STAGE ? nrec - w0 : STAGE;
+            for (u32 i = tid; i < n; i += AG_THREADS) {
+                const u64 x = s_raw[i];
+                t.pos[s + w0 + i] = (u32)x; t.rid[s + w0 + i] = (int32_t)(x >> 32);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (u64 i = s + tid; i < e; i += AG_THREADS) {                 // (a bin too large for registers: every record looks its slot up again)
+            u64 k[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) k[w] = t.keys[i * NW + w];
+            const u64 v = t.vals[i];
+            u32 h = slot_of(k);
+            for (;;) {
+                bool same = true;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) same = same && s_tk[w * CAP + h] == k[w];
+                if (same) break;
+                h = (h + 1) & (CAP - 1);
+            }
+            const u64 o = s + s_soff[h] + atomicSub(&s_tcnt[h], 1u) - 1u;
+            t.pos[o] = (u32)v; t.rid[o] = (int32_t)(v >> 32);
+        }
+    }
+}
+
 // entries and payload offsets from the per-bin slots to their final places; count histogram.  One wave per bin.
 struct AggExtCompactArgs { const u64 *scratch_e[AG_BATCH]; const u64 *scratch_p[AG_BATCH]; const u64 *bounds[AG_BATCH]; const u64 *bin_off[AG_BATCH];
-                           u64 *entries[AG_BATCH]; u64 *payoff[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; };
+                           u64 *entries[AG_BATCH]; u64 *payoff[AG_BATCH]; u32 slot_shift; u64 *histo; u32 histo_len; u32 nbins; u32 ew; };     // ew: words per entry (0 reads as 2)
 __global__ __launch_bounds__(AG_THREADS) void agg_ext_compact_kernel(AggExtCompactArgs ca)
 {
     __shared__ u32 s_hist[AG_LDS_HIST];
@@ -1000,10 +1261,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_compact_kernel(AggExtCompa
         const u64 o = bin_off[b];
         const u64 cnt = bin_off[b + 1] - o;
         const u64 slot0 = bounds[b] >> ca.slot_shift;
-        for (u64 i = lane; i < cnt * 2; i += 64) {
-            const u64 v = se[slot0 * 2 + i];
-            entries[o * 2 + i] = v;
-            if (i & 1) {
+        const u64 ew = ca.ew ? ca.ew : 2;
+        for (u64 i = lane; i < cnt * ew; i += 64) {
+            const u64 v = se[slot0 * ew + i];
+            entries[o * ew + i] = v;
+            if (i % ew == ew - 1) {
                 if (v < (u64)AG_LDS_HIST) atomicAdd(&s_hist[(u32)v], 1u);
                 else if (v < ca.histo_len) atomicAdd((unsigned long long *)&ca.histo[v], 1ULL);
             }

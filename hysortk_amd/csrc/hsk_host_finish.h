@@ -418,8 +418,11 @@ static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 /*max_t
 // ---- EXTENSION: two passes + grouping aggregation (hsk_agg.h: agg_ext_kernel) ---------------------------------------
 // pay_before[i]: offset of task i's payload range in the rank's payload arrays (payload_off values are global over the
 // owned tasks in ascending id).
+template <int NW>
 static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u64 *pay_before, u64 *d_histo, u32 histo_len, TaskOut *outs)
 {
+    static_assert(NW <= 3, "keys of one to three words");
+    constexpr u32 EW = NW + 1;                          // words per entry
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const u32 L = (u32)c->cfg.lower_freq;
     const u32 slot_shift = L >= 2 ? 1 : 0;
@@ -432,8 +435,8 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
     AggExtArgs a; memset(&a, 0, sizeof a);
     AggArgs sa; memset(&sa, 0, sizeof sa);               // the view agg_scan_kernel needs
-    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT;
-    sa.nbins = nbins; sa.shift = AG_SHIFT; sa.nw = 1;
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT; a.nw = NW; a.top_bits = NW >= 2 ? prefix_top_bits(K, NW) : 0;
+    sa.nbins = nbins; sa.shift = AG_SHIFT; sa.nw = NW;
     bool own_scratch[AG_BATCH] = {false};
     u64 ntot = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
@@ -444,9 +447,9 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         u64 *other_v = (bt[i].out_v == bt[i].vA) ? bt[i].vB : bt[i].vA;
         t.keys = bt[i].out_k; t.vals = bt[i].out_v; t.n = bt[i].n; t.bounds = d_bounds + per * i; t.bin_cnt = d_cnt + per * i; t.flags = d_flags + i;
         t.slot_shift = slot_shift; t.active = 1; t.payoff_add = pay_before[i]; ntot += bt[i].n;
-        if (slot_shift) { t.scratch_e = other_k; t.scratch_p = other_v; }       // n / 2 entries of 16 + 8 bytes: the idle ping-pong buffers
+        if (slot_shift) { t.scratch_e = other_k; t.scratch_p = other_v; }       // n / 2 entries of 8 (NW + 1) + 8 bytes: the idle ping-pong buffers (8 NW + 8 bytes per record)
         else {
-            t.scratch_e = (u64 *)c->pool.alloc(bt[i].n * 16 + 64); t.scratch_p = (u64 *)c->pool.alloc(bt[i].n * 8 + 64); own_scratch[i] = true;
+            t.scratch_e = (u64 *)c->pool.alloc(bt[i].n * EW * 8 + 64); t.scratch_p = (u64 *)c->pool.alloc(bt[i].n * 8 + 64); own_scratch[i] = true;
             if (!t.scratch_e || !t.scratch_p) return fail(c, HSK_ERR_OOM, "finish scratch");
         }
         outs[i].npay = bt[i].n;
@@ -461,8 +464,13 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     struct { u32 flags[2 * AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto launch = [&](int log2cap, u32 grid_x) {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
-        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if constexpr (NW == 1) {
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        } else {                                            // (14 + 16 NW bytes of LDS per slot: the large table of multi-word keys has 2048 slots)
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((aggw_ext_kernel<AG_LOG2CAP_SMALL, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((aggw_ext_kernel<AG_LOG2CAP_MEDIUM, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        }
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     };
     memset(&h, 0, sizeof h);
@@ -495,14 +503,14 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     u64 total[AG_BATCH];
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; }
     AggExtCompactArgs ca; memset(&ca, 0, sizeof ca);
-    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins;
+    ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
     bool any = false;
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || !done[i]) continue;
         c->stats.fused_tasks++;
         outs[i].n = total[i];
         if (outs[i].n) {
-            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * 16); outs[i].payoff = (u64 *)c->pool.alloc(outs[i].n * 8);
+            outs[i].entries = (u64 *)c->pool.alloc(outs[i].n * EW * 8); outs[i].payoff = (u64 *)c->pool.alloc(outs[i].n * 8);
             if (!outs[i].entries || !outs[i].payoff) { rc = fail(c, HSK_ERR_OOM, "task output"); break; }
             ca.scratch_e[i] = a.t[i].scratch_e; ca.scratch_p[i] = a.t[i].scratch_p; ca.bounds[i] = a.t[i].bounds; ca.bin_off[i] = a.t[i].bin_cnt;
             ca.entries[i] = outs[i].entries; ca.payoff[i] = outs[i].payoff;
@@ -521,9 +529,9 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         SortScratch sc1; rc = alloc_sort_scratch(c, sc1); if (rc) break;
         u64 *cur = bt[i].out_k, *other = (cur == bt[i].kA) ? bt[i].kB : bt[i].kA, *sk, *sv;
         u64 *vcur = bt[i].out_v, *vother = (vcur == bt[i].vA) ? bt[i].vB : bt[i].vA;
-        rc = sort_task_device<1>(c, cur, other, vcur, vother, bt[i].n, K, sc1, &sk, &sv, false);
+        rc = sort_task_device<NW>(c, cur, other, vcur, vother, bt[i].n, K, sc1, &sk, &sv, false);
         free_sort_scratch(c, sc1);
-        if (rc == HSK_OK) rc = count_task_device<1>(c, sk, sv, bt[i].n, payadd, d_histo, histo_len, outs[i]);
+        if (rc == HSK_OK) rc = count_task_device<NW>(c, sk, sv, bt[i].n, payadd, d_histo, histo_len, outs[i]);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hsk_sync(c, c->stream));

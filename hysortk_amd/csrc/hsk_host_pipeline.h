@@ -274,7 +274,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const bool fused = !ext && finish_enabled() && (NW == 1 ? hybrid_enabled() : (NW <= 3 && agg_enabled() && prefix_plan_ok<NW>(K, true)));
     const bool agg = fused && agg_enabled();
     // EXTENSION with one-word keys: two passes on the top 16 bits (payload carried) + grouping aggregation
-    const bool fused_ext = ext && NW == 1 && hybrid_enabled() && finish_enabled() && agg_enabled();
+    const bool fused_ext = ext && NW <= 3 && hybrid_enabled() && finish_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
     // Two batches in flight on ONE stream (two sets of sort buffers): the host enqueues expand / scatter / aggregation of
     // batch b + 1 BEFORE it waits for the aggregation totals of batch b, sizes batch b's outputs and enqueues its
     // compaction.  The GPU therefore never runs dry while the host waits (HSK_LAG=0: one batch at a time, every wait drains
@@ -436,11 +436,11 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
         if (fused_ext) {
-            if constexpr (NW == 1) {
+            if constexpr (NW <= 3) {
                 pt.begin(PH_COUNT);
                 TaskOut fo[XCD_BATCH]; u64 pb[XCD_BATCH];
                 for (int i = 0; i < XCD_BATCH; ++i) pb[i] = mine[pos + i] != EMPTY_TASK ? pay_before[mine[pos + i]] : 0;
-                int rc = agg_ext_finish_batch_device(c, bt, K, pb, d_histo, histo_len, fo); if (rc) return rc;
+                int rc = agg_ext_finish_batch_device<NW>(c, bt, K, pb, d_histo, histo_len, fo); if (rc) return rc;
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
                 pt.end(PH_COUNT);
             }

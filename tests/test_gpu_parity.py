@@ -679,6 +679,39 @@ def test_extension_grouping_aggregation(H, O, L, U):
     assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
 
 
+@pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 40), (77, 2, 40), (35, 1, 65535), (69, 2, 40)])
+def test_extension_multiword_keys_grouping_aggregation(H, O, K, L, U):
+    """EXTENSION=1 with keys of two and three words through the batch path: prefix passes with the payload carried (the prefix
+    continues in the word below for K=35 / 69), then aggw_ext_kernel groups every prefix bin by key.  Entries, counts and every
+    kept k-mer's payload set against the oracle; prefix-sharing variants go up the table ladder, a poly-A bin exceeds the
+    second sweep's registers."""
+    from hysortk_amd import synth
+    rng = np.random.default_rng(K)
+    seqs = list(synth.reads(120000, 150, 6000, 17))
+    pre = "".join(rng.choice(list("ACGT"), 100))
+    seqs += ["".join(rng.choice(list("ACGT"), 40)) + pre for _ in range(1800)]      # same last bases (the prefix bin), different first
+    seqs += ["AC" * 75] * 30 + [("ACGGTCATTGCA" * 13)[:150]] * 150
+    seqs += ["A" * 150] * 120
+    dna = H.DnaBuffer.from_sequences(seqs)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=17, L=L, U=U, ext=1, ntasks=16, rid_base=7, fast=True)
+    with H.Context(K=K, M=17, L=L, U=U, EXT=1, ntasks=16) as c:
+        res = c.count(dna, rid_base=7)
+        st = c.stats()
+    assert st["fused_tasks"] + st["redone_tasks"] == 16 and st["fused_tasks"] > 0, st
+    assert np.array_equal(res.task_off, ores.task_off)
+    assert np.array_equal(res.kmers, ores.keys)
+    assert np.array_equal(res.cnt, ores.cnt)
+    assert H.histogram_text(res.histo) == O.histogram_text(ores.cnt)
+    for i in list(range(0, len(res), 41)) + [len(res) - 1]:
+        pos, rid = res.payload(i)
+        a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+        assert len(pos) == int(res.cnt[i])
+        assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), i
+    sel = np.concatenate([np.arange(int(o), int(o) + int(c)) for o, c in zip(res.payload_off[:-1], res.cnt)])
+    assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist()))
+
+
 def test_resident_result_csr_on_device(H, O):
     """HSK_FLAG_KEEP_DEVICE: the list stays in HBM and hsk_result_device_task hands out the per-task entry arrays and, with
     EXTENSION, the CSR payload (payload_off / pos / rid) for a following GPU stage; read back they equal the host result."""
