@@ -1,7 +1,14 @@
-// hsk_agg.h -- "two passes, then aggregate": the last stage of filter_kmer for one-word keys without payload.
+// hsk_agg.h -- "two passes, then aggregate": the last stage of filter_kmer.
 //
-// Replaces the tail of sort_task + count_sorted_kmers (reference src/kmerops.cpp:1382-1445) for NW == 1,
-// EXTENSION == 0.  The reference sorts every k-mer instance of a task completely (RADULS, 8 byte passes) and
+// Replaces the tail of sort_task + count_sorted_kmers (reference src/kmerops.cpp:1382-1445).  Kernels by key width and
+// payload: agg_finish_kernel (one word; described below), agg2_finish_kernel / agg3_finish_kernel (two / three words),
+// agg_ext_kernel / aggw_ext_kernel<NW> (EXTENSION: the payloads grouped by key), agg_big_kernel (8-bit bins, HSK_ONEPASS
+// and the last rung of the ladder).  The probe loops of the tables are hand-written assembly (agg_count_keys,
+// agg2_count_keys, agg3_count_keys): as loops of the WAVE they cost 6 scalar instructions per probe instead of the ~25 the
+// compiler spends on execution masks -- the scalar unit was what agg_finish_kernel ran out of --, and for multi-word keys
+// the order "claimers publish, then the others wait" must not be left to the compiler's choice of which branch runs first.
+//
+// The reference sorts every k-mer instance of a task completely (RADULS, 8 byte passes) and
 // then scans the sorted array for runs.  Sequencing data repeats every k-mer about `coverage` times, so most of
 // that sorting moves copies of the same key around.  Here only the top 16 key bits are sorted globally (two
 // onesweep passes, hsk_sort.h): that cuts a 2^28-key task into 65536 prefix bins of ~4096 records, and such a
@@ -16,8 +23,9 @@
 // Bins are ascending in the key prefix and entries ascending inside a bin, so the list is exactly the sorted,
 // filtered list the reference produces.
 //
-// A bin with more distinct keys than the table holds raises AG_FLAG_OVERFLOW for its task: the host retries the
-// task with the large table and, if that overflows too, takes the long way (full-width passes + count_kernel).
+// A bin with more distinct keys than the table holds is appended to its task's overflow list; the next launch, one table
+// size up, takes the listed bins (hsk_host_finish.h); a bin beyond the last table raises AG_FLAG_OVERFLOW and its task takes
+// the long way (full-width passes + count_kernel).
 #pragma once
 #include "hsk_device.h"
 
