@@ -885,6 +885,39 @@ def test_fused_scatter_sweep_vs_oracle(H, O, seed):
     assert np.array_equal(res.cnt, ores.cnt), tag
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_wide_keys_and_extension_sweep_vs_oracle(H, O, seed):
+    """Random (K, M, EXTENSION, task count, filter) over keys of one to three words, every length of the most significant word
+    (the prefix inside it or continued in the word below), whole batches of 8 tasks: prefix passes + agg2 / agg3 / agg_ext /
+    aggw_ext kernels against the oracle, entries, counts and (EXTENSION) the payload sets."""
+    rng = np.random.default_rng(7000 + seed)
+    K = int(rng.choice([33, 34, 37, 39, 40, 47, 55, 63, 65, 66, 70, 71, 72, 80, 93, 95, 31, 27]))
+    M = int(rng.integers(9, 24))
+    EXT = int(seed % 3 != 0)
+    ntasks = int(rng.choice([8, 13, 16, 24]))
+    L = int(rng.choice([1, 2])); U = int(rng.choice([40, 65535]))
+    g = "".join(rng.choice(list("ACGT"), 60000, p=[0.35, 0.15, 0.15, 0.35] if seed % 2 else [0.25] * 4))
+    reads = [g[p:p + 150] for p in rng.integers(0, len(g) - 150, 9000)]
+    reads += ["".join(rng.choice(list("AT"), 170)) for _ in range(400)]
+    reads += ["A" * 150] * 70 + ["".join(rng.choice(list("ACGT"), 30)) + g[1000:1120] for _ in range(700)]
+    dna = H.DnaBuffer.from_sequences(reads)
+    packed, off, lens = dna.arrays()
+    ores = O.count(packed, off, lens, k=K, m=M, L=L, U=U, ext=EXT, ntasks=ntasks, rid_base=3, fast=True)
+    with H.Context(K=K, M=M, L=L, U=U, EXT=EXT, ntasks=ntasks) as c:
+        res = c.count(dna, rid_base=3)
+        st = c.stats()
+    tag = (K, M, EXT, ntasks, L, U)
+    assert st["fused_tasks"] + st["redone_tasks"] == ntasks and st["fused_tasks"] > 0, (tag, st)
+    assert np.array_equal(res.task_off, ores.task_off), tag
+    assert np.array_equal(res.kmers, ores.keys), tag
+    assert np.array_equal(res.cnt, ores.cnt), tag
+    if EXT:
+        for i in list(range(0, len(res), 211)) + [len(res) - 1]:
+            pos, rid = res.payload(i)
+            a, b = int(ores.payoff[i]), int(ores.payoff[i + 1])
+            assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
+
+
 @pytest.mark.parametrize("K", [31, 51, 77])
 def test_output_text_formatted_on_device(H, O, K, tmp_path):
     """hsk_format_entries: the "KMER\\tcount" lines of write_output_file (reference src/hysortk.cpp:138-164) formatted on the GPU
