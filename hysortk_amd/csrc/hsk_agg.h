@@ -2,7 +2,7 @@
 //
 // Replaces the tail of sort_task + count_sorted_kmers (reference src/kmerops.cpp:1382-1445).  Kernels by key width and
 // payload: agg_finish_kernel (one word; described below), agg2_finish_kernel / agg3_finish_kernel (two / three words),
-// agg_ext_kernel / aggw_ext_kernel<NW> (EXTENSION: the payloads grouped by key), agg_big_kernel (8-bit bins, HSK_ONEPASS
+// agg_ext_kernel<cap, NW> (EXTENSION: the payloads grouped by key), agg_big_kernel (8-bit bins, HSK_ONEPASS
 // and the last rung of the ladder).  The probe loops of the tables are hand-written assembly (agg_count_keys,
 // agg2_count_keys, agg3_count_keys): as loops of the WAVE they cost 6 scalar instructions per probe instead of the ~25 the
 // compiler spends on execution masks -- the scalar unit was what agg_finish_kernel ran out of --, and for multi-word keys
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg3_finish_kernel(AggArgs a)
 //      74 of this kernel's 117 ms per benchmark step).  Larger bins read their records again, find the group through
 //      the table, take the next free place of the group with an LDS atomic and store directly.  The order of the
 //      payloads inside one k-mer is free (the reference's sorts are not stable either).
-// Entries {key, count} and their payload offsets go to per-bin slots and are compacted afterwards.
+// Entries {key words, count} and their payload offsets go to per-bin slots and are compacted afterwards.
 // ------------------------------------------------------------------------------------------------------------
 struct AggExtTask {
     const u64 *keys, *vals; u64 n;
@@ -797,208 +797,12 @@ __global__ __launch_bounds__(AG_THREADS) void bin_bounds_ext_kernel(AggExtArgs a
     t.bounds[b] = lo;
 }
 
-template <int LOG2CAP>
-__global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
-{
-    constexpr int CAP = 1 << LOG2CAP;
-    constexpr int PER = CAP / AG_THREADS;
-    constexpr int UNR = 16, NBAT = 2, REGS = UNR * NBAT;  // records per lane whose slots stay in registers: bins of up to 8192 records
-                                                          // (the bins of prefixes that start with A hold twice the average: canonical k-mers)
-    constexpr u32 STAGE = (u32)CAP * 30u / 8u;            // payloads per window of the stage
-    // 30 bytes per slot, everything the kernel keeps per slot: the distinct keys compacted / ordered, their counts and origin
-    // slots; the table's keys (needed again only by the second sweep of a bin too large for registers); slot -> first record
-    // (inside the bin) of the group of the slot's key; records per slot (the second sweep counts them down again: a record's
-    // place inside its group).  For a bin in registers all of it is, once every record knows its place, the payload stage.
-    __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
-    __shared__ u32 s_scr[8];
-    __shared__ u32 s_ovf;
-    u64 *s_key = s_raw;
-    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + CAP);
-    u16 *s_slot = reinterpret_cast<u16 *>(s_cnt + CAP);
-    u64 *s_tkey = s_raw + (size_t)CAP * 14 / 8;
-    u32 *s_soff = reinterpret_cast<u32 *>(s_tkey + CAP);
-    u32 *s_tcnt = s_soff + CAP;
-    const AggExtTask &t = a.t[blockIdx.y];
-    if (!t.active) return;
-    u32 b = blockIdx.x;
-    if (t.bin_list) { if (b >= *t.bin_list_n || b >= a.nbins) return; b = t.bin_list[b]; if (b >= a.nbins) return; }
-    const int tid = threadIdx.x;
-    const u64 s = t.bounds[b], e = t.bounds[b + 1];
-    if (e == s) { if (tid == 0) t.bin_cnt[b] = 0; return; }
-    const bool in_regs = e - s <= (u64)AG_THREADS * REGS;              // (uniform)
-    const u32 nrec = in_regs ? (u32)(e - s) : 0u;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { s_tkey[j * AG_THREADS + tid] = AG_EMPTY; s_tcnt[j * AG_THREADS + tid] = 0; }
-    if (tid == 0) s_ovf = 0;
-    __syncthreads();
-
-    // ---- 1. first sweep: count ----------------------------------------------------------------------------------
-    typedef __attribute__((address_space(3))) void *LdsPtr;
-    const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_tkey, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_tcnt;
-    u32 where[REGS];                                      // in_regs: the slot every record of this lane was counted in
-#pragma unroll
-    for (int u = 0; u < REGS; ++u) where[u] = 0;
-    auto count_batch = [&](u64 i, u32 *wh) {
-        u64 k[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const u64 act = __ballot(k[u] != AG_EMPTY);
-            if (act == 0) continue;                       // (uniform)
-            u32 h = agg_slot<LOG2CAP>(k[u]);
-            if (agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u]) != 0) s_ovf = 1;
-            if (wh) wh[u] = h;
-        }
-    };
-    if (in_regs) {
-#pragma unroll
-        for (int bt_ = 0; bt_ < NBAT; ++bt_)
-            if (s + (u64)bt_ * AG_THREADS * UNR < e) count_batch(s + tid + (u64)bt_ * AG_THREADS * UNR, where + bt_ * UNR);      // (uniform)
-    } else {
-        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
-            count_batch(i, nullptr);
-            if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        }
-    }
-    __syncthreads();
-    if (s_ovf) {
-        if (tid == 0) {
-            if (t.ovf_list) { const u32 at = atomicAdd(t.ovf_n, 1u); if (at < a.nbins) t.ovf_list[at] = b; else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW); }
-            else atomicOr(t.flags, (u32)AG_FLAG_OVERFLOW);
-            t.bin_cnt[b] = 0;
-        }
-        return;
-    }
-
-    // ---- 2. distinct keys in key order, group offsets --------------------------------------------------------------
-    u32 D;
-    {
-        u32 occ = 0;
-        u64 mk[PER]; u32 mc[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { mk[j] = s_tkey[tid * PER + j]; mc[j] = s_tcnt[tid * PER + j]; occ += mk[j] != AG_EMPTY; }
-        u32 o = block_excl_scan_256<u32>(occ, s_scr, &D);             // (barriers inside: the counts are in registers before s_cnt / s_slot are written)
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (mk[j] != AG_EMPTY) { s_key[o] = mk[j]; s_cnt[o] = mc[j]; s_slot[o] = (u16)(tid * PER + j); ++o; }
-    }
-    __syncthreads();
-    D = (u32)__builtin_amdgcn_readfirstlane((int)D);
-    if (D <= (u32)AG_THREADS) {
-        u64 k = 0; u32 c = 0, r = 0; u16 sl = 0;
-        if ((u32)tid < D) {
-            k = s_key[tid]; c = s_cnt[tid]; sl = s_slot[tid];
-            for (u32 j = 0; j < D; ++j) r += s_key[j] < k;
-        }
-        __syncthreads();
-        if ((u32)tid < D) { s_key[r] = k; s_cnt[r] = c; s_slot[r] = sl; }
-        __syncthreads();
-    } else {
-        u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_key[i] = AG_EMPTY; s_cnt[i] = 0; s_slot[i] = 0; }
-        __syncthreads();
-        for (u32 kk = 2; kk <= P; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < P; i += AG_THREADS) {
-                    const u32 q = i ^ j;
-                    if (q > i) {
-                        const u64 x = s_key[i], y = s_key[q];
-                        const bool up = (i & kk) == 0;
-                        if ((x > y) == up) {
-                            const u32 cx = s_cnt[i], cy = s_cnt[q]; const u16 sx = s_slot[i], sy = s_slot[q];
-                            s_key[i] = y; s_key[q] = x; s_cnt[i] = cy; s_cnt[q] = cx; s_slot[i] = sy; s_slot[q] = sx;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
-    u32 kept = 0, gof[PER];
-    {
-        u32 csum = 0, cv[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const u32 i = tid * PER + j;
-            cv[j] = i < D ? s_cnt[i] : 0;
-            csum += cv[j];
-            kept += (i < D && cv[j] >= a.lower && cv[j] <= a.upper);
-        }
-        u32 go = block_excl_scan_256<u32>(csum, s_scr, nullptr);
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const u32 i = tid * PER + j;
-            gof[j] = go;
-            if (i < D) s_soff[s_slot[i]] = go;
-            go += cv[j];
-        }
-    }
-    u32 tot;
-    const u32 w = block_excl_scan_256<u32>(kept, s_scr, &tot);      // (barriers inside: s_soff is complete for the second sweep)
-    {
-        const u64 slot0 = (s >> t.slot_shift) + w;
-        u64 *de = t.scratch_e + slot0 * 2; u64 *dp = t.scratch_p + slot0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const u32 i = tid * PER + j;
-            if (i < D) {
-                const u32 c = s_cnt[i];
-                if (c >= a.lower && c <= a.upper) { de[0] = s_key[i]; de[1] = (u64)c; dp[0] = t.payoff_add + s + gof[j]; de += 2; ++dp; }
-            }
-        }
-    }
-    if (tid == 0) t.bin_cnt[b] = tot;
-    __syncthreads();                                                // the ordered keys and counts have been read: s_raw is free
-
-    // ---- 3. second sweep: every payload to its place ---------------------------------------------------------------
-    if (in_regs) {
-#pragma unroll
-        for (int u = 0; u < REGS; ++u) {                  // where[u] becomes the record's place in the bin (inside a group in any order)
-            const u32 r = (u32)tid + (u32)u * AG_THREADS;
-            where[u] = r < nrec ? s_soff[where[u]] + atomicSub(&s_tcnt[where[u]], 1u) - 1u : ~0u;
-        }
-        __syncthreads();                                   // (the offsets and counts have been read: they are stage now)
-        for (u32 w0 = 0; w0 < nrec; w0 += STAGE) {
-#pragma unroll
-            for (int bt_ = 0; bt_ < NBAT; ++bt_) {
-                if ((u32)bt_ * AG_THREADS * UNR >= nrec) continue;                                  // (uniform)
-                u64 v[UNR];                                // (read again for every window: the bin's payloads stay in L2)
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) { const u32 r = (u32)tid + (u32)(bt_ * UNR + u) * AG_THREADS; v[u] = t.vals[s + (r < nrec ? r : 0u)]; }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) { const u32 o = where[bt_ * UNR + u]; if (o - w0 < STAGE) s_raw[o - w0] = v[u]; }      // (places before the window wrap to huge values, ~0 stays out of every window)
-            }
-            __syncthreads();
-            const u32 n = nrec - w0 < STAGE ? nrec - w0 : STAGE;
-            for (u32 i = tid; i < n; i += AG_THREADS) {
-                const u64 x = s_raw[i];
-                t.pos[s + w0 + i] = (u32)x; t.rid[s + w0 + i] = (int32_t)(x >> 32);
-            }
-            __syncthreads();
-        }
-    } else {
-        constexpr int UNR2 = 8;
-        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR2) {
-            u64 k[UNR2], v[UNR2];
-#pragma unroll
-            for (int u = 0; u < UNR2; ++u) { const u64 idx = i + (u64)u * AG_THREADS; const bool ok = idx < e; k[u] = ok ? t.keys[idx] : AG_EMPTY; v[u] = ok ? t.vals[idx] : 0; }
-#pragma unroll
-            for (int u = 0; u < UNR2; ++u) {
-                if (k[u] == AG_EMPTY) continue;
-                u32 h = agg_slot<LOG2CAP>(k[u]);
-                while (s_tkey[h] != k[u]) h = (h + 1) & (CAP - 1);             // present: the first sweep put it there
-                const u64 o = s + s_soff[h] + atomicSub(&s_tcnt[h], 1u) - 1u;
-                t.pos[o] = (u32)v[u]; t.rid[o] = (int32_t)(v[u] >> 32);
-            }
-        }
-    }
-}
-
-// The same for keys of two and three words (K > 32 with EXTENSION; until round 2 these took 13 - 20 full LSD passes over
-// records of 24 - 32 bytes): the table and the ordered keys hold NW words per slot (14 + 16 NW bytes of LDS per slot: tables of 1024
-// and 2048 slots), slots are claimed with agg2_count_keys / agg3_count_keys, everything else is agg_ext_kernel's.  Records
-// {word 0 .. word NW-1}, entries {words, count}.
+// The kernel, for keys of NW = 1 .. 3 words (records {word 0 .. word NW-1}, entries {words, count}).  14 + 16 NW bytes of LDS per
+// slot -- the table's keys, the distinct keys compacted / ordered with their counts and origin slots, slot -> first record of the
+// slot's group, records per slot --, all of which becomes the payload stage once every record of a bin in registers knows its
+// place.  Tables: 1024 slots first; 4096 (one word) or 2048 (two, three words) for the bins the first could not hold.  Slots are
+// claimed with agg_count_keys / agg2_count_keys / agg3_count_keys.  (Multi-word keys with EXTENSION took 13 - 20 full LSD passes over
+// records of 24 - 32 bytes until round 2.)
 template <int NW> __device__ __forceinline__ bool keyw_less(const u64 (&x)[NW], const u64 (&y)[NW])
 {
 #pragma unroll
@@ -1006,12 +810,14 @@ template <int NW> __device__ __forceinline__ bool keyw_less(const u64 (&x)[NW], 
     return x[0] < y[0];
 }
 template <int LOG2CAP, int NW>
-__global__ __launch_bounds__(AG_THREADS) void aggw_ext_kernel(AggExtArgs a)
+__global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
 {
-    static_assert(NW == 2 || NW == 3, "one-word keys: agg_ext_kernel");
+    static_assert(NW >= 1 && NW <= 3, "keys of one to three words");
     constexpr int CAP = 1 << LOG2CAP;
     constexpr int PER = CAP / AG_THREADS;
-    constexpr int UNR = 8, NBAT = 4, REGS = UNR * NBAT;
+    // records per lane whose slots stay in registers: bins of up to 8192 records (the bins of prefixes that start with A hold
+    // twice the average: canonical k-mers), loaded in batches of UNR
+    constexpr int UNR = NW == 1 ? 16 : 8, REGS = 32, NBAT = REGS / UNR;
     constexpr u32 STAGE = (u32)CAP * (14u + 16u * NW) / 8u;
     __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
     __shared__ u32 s_scr[8];
@@ -1048,7 +854,8 @@ __global__ __launch_bounds__(AG_THREADS) void aggw_ext_kernel(AggExtArgs a)
 #pragma unroll
     for (int u = 0; u < REGS; ++u) where[u] = 0;
     auto slot_of = [&](const u64 (&k)[NW]) -> u32 {
-        const u64 m = NW == 2 ? (k[0] ^ (k[1] >> 9) ^ (k[1] << 21)) : (k[0] ^ (k[1] >> 7) ^ (k[1] << 23) ^ (k[NW - 1] >> 9) ^ (k[NW - 1] << 21));
+        if (NW == 1) return agg_slot<LOG2CAP>(k[0]);
+        const u64 m = NW == 2 ? (k[0] ^ (k[NW - 1] >> 9) ^ (k[NW - 1] << 21)) : (k[0] ^ (k[NW > 1 ? 1 : 0] >> 7) ^ (k[NW > 1 ? 1 : 0] << 23) ^ (k[NW - 1] >> 9) ^ (k[NW - 1] << 21));
         const u32 x = (u32)(m >> 32) ^ (u32)m;
         return (x * 0x9E3779B1u) >> (32 - LOG2CAP);
     };
@@ -1066,8 +873,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggw_ext_kernel(AggExtArgs a)
             if (act == 0) continue;                       // (uniform)
             u32 h = slot_of(k[u]), tmo = 0;
             u64 left;
-            if (NW == 2) left = agg2_count_keys<(u32)CAP - 1u>(act, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][0], tmo);
-            else left = agg3_count_keys<(u32)CAP - 1u>(act, tk_lds + 2u * (u32)CAP * 8u, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][NW == 3 ? 1 : 0], k[u][0], tmo);
+            if (NW == 1) left = agg_count_keys<(u32)CAP - 1u>(act, tk_lds, cnt_lds, h, k[u][0]);
+            else if (NW == 2) left = agg2_count_keys<(u32)CAP - 1u>(act, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][0], tmo);
+            else left = agg3_count_keys<(u32)CAP - 1u>(act, tk_lds + 2u * (u32)CAP * 8u, tk_lds + (u32)CAP * 8u, tk_lds, cnt_lds, h, k[u][NW - 1], k[u][NW > 1 ? 1 : 0], k[u][0], tmo);
             if (left != 0 || tmo) s_ovf = 1;
             if (wh) wh[u] = h;
         }

@@ -464,13 +464,10 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     struct { u32 flags[2 * AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto launch = [&](int log2cap, u32 grid_x) {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
-        if constexpr (NW == 1) {
-            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-            else hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        } else {                                            // (14 + 16 NW bytes of LDS per slot: the large table of multi-word keys has 2048 slots)
-            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((aggw_ext_kernel<AG_LOG2CAP_SMALL, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-            else hipLaunchKernelGGL((aggw_ext_kernel<AG_LOG2CAP_MEDIUM, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        }
+        // (14 + 16 NW bytes of LDS per slot: the second table has 4096 slots for one-word keys, 2048 for two and three words)
+        constexpr int BIG = NW == 1 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_MEDIUM;
+        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_ext_kernel<BIG, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     };
     memset(&h, 0, sizeof h);

@@ -682,7 +682,7 @@ def test_extension_grouping_aggregation(H, O, L, U):
 @pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 40), (77, 2, 40), (35, 1, 65535), (69, 2, 40)])
 def test_extension_multiword_keys_grouping_aggregation(H, O, K, L, U):
     """EXTENSION=1 with keys of two and three words through the batch path: prefix passes with the payload carried (the prefix
-    continues in the word below for K=35 / 69), then aggw_ext_kernel groups every prefix bin by key.  Entries, counts and every
+    continues in the word below for K=35 / 69), then agg_ext_kernel<cap, NW> groups every prefix bin by key.  Entries, counts and every
     kept k-mer's payload set against the oracle; prefix-sharing variants go up the table ladder, a poly-A bin exceeds the
     second sweep's registers."""
     from hysortk_amd import synth
@@ -888,8 +888,8 @@ def test_fused_scatter_sweep_vs_oracle(H, O, seed):
 @pytest.mark.parametrize("seed", range(12))
 def test_wide_keys_and_extension_sweep_vs_oracle(H, O, seed):
     """Random (K, M, EXTENSION, task count, filter) over keys of one to three words, every length of the most significant word
-    (the prefix inside it or continued in the word below), whole batches of 8 tasks: prefix passes + agg2 / agg3 / agg_ext /
-    aggw_ext kernels against the oracle, entries, counts and (EXTENSION) the payload sets."""
+    (the prefix inside it or continued in the word below), whole batches of 8 tasks: prefix passes + agg2 / agg3 /
+    agg_ext kernels (one to three key words) against the oracle, entries, counts and (EXTENSION) the payload sets."""
     rng = np.random.default_rng(7000 + seed)
     K = int(rng.choice([33, 34, 37, 39, 40, 47, 55, 63, 65, 66, 70, 71, 72, 80, 93, 95, 31, 27]))
     M = int(rng.integers(9, 24))
