@@ -337,6 +337,8 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         if (ovf_bins * 20 > (u64)nact * nbins) c->agg_first_cap = std::min(p.first_cap + 1, (int)AG_LOG2CAP_LARGE);
         else if (ovf_bins == 0 && p.first_cap > AG_LOG2CAP_SMALL && maxd < (1u << (p.first_cap - 1)) * 3 / 4) c->agg_first_cap = p.first_cap - 1;
     }
+    { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
+      if (force_off && NW == 1 && !c->forbid_long_way) c->agg_off = true; }
     // ---- the ladder, bin by bin: the listed bins again one table size up, until no bin is left or the rungs are ----------------
     if (!big && ovf_bins) {
         AggArgs keep = a;
@@ -349,6 +351,15 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             int next = (NW >= 2) ? (cap < AG_LOG2CAP_LARGE ? AG_LOG2CAP_LARGE : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
             if (next > max_rung) next = 0;
             if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
+            // More than half of all bins did not fit 2048 slots: this input has (nearly) as many distinct k-mers as k-mers -- reads with
+            // 5 % errors and more -- and the aggregation is the wrong tool.  No further rungs: the tasks of this batch take the long way
+            // now, the batches after it (and later calls on this context) four prefix passes + the tile finish instead of two + tables.
+            static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
+            if (adapt && NW == 1 && !c->forbid_long_way && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
+                c->agg_off = true;
+                for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false;
+                break;
+            }
             cap = next;
             const bool last = (NW >= 2) || cap == AG_LOG2CAP_HUGE;
             HIPCHK(c, hipMemsetAsync(p.d_flags + (2 + (cur ^ 1)) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));

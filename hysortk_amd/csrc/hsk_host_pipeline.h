@@ -373,10 +373,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         return HSK_OK;
     };
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
+    bool slot_agg[2] = {false, false};                    // ... and whether the aggregating finish follows it (hsk_ctx::agg_off can end that in the middle of a call)
     BatchTask bts[2][XCD_BATCH];
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
-        const int prefix_bits = (agg || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        slot_agg[sl] = agg && !(NW == 1 && c->agg_off);
+        const int prefix_bits = (slot_agg[sl] || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
         const int npass = batch_pass_plan<NW>(c, K, fused || fused_ext, prefix_bits, plan);
@@ -395,7 +397,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
         }
         int rc;
-        if (xs && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
+        if (xs && slot_agg[sl] && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
             if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
@@ -426,6 +428,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
     for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
         const int sl = lag ? (int)(b & 1) : 0;
+        if (pend[sl].active) { int rc = finish_stage2(sl, false); if (rc) return rc; }       // (only after hsk_ctx::agg_off ended the aggregation in the middle of the call: the slot's buffers are about to be reused)
         if (feeder) {                                   // exposed (not overlapped) part of the exchange
             pt.begin(PH_EXCH);
             for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK) continue; int rc = feeder->need(feeder->group_of[mine[pos + i]]); if (rc) return rc; }
@@ -448,20 +451,20 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 for (int i = 0; i < XCD_BATCH; ++i) if (mine[pos + i] != EMPTY_TASK) touts[mine[pos + i]] = fo[i];
                 pt.end(PH_COUNT);
             }
-        } else if (agg) {
+        } else if (agg && slot_agg[sl]) {
             if constexpr (NW <= 3) {
                 // the previous batch first: this batch's expand and scatter pass are queued behind its aggregation, so the
                 // wait for its totals does not idle the GPU, and its compaction (and result copy) starts one kernel earlier
                 // (stage 2 of the previous batch BEFORE this batch's stage 1 would start its result copy one kernel earlier, but a
                 // device-to-host copy running beside agg_finish_kernel stretches a batch from 19 to 32 ms: measured, off)
                 static const bool s2first = getenv("HSK_STAGE2_FIRST") && atoi(getenv("HSK_STAGE2_FIRST")) != 0;
-                if (lag && b > 0 && s2first) { int rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                if (lag && b > 0 && s2first && pend[sl ^ 1].active) { int rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
                 pt.begin(PH_COUNT);
                 int rc = agg_stage1<NW>(c, bt, K, prefix_bits, sl, pend[sl]);
                 pt.end(PH_COUNT);
                 if (rc) return rc;
                 pend_pos[sl] = pos;
-                if (lag && b > 0 && !s2first) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                if (lag && b > 0 && !s2first && pend[sl ^ 1].active) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
                 if (!lag) { rc = finish_stage2(sl, false); if (rc) return rc; }
             }
         } else if (fused) {
@@ -482,7 +485,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             pt.end(PH_COUNT);
         }
     }
-    if (lag && agg && nbatch > 0) { int rc = finish_stage2((int)((nbatch - 1) & 1), false); if (rc) return rc; }
+    if (lag && agg && nbatch > 0) for (int sl = 0; sl < 2; ++sl) if (pend[sl].active) { int rc = finish_stage2(sl, false); if (rc) return rc; }
     for (; pos < mine.size(); ++pos) {
         const u32 t = mine[pos];
         const u64 n = segs[t].nkmers;
