@@ -74,7 +74,8 @@ __device__ __forceinline__ void agg_bin_overflow(const AggTask &t, u32 nbins, u3
     atomicMax(t.flags + AG_BATCH, cap);
     t.bin_cnt[b] = 0;
 }
-struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; };   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
+struct AggArgs { AggTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; int top_sig; };   // top_sig: significant bits of the most significant word (multi-word keys)
+//   // bins = key >> shift, nbins of them (65536 / 48, or 256 / 56)
 // top_bits (multi-word keys): how many of the 16 prefix bits the most significant word holds (0 or 16: all); the rest are the top
 // bits of the word below
 __device__ __forceinline__ u32 agg_bin_of(const AggArgs &a, const u64 *rec)
@@ -350,6 +351,82 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 // ~0 is no valid word 0: a canonical k-mer that starts with 32 T needs a reverse complement that starts with 32 T
 // too, i.e. a k-mer whose last 32 bases are A, impossible for K < 64 next to 32 leading T.
 // ------------------------------------------------------------------------------------------------------------
+// Many distinct keys (more than a workgroup has lanes) of NW words in key order, as agg_emit_bin does it for one word: a counting
+// sort on the key bits right below the 16-bit bin prefix, then every key ranks itself inside its bucket (~10 LDS operations per
+// key; the bitonic network this replaces for multi-word keys and EXTENSION made bins of ~1000 keys -- reads with 1 % errors --
+// ten times slower).  The bits come from the significant bit string of the key, most significant word first: the top word holds
+// top_sig of them (left-aligned, zeros below), the word under it continues.  kw[w]: word w of key i at kw[w][i]; s_slot (SLOT):
+// carried along.  In place: every lane holds its keys in registers between "all read" and "all written".
+template <int LOG2CAP, int NW, bool SLOT>
+__device__ __forceinline__ void agg_order_many(u32 D, u64 *const (&kw)[NW], u32 *s_cnt, u16 *s_slot, u32 *s_bkt, u32 *s_scr, int top_sig)
+{
+    constexpr int CAP = 1 << LOG2CAP, EPT = CAP / AG_THREADS, NBKT = CAP / 2, LOG2BKT = LOG2CAP - 1;
+    const int tid = threadIdx.x;
+    auto bucket = [&](const u64 (&k)[NW]) -> u32 {
+        u64 hi = k[NW - 1];
+        if (NW > 1 && top_sig < 64) hi |= k[NW > 1 ? NW - 2 : 0] >> top_sig;
+        return (u32)(hi >> (48 - LOG2BKT)) & (u32)(NBKT - 1);
+    };
+    for (int i = tid; i < NBKT; i += AG_THREADS) s_bkt[i] = 0;
+    __syncthreads();
+    u64 ek[EPT][NW]; u32 ec[EPT], er[EPT], eb[EPT]; u16 es[EPT];
+#pragma unroll
+    for (int x = 0; x < EPT; ++x) {
+        const u32 i = x * AG_THREADS + tid;
+        ec[x] = 0; er[x] = 0; eb[x] = ~0u; es[x] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ek[x][w] = 0;
+        if (i < D) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ek[x][w] = kw[w][i];
+            ec[x] = s_cnt[i]; if (SLOT) es[x] = s_slot[i];
+            eb[x] = bucket(ek[x]);
+            er[x] = atomicAdd(&s_bkt[eb[x]], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int BPT = NBKT / AG_THREADS;
+        u32 v[BPT], sum = 0;
+#pragma unroll
+        for (int x = 0; x < BPT; ++x) { v[x] = s_bkt[tid * BPT + x]; sum += v[x]; }
+        u32 ex = block_excl_scan_256<u32>(sum, s_scr, nullptr);
+#pragma unroll
+        for (int x = 0; x < BPT; ++x) { s_bkt[tid * BPT + x] = ex; ex += v[x]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < EPT; ++x)
+        if (eb[x] != ~0u) {
+            const u32 pos = s_bkt[eb[x]] + er[x];               // bucket-major
+#pragma unroll
+            for (int w = 0; w < NW; ++w) kw[w][pos] = ek[x][w];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < EPT; ++x) {
+        if (eb[x] == ~0u) continue;
+        const u32 b0 = s_bkt[eb[x]], b1 = (eb[x] + 1 < (u32)NBKT) ? s_bkt[eb[x] + 1] : D;
+        u32 r = b0;
+        for (u32 q = b0; q < b1; ++q) {
+            bool less = false, decided = false;
+#pragma unroll
+            for (int w = NW - 1; w >= 0; --w) { const u64 o = kw[w][q]; if (!decided && o != ek[x][w]) { less = o < ek[x][w]; decided = true; } }
+            r += less ? 1u : 0u;
+        }
+        er[x] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < EPT; ++x)
+        if (eb[x] != ~0u) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) kw[w][er[x]] = ek[x][w];
+            s_cnt[er[x]] = ec[x]; if (SLOT) s_slot[er[x]] = es[x];
+        }
+    __syncthreads();
+}
+
 // agg_count_keys for two-word keys: a slot is claimed on word 1 (compare-and-swap), the claimer publishes word 0 and counts
 // itself; a lane that finds its word 1 in the slot reads word 0 until it is there (claimers of the same wave have issued
 // their store before -- the LDS executes a wave's operations in order --, claimers of other waves never wait for anything
@@ -432,6 +509,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     __shared__ u64 s_k1[CAP];
     __shared__ u64 s_k0[CAP];
     __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_bkt[CAP / 2];  // buckets of the counting sort that orders many distinct keys
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
@@ -494,25 +572,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
         if ((u32)tid < D) { s_k1[r] = k1; s_k0[r] = k0; s_cnt[r] = c; }
         __syncthreads();
     } else {
-        u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_k1[i] = AG_EMPTY; s_k0[i] = AG_EMPTY; s_cnt[i] = 0; }
-        __syncthreads();
-        for (u32 kk = 2; kk <= P; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < P; i += AG_THREADS) {
-                    const u32 q = i ^ j;
-                    if (q > i) {
-                        const u64 x1 = s_k1[i], x0 = s_k0[i], y1 = s_k1[q], y0 = s_k0[q];
-                        const bool up = (i & kk) == 0;
-                        if (key2_less(y1, y0, x1, x0) == up) {
-                            const u32 cx = s_cnt[i], cy = s_cnt[q];
-                            s_k1[i] = y1; s_k0[i] = y0; s_cnt[i] = cy; s_k1[q] = x1; s_k0[q] = x0; s_cnt[q] = cx;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        u64 *const kw[2] = {s_k0, s_k1};
+        agg_order_many<LOG2CAP, 2, false>(D, kw, s_cnt, nullptr, s_bkt, s_scr, a.top_sig);
     }
 
     // ---- filter, entries {word 0, word 1, count} in key order to the bin's slots -----------------------------------
@@ -638,6 +699,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg3_finish_kernel(AggArgs a)
     __shared__ u64 s_k1[CAP];
     __shared__ u64 s_k0[CAP];
     __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_bkt[CAP / 2];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
     const AggTask &t = a.t[blockIdx.y];
@@ -707,25 +769,8 @@ __global__ __launch_bounds__(AG_THREADS) void agg3_finish_kernel(AggArgs a)
         if ((u32)tid < D) { s_k2[r] = k2; s_k1[r] = k1; s_k0[r] = k0; s_cnt[r] = c; }
         __syncthreads();
     } else {
-        u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) { s_k2[i] = AG_EMPTY; s_k1[i] = AG_EMPTY; s_k0[i] = AG_EMPTY; s_cnt[i] = 0; }
-        __syncthreads();
-        for (u32 kk = 2; kk <= P; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < P; i += AG_THREADS) {
-                    const u32 q = i ^ j;
-                    if (q > i) {
-                        const u64 x2 = s_k2[i], x1 = s_k1[i], x0 = s_k0[i], y2 = s_k2[q], y1 = s_k1[q], y0 = s_k0[q];
-                        const bool up = (i & kk) == 0;
-                        if (key3_less(y2, y1, y0, x2, x1, x0) == up) {
-                            const u32 cx = s_cnt[i], cy = s_cnt[q];
-                            s_k2[i] = y2; s_k1[i] = y1; s_k0[i] = y0; s_cnt[i] = cy; s_k2[q] = x2; s_k1[q] = x1; s_k0[q] = x0; s_cnt[q] = cx;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        u64 *const kw[3] = {s_k0, s_k1, s_k2};
+        agg_order_many<LOG2CAP, 3, false>(D, kw, s_cnt, nullptr, s_bkt, s_scr, a.top_sig);
     }
 
     // ---- filter, entries {word 0, word 1, word 2, count} in key order to the bin's slots -----------------------------
@@ -777,7 +822,7 @@ struct AggExtTask {
     const u32 *bin_list; const u32 *bin_list_n;
     u32 *ovf_list; u32 *ovf_n;
 };
-struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; };     // nw, top_bits: as in AggArgs (nw = 0 reads as 1)
+struct AggExtArgs { AggExtTask t[AG_BATCH]; u32 lower, upper; u32 nbins; int shift; int nw; int top_bits; int top_sig; };     // nw, top_bits: as in AggArgs (nw = 0 reads as 1)
 
 __global__ __launch_bounds__(AG_THREADS) void bin_bounds_ext_kernel(AggExtArgs a)
 {
@@ -820,6 +865,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
     constexpr int UNR = NW == 1 ? 16 : 8, REGS = 32, NBAT = REGS / UNR;
     constexpr u32 STAGE = (u32)CAP * (14u + 16u * NW) / 8u;
     __shared__ __attribute__((aligned(16))) u64 s_raw[STAGE];
+    __shared__ u32 s_bkt[CAP / 2];
     __shared__ u32 s_scr[8];
     __shared__ u32 s_ovf;
     // raw: [ordered keys NW x CAP x 8][counts CAP x 4][origin slots CAP x 2][table keys NW x CAP x 8][group offsets CAP x 4][table counts CAP x 4]
@@ -946,33 +992,11 @@ __global__ __launch_bounds__(AG_THREADS) void agg_ext_kernel(AggExtArgs a)
         }
         __syncthreads();
     } else {
-        u32 P = 512; while (P < D) P <<= 1;
-        for (u32 i = D + tid; i < P; i += AG_THREADS) {
+        u64 *kw[NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s_k[w * CAP + i] = AG_EMPTY;
-            s_cnt[i] = 0; s_slot[i] = 0;
-        }
-        __syncthreads();
-        for (u32 kk = 2; kk <= P; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < P; i += AG_THREADS) {
-                    const u32 q = i ^ j;
-                    if (q > i) {
-                        u64 x[NW], y[NW];
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) { x[w] = s_k[w * CAP + i]; y[w] = s_k[w * CAP + q]; }
-                        const bool up = (i & kk) == 0;
-                        if (keyw_less<NW>(y, x) == up) {
-                            const u32 cx = s_cnt[i], cy = s_cnt[q]; const u16 sx = s_slot[i], sy = s_slot[q];
-#pragma unroll
-                            for (int w = 0; w < NW; ++w) { s_k[w * CAP + i] = y[w]; s_k[w * CAP + q] = x[w]; }
-                            s_cnt[i] = cy; s_cnt[q] = cx; s_slot[i] = sy; s_slot[q] = sx;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        for (int w = 0; w < NW; ++w) kw[w] = s_k + (size_t)w * CAP;
+        u64 *const (&kwc)[NW] = reinterpret_cast<u64 *const (&)[NW]>(kw);
+        agg_order_many<LOG2CAP, NW, true>(D, kwc, s_cnt, s_slot, s_bkt, s_scr, a.top_sig);
     }
     u32 kept = 0, gof[PER];
     {

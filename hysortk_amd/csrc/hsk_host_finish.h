@@ -237,9 +237,11 @@ static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = records; ep.bytes = records * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
     if (NW == 3) {
         if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else if (NW == 2) {
         if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else
     if (p.big || log2cap == AG_LOG2CAP_HUGE) hipLaunchKernelGGL(agg_big_kernel, dim3(grid_x, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
@@ -285,6 +287,7 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     AggArgs &a = p.a; memset(&a, 0, sizeof a);
     a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = 64 - prefix_bits; a.nw = NW;
     a.top_bits = (NW >= 2 && prefix_bits == 16) ? prefix_top_bits(K, NW) : 0;
+    a.top_sig = NW >= 2 ? 2 * (K - 32 * (NW - 1)) : 64;
     u64 nmax = 0;
     for (int i = 0; i < AG_BATCH; ++i) {
         AggTask &t = a.t[i];
@@ -305,7 +308,6 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     // slots, reads with ~1 % errors move to 2048 after their first batch); bins of 6144 records and more on average (tasks far
     // above 2^28 k-mers) start on the large table.  Two-word keys: small / large only.
     p.first_cap = p.big ? AG_LOG2CAP_SMALL : std::max(c->agg_first_cap, nmax / nbins >= 6144 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL);
-    if (NW >= 2 && p.first_cap == AG_LOG2CAP_MEDIUM) p.first_cap = AG_LOG2CAP_LARGE;
     int rc = agg_launch_rung<NW>(c, p, p.first_cap, nbins, p.ntot); if (rc) return rc;
     rc = agg_launch_scan(c, p); if (rc) return rc;
     p.ev = ev_get(c);
@@ -330,12 +332,14 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     int rc = HSK_OK, nact = 0;
     u64 ovf_bins = 0;
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; if (bt[i].n) { ++nact; ovf_bins += h.ovf[0][i]; } }
-    if (!big && NW == 1 && !c->forbid_long_way && nact) {
+    if (!big && !c->forbid_long_way && nact) {
         // next batch (and next call): one table size up when more than one bin in twenty did not fit this one (each of them is
-        // read twice), one size down again when nothing overflowed and no bin came anywhere near this size's limit
+        // read twice), one size down again when nothing overflowed and no bin came anywhere near this size's limit (one-word
+        // keys: the kernel reports its fullest bin; multi-word keys: after four batches without an overflow)
         u32 maxd = 0; for (int i = 0; i < AG_BATCH; ++i) if (bt[i].n) maxd = std::max(maxd, h.maxd[i]);
-        if (ovf_bins * 20 > (u64)nact * nbins) c->agg_first_cap = std::min(p.first_cap + 1, (int)AG_LOG2CAP_LARGE);
-        else if (ovf_bins == 0 && p.first_cap > AG_LOG2CAP_SMALL && maxd < (1u << (p.first_cap - 1)) * 3 / 4) c->agg_first_cap = p.first_cap - 1;
+        if (ovf_bins * 20 > (u64)nact * nbins) { c->agg_first_cap = std::min(p.first_cap + 1, (int)AG_LOG2CAP_LARGE); c->agg_clean_batches = 0; }
+        else if (ovf_bins == 0 && p.first_cap > AG_LOG2CAP_SMALL &&
+                 (NW == 1 ? maxd < (1u << (p.first_cap - 1)) * 3 / 4 : ++c->agg_clean_batches >= 4)) { c->agg_first_cap = p.first_cap - 1; c->agg_clean_batches = 0; }
     }
     { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
       if (force_off && NW == 1 && !c->forbid_long_way) c->agg_off = true; }
@@ -348,7 +352,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             u32 longest = 0; u64 nb = 0; for (int i = 0; i < AG_BATCH; ++i) { longest = std::max(longest, n_cur[i]); nb += n_cur[i]; }
             if (!longest) break;
             static const int max_rung = getenv("HSK_AGG_MAXRUNG") ? atoi(getenv("HSK_AGG_MAXRUNG")) : AG_LOG2CAP_HUGE;     // (tests: stop the ladder early, the listed bins' tasks take the long way)
-            int next = (NW >= 2) ? (cap < AG_LOG2CAP_LARGE ? AG_LOG2CAP_LARGE : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
+            int next = (NW >= 2) ? (cap < AG_LOG2CAP_LARGE ? cap + 1 : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
             if (next > max_rung) next = 0;
             if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
             // More than half of all bins did not fit 2048 slots: this input has (nearly) as many distinct k-mers as k-mers -- reads with
@@ -361,7 +365,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
                 break;
             }
             cap = next;
-            const bool last = (NW >= 2) || cap == AG_LOG2CAP_HUGE;
+            const bool last = (NW >= 2) ? cap == AG_LOG2CAP_LARGE : cap == AG_LOG2CAP_HUGE;
             HIPCHK(c, hipMemsetAsync(p.d_flags + (2 + (cur ^ 1)) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));
             for (int i = 0; i < AG_BATCH; ++i) {
                 AggTask &t = a.t[i];
@@ -449,7 +453,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     HIPCHK(c, hipMemsetAsync(d_flags, 0, 64, c->stream));
     AggExtArgs a; memset(&a, 0, sizeof a);
     AggArgs sa; memset(&sa, 0, sizeof sa);               // the view agg_scan_kernel needs
-    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT; a.nw = NW; a.top_bits = NW >= 2 ? prefix_top_bits(K, NW) : 0;
+    a.lower = L; a.upper = (u32)c->cfg.upper_freq; a.nbins = nbins; a.shift = AG_SHIFT; a.nw = NW; a.top_bits = NW >= 2 ? prefix_top_bits(K, NW) : 0; a.top_sig = NW >= 2 ? 2 * (K - 32 * (NW - 1)) : 64;
     sa.nbins = nbins; sa.shift = AG_SHIFT; sa.nw = NW;
     bool own_scratch[AG_BATCH] = {false};
     u64 ntot = 0;
@@ -472,35 +476,54 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         sa.t[i].bin_cnt = t.bin_cnt; sa.t[i].bin_off = t.bin_cnt; sa.t[i].active = 1;       // (in place: this path scans once)
     }
     // The table ladder, bin by bin (as agg_stage1 / agg_stage2 do for keys without payload: nearly every task has a few outlier
-    // bins, a task-wide retry would run everything on the large table's one workgroup per CU): the small table over all bins,
-    // the bins it could not hold listed; the large table over the listed bins; a bin beyond that sends its task the long way.
-    u32 *d_list; DALLOC(c, d_list, u32 *, (size_t)nbins * 4 * AG_BATCH);
-    struct { u32 flags[2 * AG_BATCH]; u64 total[AG_BATCH]; } h;
+    // bins, a task-wide retry would run everything on the largest table's one workgroup per CU): the first table over all bins,
+    // the bins it could not hold listed; the next table over the listed bins, and so on; a bin beyond the last table sends its
+    // task the long way.  14 + 16 NW bytes of LDS per slot: 1024 / 2048 / 4096 slots for one-word keys (5 / 2 / 1 workgroups per
+    // CU), 1024 / 2048 for two and three words.  The first table follows the previous batches like agg_stage2's (reads with
+    // ~1 % errors: ~900 distinct keys per bin, every bin overflows 1024 slots).
+    constexpr int TOP = NW == 1 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_MEDIUM;
+    u32 *d_list; DALLOC(c, d_list, u32 *, (size_t)nbins * 4 * AG_BATCH * 2);
+    struct { u32 flags[3 * AG_BATCH]; u64 total[AG_BATCH]; } h;
     auto launch = [&](int log2cap, u32 grid_x) {
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = ntot; ep.bytes = ntot * 16; (void)hipEventRecord(ep.a, c->stream); }
-        // (14 + 16 NW bytes of LDS per slot: the second table has 4096 slots for one-word keys, 2048 for two and three words)
-        constexpr int BIG = NW == 1 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_MEDIUM;
         if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_SMALL, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((agg_ext_kernel<BIG, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else if (log2cap == AG_LOG2CAP_MEDIUM || NW > 1) hipLaunchKernelGGL((agg_ext_kernel<AG_LOG2CAP_MEDIUM, NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((agg_ext_kernel<(NW == 1 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_MEDIUM), NW>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     };
     memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_ext_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
-    for (int i = 0; i < AG_BATCH; ++i) { a.t[i].ovf_list = d_list + (size_t)nbins * i; a.t[i].ovf_n = d_flags + AG_BATCH + i; }
-    launch(AG_LOG2CAP_SMALL, nbins);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));
-    u32 longest = 0;
-    for (int i = 0; i < AG_BATCH; ++i) if (a.t[i].active) longest = std::max(longest, std::min(h.flags[AG_BATCH + i], nbins));
-    if (longest) {
-        AggExtArgs keep = a;
-        for (int i = 0; i < AG_BATCH; ++i) {
-            AggExtTask &t = a.t[i];
-            t.active = (keep.t[i].active && h.flags[AG_BATCH + i]) ? 1 : 0; c->stats.agg_retried_tasks += t.active;
-            t.bin_list = t.ovf_list; t.bin_list_n = t.ovf_n; t.ovf_list = nullptr; t.ovf_n = nullptr;
+    int nact = 0; for (int i = 0; i < AG_BATCH; ++i) nact += a.t[i].active ? 1 : 0;
+    int cap = std::min(std::max(c->agg_first_cap, (int)AG_LOG2CAP_SMALL), TOP - 1);     // (never the last table first: its overflows are not counted)
+    const int first_cap = cap;
+    {
+        const AggExtArgs keep = a;
+        int cur = 0;                                        // list the running rung appends to
+        u32 grid_x = nbins;
+        for (bool first = true;; first = false) {
+            const bool last = cap == TOP;
+            for (int i = 0; i < AG_BATCH; ++i) {
+                AggExtTask &t = a.t[i];
+                if (!first) { t.bin_list = d_list + ((size_t)(cur ^ 1) * AG_BATCH + i) * nbins; t.bin_list_n = d_flags + (1 + (cur ^ 1)) * AG_BATCH + i; }
+                t.ovf_list = last ? nullptr : d_list + ((size_t)cur * AG_BATCH + i) * nbins;
+                t.ovf_n = last ? nullptr : d_flags + (1 + cur) * AG_BATCH + i;
+            }
+            if (!last) HIPCHK(c, hipMemsetAsync(d_flags + (1 + cur) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));
+            launch(cap, grid_x);
+            HIPCHK(c, hipGetLastError());
+            if (last) break;
+            HIPCHK(c, hipMemcpyAsync(h.flags, d_flags, sizeof h.flags, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hsk_sync(c, c->stream));
+            u32 longest = 0; u64 listed = 0;
+            for (int i = 0; i < AG_BATCH; ++i) if (keep.t[i].active) { const u32 n = std::min(h.flags[(1 + cur) * AG_BATCH + i], nbins); longest = std::max(longest, n); listed += n; }
+            if (first && nact) {                            // the next batch's first table
+                if (listed * 20 > (u64)nact * nbins) { c->agg_first_cap = std::min(first_cap + 1, TOP - 1); c->agg_clean_batches = 0; }
+                else if (listed == 0 && first_cap > AG_LOG2CAP_SMALL && ++c->agg_clean_batches >= 4) { c->agg_first_cap = first_cap - 1; c->agg_clean_batches = 0; }
+            }
+            if (!longest) break;
+            for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
+            ++cap; cur ^= 1; grid_x = longest;
         }
-        launch(AG_LOG2CAP_LARGE, longest);
         a = keep;
     }
     for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;

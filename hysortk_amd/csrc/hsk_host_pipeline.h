@@ -397,7 +397,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
         }
         int rc;
-        if (xs && slot_agg[sl] && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
+        if (xs && (slot_agg[sl] || fused_ext) && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
             if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
