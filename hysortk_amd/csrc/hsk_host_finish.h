@@ -359,8 +359,9 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             // 5 % errors and more -- and the aggregation is the wrong tool.  No further rungs: the tasks of this batch take the long way
             // now, the batches after it (and later calls on this context) four prefix passes + the tile finish instead of two + tables.
             static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
-            if (adapt && NW == 1 && !c->forbid_long_way && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
-                c->agg_off = true;
+            // (multi-word keys have no tile finish to change to: their tasks just stop climbing a ladder that ends in the long way anyway)
+            if (adapt && !c->forbid_long_way && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
+                if (NW == 1) c->agg_off = true;
                 for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false;
                 break;
             }
@@ -494,6 +495,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     memset(&h, 0, sizeof h);
     hipLaunchKernelGGL(bin_bounds_ext_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     int nact = 0; for (int i = 0; i < AG_BATCH; ++i) nact += a.t[i].active ? 1 : 0;
+    bool hopeless[AG_BATCH] = {false};
     int cap = std::min(std::max(c->agg_first_cap, (int)AG_LOG2CAP_SMALL), TOP - 1);     // (never the last table first: its overflows are not counted)
     const int first_cap = cap;
     {
@@ -521,6 +523,13 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
                 else if (listed == 0 && first_cap > AG_LOG2CAP_SMALL && ++c->agg_clean_batches >= 4) { c->agg_first_cap = first_cap - 1; c->agg_clean_batches = 0; }
             }
             if (!longest) break;
+            // more than half of all bins beyond 2048 slots: (nearly) as many distinct k-mers as k-mers; the listed bins' tasks take the
+            // long way now instead of after the last table
+            static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
+            if (adapt && cap >= AG_LOG2CAP_MEDIUM && listed * 2 > (u64)nact * nbins) {
+                for (int i = 0; i < AG_BATCH; ++i) if (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) hopeless[i] = true;
+                break;
+            }
             for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
             ++cap; cur ^= 1; grid_x = longest;
         }
@@ -535,7 +544,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
     int rc = HSK_OK;
     bool done[AG_BATCH];
     u64 total[AG_BATCH];
-    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; total[i] = h.total[i]; }
+    for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || (!h.flags[i] && !hopeless[i]); total[i] = h.total[i]; }
     AggExtCompactArgs ca; memset(&ca, 0, sizeof ca);
     ca.slot_shift = slot_shift; ca.histo = d_histo; ca.histo_len = histo_len; ca.nbins = nbins; ca.ew = EW;
     bool any = false;
