@@ -225,6 +225,27 @@ struct AggPending {
     hipEvent_t ev = nullptr;
     AggHostRead *h = nullptr;                           // pinned
 };
+// The long way for SEVERAL tasks of a batch at once (input with nearly unique k-mers sends whole batches there): the
+// full-width passes as eight-task launches from the tasks' current order (one task at a time they run at well under half the
+// rate), then the two-pass counter per task.  redo[i]: task i takes it; pay_before: EXTENSION (null otherwise).
+template <int NW>
+static int long_way_batch(hsk_ctx *c, const BatchTask *bt, const bool *redo, int K, const u64 *pay_before, u64 *d_histo, u32 histo_len, TaskOut *outs)
+{
+    BatchTask b2[XCD_BATCH];
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        b2[i] = bt[i];
+        if (!redo[i]) { b2[i].n = 0; continue; }
+        if (bt[i].out_k != bt[i].kA) { std::swap(b2[i].kA, b2[i].kB); std::swap(b2[i].vA, b2[i].vB); }      // the current order becomes the A side
+        c->stats.redone_tasks++;
+    }
+    const auto counted = c->stats.redone_tasks;
+    int rc = sort_batch_device<NW>(c, b2, K, false);
+    c->stats.redone_tasks = counted;                        // (a task the prefix plan of these passes has to redo once more is still one redone task)
+    for (int i = 0; i < XCD_BATCH && rc == HSK_OK; ++i)
+        if (redo[i]) rc = count_task_device<NW>(c, b2[i].out_k, b2[i].out_v, bt[i].n, pay_before ? pay_before[i] : 0, d_histo, histo_len, outs[i]);
+    return rc;
+}
+
 constexpr int AG_LOG2CAP_HUGE = 13;                     // last rung for one-word keys: agg_big_kernel (8192 slots, 1024 threads) on the listed bins
 
 // One rung of the ladder: the aggregation kernel with a 2^log2cap table over all bins (grid_x = nbins) or over the listed
@@ -404,6 +425,15 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         }
     }
     if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(big ? 64 : 256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    if (!big && !c->forbid_long_way && rc == HSK_OK) {
+        bool redo[AG_BATCH]; int nredo = 0;
+        for (int i = 0; i < AG_BATCH; ++i) { redo[i] = bt[i].n != 0 && !done[i]; nredo += redo[i]; }
+        if (nredo >= 3) {
+            for (int i = 0; i < AG_BATCH; ++i) if (redo[i] && p.own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; p.own_scratch[i] = false; }   // (stream-ordered reuse)
+            rc = long_way_batch<NW>(c, bt, redo, p.K, nullptr, d_histo, histo_len, outs);
+            for (int i = 0; i < AG_BATCH; ++i) if (redo[i]) done[i] = true;
+        }
+    }
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
         if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
@@ -561,6 +591,19 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         }
     }
     if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_ext_compact_kernel, dim3(256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
+    {
+        bool redo[AG_BATCH]; int nredo = 0;
+        for (int i = 0; i < AG_BATCH; ++i) { redo[i] = bt[i].n != 0 && !done[i]; nredo += redo[i]; }
+        if (nredo >= 3 && rc == HSK_OK) {
+            HIPCHK(c, hsk_sync(c, c->stream));
+            for (int i = 0; i < AG_BATCH; ++i) if (redo[i]) {
+                if (own_scratch[i]) { c->pool.release(a.t[i].scratch_e); c->pool.release(a.t[i].scratch_p); own_scratch[i] = false; }
+                free_task_out(c, outs[i]);
+            }
+            rc = long_way_batch<NW>(c, bt, redo, K, pay_before, d_histo, histo_len, outs);
+            for (int i = 0; i < AG_BATCH; ++i) if (redo[i]) done[i] = true;
+        }
+    }
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
         // the long way for this task: full-width passes (payload carried) from the current order, then the two-pass counter
