@@ -124,6 +124,7 @@ struct hsk_ctx {
                                        // previous batch, so that reads with errors / low coverage do not pay for a table they overflow anyway
     bool xcd_batch_ok = true;          // hsk_init's census saw workgroups on all eight XCC ids (see xcc_census_kernel)
     int agg_clean_batches = 0;         // EXTENSION: batches in a row whose first table held every bin (four of them: one table size down again)
+    int agg_off_calls = 0;             // calls since agg_off was set
     bool agg_off = false;              // one-word keys without payload: the input has too few copies per k-mer for the LDS aggregation (most bins of a
                                        // batch overflowed the 2048-slot table): batches take four prefix passes + the tile finish from here on
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone

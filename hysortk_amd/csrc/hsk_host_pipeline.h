@@ -653,6 +653,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     memset(out, 0, sizeof *out);
     ResultPriv *rp = new ResultPriv();
     out->priv = rp; out->nw = NW;
+    if (c->agg_off && ++c->agg_off_calls >= 8) { c->agg_off = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
     PhaseTimer pt(c);
     pt.begin(PH_TOTAL);
 
