@@ -124,7 +124,8 @@ struct hsk_ctx {
                                        // previous batch, so that reads with errors / low coverage do not pay for a table they overflow anyway
     bool xcd_batch_ok = true;          // hsk_init's census saw workgroups on all eight XCC ids (see xcc_census_kernel)
     int agg_clean_batches = 0;         // EXTENSION: batches in a row whose first table held every bin (four of them: one table size down again)
-    int agg_off_calls = 0;             // calls since agg_off was set
+    int agg_off_calls = 0;             // calls since agg_off / agg_off_wide was set
+    bool agg_off_wide = false;         // the same for multi-word keys and EXTENSION: no prefix passes + tables, the full-width passes and the two-pass counter
     bool agg_off = false;              // one-word keys without payload: the input has too few copies per k-mer for the LDS aggregation (most bins of a
                                        // batch overflowed the 2048-slot table): batches take four prefix passes + the tile finish from here on
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone

@@ -363,7 +363,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
                  (NW == 1 ? maxd < (1u << (p.first_cap - 1)) * 3 / 4 : ++c->agg_clean_batches >= 4)) { c->agg_first_cap = p.first_cap - 1; c->agg_clean_batches = 0; }
     }
     { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
-      if (force_off && NW == 1 && !c->forbid_long_way) c->agg_off = true; }
+      if (force_off && !c->forbid_long_way) { if (NW == 1) c->agg_off = true; else c->agg_off_wide = true; } }
     // ---- the ladder, bin by bin: the listed bins again one table size up, until no bin is left or the rungs are ----------------
     if (!big && ovf_bins) {
         AggArgs keep = a;
@@ -382,7 +382,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
             // (multi-word keys have no tile finish to change to: their tasks just stop climbing a ladder that ends in the long way anyway)
             if (adapt && !c->forbid_long_way && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
-                if (NW == 1) c->agg_off = true;
+                if (NW == 1) c->agg_off = true; else c->agg_off_wide = true;
                 for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false;
                 break;
             }
@@ -558,6 +558,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
             static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
             if (adapt && cap >= AG_LOG2CAP_MEDIUM && listed * 2 > (u64)nact * nbins) {
                 for (int i = 0; i < AG_BATCH; ++i) if (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) hopeless[i] = true;
+                c->agg_off_wide = true;                      // the batches after this one: no prefix passes and tables at all
                 break;
             }
             for (int i = 0; i < AG_BATCH; ++i) { a.t[i].active = (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) ? 1 : 0; c->stats.agg_retried_tasks += a.t[i].active; }
@@ -565,6 +566,8 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         }
         a = keep;
     }
+    { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as in agg_stage2)
+      if (force_off) c->agg_off_wide = true; }
     for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
     hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);
     HIPCHK(c, hipGetLastError());

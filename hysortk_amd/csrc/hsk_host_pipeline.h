@@ -373,15 +373,21 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         return HSK_OK;
     };
     int slot_prefix[2] = {0, 0};                          // the digit plan a slot's batch was expanded for
-    bool slot_agg[2] = {false, false};                    // ... and whether the aggregating finish follows it (hsk_ctx::agg_off can end that in the middle of a call)
+    // ... and which finish follows it: the aggregation (slot_agg), the grouping aggregation of EXTENSION (slot_fext), or -- once
+    // hsk_ctx::agg_off / agg_off_wide have found the input to hold (nearly) only unique k-mers, possibly in the middle of a call --
+    // the tile finish (one-word keys) / full-width passes and the two-pass counter (everything else); slot_follow: a finish that
+    // wants prefix passes only
+    bool slot_agg[2] = {false, false}, slot_fext[2] = {false, false}, slot_follow[2] = {false, false};
     BatchTask bts[2][XCD_BATCH];
     // one launch expands the eight tasks mine[bpos ..] into the slot's buffers and counts the digits of the passes that follow
     auto issue_expand = [&](size_t bpos, int sl) -> int {
-        slot_agg[sl] = agg && !(NW == 1 && c->agg_off);
-        const int prefix_bits = (slot_agg[sl] || fused_ext) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        slot_agg[sl] = agg && !(NW == 1 ? c->agg_off : c->agg_off_wide);
+        slot_fext[sl] = fused_ext && !c->agg_off_wide;
+        slot_follow[sl] = slot_agg[sl] || slot_fext[sl] || (NW == 1 && fused);
+        const int prefix_bits = (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
-        const int npass = batch_pass_plan<NW>(c, K, fused || fused_ext, prefix_bits, plan);
+        const int npass = batch_pass_plan<NW>(c, K, slot_follow[sl], prefix_bits, plan);
         pt.begin(PH_EXTRACT);
         HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
         ExpandJob jobs[XCD_BATCH];
@@ -397,7 +403,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
         }
         int rc;
-        if (xs && (slot_agg[sl] || fused_ext) && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
+        if (xs && (slot_agg[sl] || slot_fext[sl]) && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
             if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
@@ -440,9 +446,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         const int prefix_bits = slot_prefix[sl];
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
-        else { int rc = sort_batch_device<NW>(c, bt, K, fused || fused_ext, prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
+        else { int rc = sort_batch_device<NW>(c, bt, K, slot_follow[sl], prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
         pt.end(PH_SORT);
-        if (fused_ext) {
+        if (slot_fext[sl]) {
             if constexpr (NW <= 3) {
                 pt.begin(PH_COUNT);
                 TaskOut fo[XCD_BATCH]; u64 pb[XCD_BATCH];
@@ -467,7 +473,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 if (lag && b > 0 && !s2first && pend[sl ^ 1].active) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
                 if (!lag) { rc = finish_stage2(sl, false); if (rc) return rc; }
             }
-        } else if (fused) {
+        } else if (fused && NW == 1 && !ext) {
             if constexpr (NW == 1) {
                 pt.begin(PH_COUNT);
                 TaskOut fo[XCD_BATCH];
@@ -653,7 +659,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     memset(out, 0, sizeof *out);
     ResultPriv *rp = new ResultPriv();
     out->priv = rp; out->nw = NW;
-    if (c->agg_off && ++c->agg_off_calls >= 8) { c->agg_off = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
+    if ((c->agg_off || c->agg_off_wide) && ++c->agg_off_calls >= 8) { c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
     PhaseTimer pt(c);
     pt.begin(PH_TOTAL);
 

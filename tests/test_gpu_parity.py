@@ -588,6 +588,35 @@ def test_fused_finish_equals_two_pass_path(H):
     assert int(outs[0][1]) > 100000
 
 
+@pytest.mark.parametrize("K,EXT", [(31, 1), (51, 0), (77, 0), (51, 1), (31, 0)])
+def test_leaving_the_aggregation_in_the_middle_of_a_call(K, EXT):
+    """hsk_ctx::agg_off / agg_off_wide (set when a batch finds most bins beyond the tables: input with nearly unique k-mers) change
+    the finish of the batches that follow -- tile finish or full-width passes + two-pass counter -- in the middle of a call.
+    HSK_AGG_ADAPT=2 sets them after the first batch of three; lists, counts and payload sets must equal the default's and a
+    second call on the same context (off from the start) must give the same again.  Subprocesses: the switch is read once."""
+    import subprocess, sys, os
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "from hysortk_amd import synth\n"
+            "seqs = list(synth.reads(300000, 150, 40000, 11)) + ['AC' * 75] * 20\n"
+            "dna = H.DnaBuffer.from_sequences(seqs)\n"
+            "c = H.Context(K=%d, M=17, L=1, U=65535, EXT=%d, ntasks=24)\n"
+            "for it in range(2):\n"
+            "    r = c.count(dna, rid_base=5)\n"
+            "    h = hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes())\n"
+            "    if %d:\n"
+            "        own = np.repeat(np.arange(len(r)), r.cnt.astype(np.int64))\n"
+            "        sel = np.concatenate([np.arange(int(o), int(o) + int(n)) for o, n in zip(r.payload_off[:-1], r.cnt)])\n"
+            "        trip = np.stack([own, r.rid[sel].astype(np.int64), r.pos[sel].astype(np.int64)], 1)\n"
+            "        trip = trip[np.lexsort((trip[:, 2], trip[:, 1], trip[:, 0]))]\n"
+            "        h.update(trip.tobytes())\n"
+            "    print(h.hexdigest(), len(r))\n") % (util.ROOT, K, EXT, EXT)
+    outs = []
+    for env in ({}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}):
+        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
+    assert len(outs) == 6 and len({o[0] for o in outs}) == 1, outs
+    assert int(outs[0][1]) > 100000
+
+
 @pytest.mark.parametrize("K,L,U", [(51, 1, 65535), (51, 2, 50), (41, 2, 50), (63, 1, 65535), (35, 2, 50), (33, 1, 65535), (36, 2, 50), (39, 2, 50)])
 def test_two_word_keys_prefix_sort_and_aggregation(H, O, K, L, U):
     """32 < K < 64: two scatter passes on the top 16 bits of the most significant word + aggregation of 128-bit keys in LDS
