@@ -947,6 +947,27 @@ def test_wide_keys_and_extension_sweep_vs_oracle(H, O, seed):
             assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist())), (tag, i)
 
 
+@pytest.mark.parametrize("K,M,EXT", [(5, 3, 0), (7, 4, 0), (9, 5, 1), (11, 7, 0), (13, 6, 1), (15, 9, 0), (16, 11, 0), (19, 17, 1)])
+def test_short_kmers_vs_oracle(H, O, K, M, EXT):
+    """The low end of K (down to keys of 10 bits: fewer than the 16 prefix bits, nearly every prefix bin empty, every k-mer
+    thousands of times) with both task counts (single tasks, whole batches)."""
+    from hysortk_amd import synth
+    seqs = list(synth.reads(40000, 150, 3000, 23)) + ["ACGT" * 30] * 50 + ["A" * 150] * 10
+    dna = H.DnaBuffer.from_sequences(seqs)
+    packed, off, lens = dna.arrays()
+    for ntasks in (3, 16):
+        ores = O.count(packed, off, lens, k=K, m=M, L=1, U=65535, ext=EXT, ntasks=ntasks, rid_base=2, fast=True)
+        with H.Context(K=K, M=M, L=1, U=65535, EXT=EXT, ntasks=ntasks) as c:
+            res = c.count(dna, rid_base=2)
+        tag = (K, M, EXT, ntasks)
+        assert np.array_equal(res.task_off, ores.task_off), tag
+        assert np.array_equal(res.kmers, ores.keys), tag
+        assert np.array_equal(res.cnt, ores.cnt), tag
+        if EXT:
+            sel = np.concatenate([np.arange(int(o), int(o) + int(n)) for o, n in zip(res.payload_off[:-1], res.cnt)])
+            assert sorted(zip(res.rid[sel].tolist(), res.pos[sel].tolist())) == sorted(zip(ores.rid.tolist(), ores.pos.tolist())), tag
+
+
 @pytest.mark.parametrize("K", [31, 51, 77])
 def test_output_text_formatted_on_device(H, O, K, tmp_path):
     """hsk_format_entries: the "KMER\\tcount" lines of write_output_file (reference src/hysortk.cpp:138-164) formatted on the GPU
