@@ -304,7 +304,9 @@ static int check_host_index(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *o
 
 // read_byte_off[r] == sum of (read_len + 3) / 4 over the reads before r?  (what DnaBuffer guarantees, reference src/dnabuffer.cpp:24-31)
 // Four threads: segment sums, then every segment is checked against its base.  Runs beside the GPU's scan.
-static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint64_t nreads)
+// ... and do they end inside the packed buffer?  (A back-to-back index whose summed length runs past packed_bytes is "not fine"
+// here too: the caller's offsets are then checked on the device like any other index, and index_check_kernel rejects them.)
+static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint64_t nreads, uint64_t packed_bytes)
 {
     constexpr int NT = 4;
     uint64_t seg[NT + 1], sum[NT];
@@ -325,7 +327,7 @@ static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint6
         for (auto &x : th) x.join();
     }
     bool all = true; for (int t = 0; t < NT; ++t) all &= ok[t];
-    return all;
+    return all && base[NT - 1] + sum[NT - 1] <= packed_bytes;
 }
 
 // Inputs in pinned host memory (hsk_host_alloc, hipHostMalloc, hipHostRegister) are not copied first: scan_kernel reads the
@@ -336,6 +338,30 @@ static bool zero_copy_enabled()
 {
     static const bool on = !(getenv("HSK_ZERO_COPY") && atoi(getenv("HSK_ZERO_COPY")) == 0);
     return on;
+}
+
+// hsk_count() with a pinned DnaBuffer: only the read lengths travel ahead of the scan, the byte offsets are their prefix sums
+// (roff_*_kernel); the caller's offsets are compared with that layout by host threads while the GPU scans.  Returns a status
+// like upload_input: the caller releases whatever was allocated, on every path.
+static int derive_input(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len, uint64_t nreads, DevInput &d, u64 *&d_given, u64 *&d_tsum)
+{
+    const u64 ntl = (nreads + ROFF_TILE - 1) / ROFF_TILE;
+    DALLOC(c, d.packed, u8 *, packed_bytes + 64);
+    DALLOC(c, d.roff, u64 *, (nreads + 1) * 8);
+    DALLOC(c, d.rlen, u32 *, (nreads + 1) * 4);
+    DALLOC(c, d_given, u64 *, (nreads + 1) * 8);
+    DALLOC(c, d_tsum, u64 *, ntl * 8 + 64);
+    u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
+    *stage = packed_bytes;
+    HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(roff_tilesum_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum);
+    hipLaunchKernelGGL(roff_tilescan_kernel, dim3(1), dim3(PARSE_THREADS), 0, c->stream, d_tsum, ntl);
+    hipLaunchKernelGGL(roff_write_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum, d.roff);
+    HIPCHK(c, hipMemcpyAsync(d.roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
+    // the caller's offsets stay on the host: four threads check them against the back-to-back layout while the GPU scans
+    c->roff_given = d_given; c->roff_host = off;
+    c->roff_check = std::async(std::launch::async, offsets_back_to_back, off, len, nreads, packed_bytes);
+    return HSK_OK;
 }
 
 extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *off, const uint32_t *len,
@@ -359,24 +385,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     u64 *d_given = nullptr, *d_tsum = nullptr;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 5; (void)hipEventRecord(ep.a, c->stream); }
     if (!derive) rc = upload_input(c, zc ? nullptr : packed, packed_bytes, off, len, nreads, d, false);
-    else {
-        const u64 ntl = (nreads + ROFF_TILE - 1) / ROFF_TILE;
-        DALLOC(c, d.packed, u8 *, packed_bytes + 64);
-        DALLOC(c, d.roff, u64 *, (nreads + 1) * 8);
-        DALLOC(c, d.rlen, u32 *, (nreads + 1) * 4);
-        DALLOC(c, d_given, u64 *, (nreads + 1) * 8);
-        DALLOC(c, d_tsum, u64 *, ntl * 8 + 64);
-        u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
-        *stage = packed_bytes;
-        HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(roff_tilesum_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum);
-        hipLaunchKernelGGL(roff_tilescan_kernel, dim3(1), dim3(PARSE_THREADS), 0, c->stream, d_tsum, ntl);
-        hipLaunchKernelGGL(roff_write_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum, d.roff);
-        HIPCHK(c, hipMemcpyAsync(d.roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
-        // the caller's offsets stay on the host: four threads check them against the back-to-back layout while the GPU scans
-        c->roff_given = d_given; c->roff_host = off;
-        c->roff_check = std::async(std::launch::async, offsets_back_to_back, off, len, nreads);
-    }
+    else rc = derive_input(c, packed_bytes, off, len, nreads, d, d_given, d_tsum);
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     c->stats.h2d_bytes += packed_bytes + nreads * 12;
     if (rc == HSK_OK && device_check && !derive) {

@@ -50,7 +50,11 @@ inline RcclApi *rccl_api(std::string *err)
     tried = true;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    // HSK_RCCL_LIB (honoured only when set): another library exporting the same nine entry points, e.g. the stand-in
+    // transport of tests/fakerccl that lets the ranks of tests/test_gpu_rccl.py share ONE GPU (RCCL refuses that)
+    const char *forced = getenv("HSK_RCCL_LIB");
+    if (forced && *forced) { h = dlopen(forced, RTLD_NOW | RTLD_LOCAL); if (!h) { if (err) *err = std::string("dlopen(HSK_RCCL_LIB=") + forced + ") failed: " + dlerror(); return nullptr; } }
+    else for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { if (err) *err = std::string("dlopen(librccl) failed: ") + dlerror(); return nullptr; }
 #define HSK_SYM(field, name) *(void **)(&api.field) = dlsym(h, name); if (!api.field) { if (err) *err = std::string("missing RCCL symbol ") + name; return nullptr; }
     HSK_SYM(GetUniqueId, "ncclGetUniqueId") HSK_SYM(CommInitRank, "ncclCommInitRank") HSK_SYM(CommDestroy, "ncclCommDestroy")
@@ -76,6 +80,10 @@ struct Comm {
 
     bool solo = false;                                            // selftest: treat a one-rank communicator as active
     bool active() const { return comm != nullptr && (nranks > 1 || solo); }
+    // one ncclSend / ncclRecv carries at most this many bytes; longer messages travel as several (both sides cut the same
+    // byte count the same way).  80 Gbp without the per-group overlap puts ~1.9 GB per peer into one message: counts beyond
+    // 2^31 are where collective libraries have broken before.  HSK_RCCL_MSG_MAX: test hook (small pieces).
+    size_t msg_max = (size_t)1 << 30;
 
     static int get_unique_id(void *id128)
     {
@@ -91,6 +99,7 @@ struct Comm {
         api = rccl_api(&last_error);
         if (!api) return -1;
         UidByValue id; memcpy(id.internal, id128, 128);
+        if (const char *mm = getenv("HSK_RCCL_MSG_MAX")) { const long long v = atoll(mm); if (v >= 64) msg_max = (size_t)v; }
         int rc = api->CommInitRank(&comm, nranks_, id, rank_);
         if (rc) { last_error = std::string("ncclCommInitRank: ") + api->GetErrorString(rc); comm = nullptr; return rc; }
         return 0;
@@ -213,33 +222,63 @@ inline void assign_task_groups(int nranks, uint32_t ntasks, const std::vector<in
     for (uint32_t t = 0; t < ntasks; ++t) { const int q = owner[t]; group_of[t] = seen[q] / group_size; ++seen[q]; ngroups = std::max(ngroups, group_of[t] + 1); }
 }
 
+// One ncclGroupStart ... ncclGroupEnd bracket of byte messages.  The group is closed on EVERY path (an early return between
+// the two calls would leave the communicator inside an open group: unusable afterwards, peers blocked); after the first
+// error nothing more is added, end() reports it.  Messages longer than Comm::msg_max travel in pieces.
+struct P2PGroup {
+    Comm &cm; int rc = 0; bool open = false; std::string first_error;
+    explicit P2PGroup(Comm &c) : cm(c) { note(cm.check(cm.api->GroupStart(), "ncclGroupStart")); open = rc == 0; }
+    ~P2PGroup() { if (open) (void)cm.api->GroupEnd(); }
+    void note(int r) { if (r && !rc) { rc = r; first_error = cm.last_error; } }
+    void send(const void *p, size_t bytes, int peer, hipStream_t s, const char *what)
+    {
+        for (size_t o = 0; o < bytes && !rc; o += cm.msg_max)
+            note(cm.check(cm.api->Send((const char *)p + o, std::min(cm.msg_max, bytes - o), RCCL_UINT8, peer, cm.comm, s), what));
+    }
+    void recv(void *p, size_t bytes, int peer, hipStream_t s, const char *what)
+    {
+        for (size_t o = 0; o < bytes && !rc; o += cm.msg_max)
+            note(cm.check(cm.api->Recv((char *)p + o, std::min(cm.msg_max, bytes - o), RCCL_UINT8, peer, cm.comm, s), what));
+    }
+    int end()
+    {
+        if (open) { open = false; note(cm.check(cm.api->GroupEnd(), "ncclGroupEnd")); }
+        if (rc) cm.last_error = first_error;
+        return rc;
+    }
+};
+
 // the grouped send/recv of one plan on stream s (self share: device copy).  Does not synchronise.
+// Every rank posts what the plan says, whether its own count has failed or not (GroupFeeder::drain_after_failure): a rank
+// that stopped taking part would leave its peers blocked in their receives.
 inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &pl, const uint8_t *sm_len, const uint8_t *sm_bytes,
                          const uint32_t *sm_pos, const int32_t *sm_rid, ExchangeBuffers &xb)
 {
     const int nr = cm.nranks, me = cm.rank;
-    int rc;
-    if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return rc;
-    for (int q = 0; q < nr; ++q) {
-        if (q == me) continue;
-        if (pl.send_sup[q]) {
-            if ((rc = cm.check(cm.api->Send(sm_len + pl.send_sup_off[q], pl.send_sup[q], RCCL_UINT8, q, cm.comm, s), "ncclSend(len)"))) return rc;
-            if ((rc = cm.check(cm.api->Send(sm_bytes + pl.send_byte_off[q], pl.send_bytes[q], RCCL_UINT8, q, cm.comm, s), "ncclSend(bytes)"))) return rc;
-            if (ext) {
-                if ((rc = cm.check(cm.api->Send(sm_pos + pl.send_sup_off[q], pl.send_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclSend(pos)"))) return rc;
-                if ((rc = cm.check(cm.api->Send(sm_rid + pl.send_sup_off[q], pl.send_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclSend(rid)"))) return rc;
+    {
+        P2PGroup g(cm);
+        for (int q = 0; q < nr && !g.rc; ++q) {
+            if (q == me) continue;
+            if (pl.send_sup[q]) {
+                g.send(sm_len + pl.send_sup_off[q], pl.send_sup[q], q, s, "ncclSend(len)");
+                g.send(sm_bytes + pl.send_byte_off[q], pl.send_bytes[q], q, s, "ncclSend(bytes)");
+                if (ext) {
+                    g.send(sm_pos + pl.send_sup_off[q], pl.send_sup[q] * 4, q, s, "ncclSend(pos)");
+                    g.send(sm_rid + pl.send_sup_off[q], pl.send_sup[q] * 4, q, s, "ncclSend(rid)");
+                }
+            }
+            if (pl.recv_sup[q]) {
+                g.recv(xb.len + pl.recv_sup_off[q], pl.recv_sup[q], q, s, "ncclRecv(len)");
+                g.recv(xb.bytes + pl.recv_byte_off[q], pl.recv_bytes[q], q, s, "ncclRecv(bytes)");
+                if (ext) {
+                    g.recv(xb.pos + pl.recv_sup_off[q], pl.recv_sup[q] * 4, q, s, "ncclRecv(pos)");
+                    g.recv(xb.rid + pl.recv_sup_off[q], pl.recv_sup[q] * 4, q, s, "ncclRecv(rid)");
+                }
             }
         }
-        if (pl.recv_sup[q]) {
-            if ((rc = cm.check(cm.api->Recv(xb.len + pl.recv_sup_off[q], pl.recv_sup[q], RCCL_UINT8, q, cm.comm, s), "ncclRecv(len)"))) return rc;
-            if ((rc = cm.check(cm.api->Recv(xb.bytes + pl.recv_byte_off[q], pl.recv_bytes[q], RCCL_UINT8, q, cm.comm, s), "ncclRecv(bytes)"))) return rc;
-            if (ext) {
-                if ((rc = cm.check(cm.api->Recv(xb.pos + pl.recv_sup_off[q], pl.recv_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclRecv(pos)"))) return rc;
-                if ((rc = cm.check(cm.api->Recv(xb.rid + pl.recv_sup_off[q], pl.recv_sup[q] * 4, RCCL_UINT8, q, cm.comm, s), "ncclRecv(rid)"))) return rc;
-            }
-        }
+        const int rc = g.end();
+        if (rc) return rc;
     }
-    if ((rc = cm.check(cm.api->GroupEnd(), "ncclGroupEnd"))) return rc;
     if (pl.send_sup[me]) {
         if (hipMemcpyAsync(xb.len + pl.recv_sup_off[me], sm_len + pl.send_sup_off[me], pl.send_sup[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
         if (hipMemcpyAsync(xb.bytes + pl.recv_byte_off[me], sm_bytes + pl.send_byte_off[me], pl.send_bytes[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
@@ -268,7 +307,13 @@ inline int exchange_supermers(Comm &cm, hipStream_t s, Pool &pool, bool ext, int
     xb.len = (uint8_t *)pool.alloc(pl.recv_tot_sup + 64);
     xb.bytes = (uint8_t *)pool.alloc(pl.recv_tot_bytes + 64); xb.nbytes = pl.recv_tot_bytes;
     if (ext) { xb.pos = (uint32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); xb.rid = (int32_t *)pool.alloc(pl.recv_tot_sup * 4 + 64); }
-    if (!xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid))) { cm.last_error = "oom"; return -1; }
+    {   // every rank must have its receive arrays before anybody sends
+        const bool oom = !xb.len || !xb.bytes || (ext && (!xb.pos || !xb.rid));
+        std::vector<uint64_t> none;
+        rc = cm.allreduce_with_status(none, RCCL_MAX, oom, s, pool);
+        if (oom) { cm.last_error = "oom"; return -1; }
+        if (rc) { if (rc > 0) cm.last_error = "a rank ran out of memory before the supermer exchange"; return rc; }
+    }
     // 2. payload: one grouped send/recv per peer and array (self: device copy)
     if ((rc = post_exchange(cm, s, ext, pl, sm_len, sm_bytes, sm_pos, sm_rid, xb))) return rc;
     if (hipStreamSynchronize(s) != hipSuccess) return -2;

@@ -12,6 +12,17 @@
 // ------------------------------------------------------------------------------------------------
 struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; };
 
+// HSK_TEST_FAIL="<rank>:<site>" (tests/test_gpu_rccl.py, read at every call): the named step of that rank fails as if an
+// allocation had returned null.  Sites: sortbuf (before the first task group travels), group1 (the exchange buffers of the
+// second group: peers are already inside the exchange), late (the second batch: everything is in flight).
+static bool test_fail(hsk_ctx *c, const char *site)
+{
+    const char *e = getenv("HSK_TEST_FAIL");
+    if (!e || !*e) return false;
+    const char *colon = strchr(e, ':');
+    return colon && atoi(e) == c->comm.rank && strcmp(colon + 1, site) == 0;
+}
+
 struct GroupFeeder {
     hsk_ctx *c = nullptr;
     int nranks = 1, rank = 0, ngroups = 0;
@@ -26,6 +37,7 @@ struct GroupFeeder {
     std::vector<SupermerStore> *st_all = nullptr;
     std::vector<std::vector<PackJob>> packs;           // [group] byte-packing jobs issued with the group (scratch released with it)
     bool lazy_pack = false;                            // the stores' bytes are produced group by group (pack_group_*)
+    bool live = false;                                 // RCCL: every rank got past the last agreement before the exchange and will post every group
     const std::vector<std::vector<ExchangePlan>> *pl_all = nullptr;     // [rank][group]
     u64 bytes_moved = 0;
 
@@ -42,6 +54,7 @@ struct GroupFeeder {
     int post(int g)
     {
         ExchangeBuffers &b = xb[g]; const ExchangePlan &p = pl[g];
+        if (g == 1 && !draining && test_fail(c, "group1")) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d (injected)", g);
         b.len = (u8 *)c->pool.alloc(p.recv_tot_sup + 64); b.bytes = (u8 *)c->pool.alloc(p.recv_tot_bytes + 64); b.nbytes = p.recv_tot_bytes;
         if (ext) { b.pos = (u32 *)c->pool.alloc(p.recv_tot_sup * 4 + 64); b.rid = (int32_t *)c->pool.alloc(p.recv_tot_sup * 4 + 64); }
         if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid))) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
@@ -104,6 +117,32 @@ struct GroupFeeder {
             packs[released].clear();
             if (arrived[released]) { ev_put(c, arrived[released]); arrived[released] = nullptr; }
         }
+    }
+    // This rank's count has failed after the exchange began (RCCL only).  Its peers still expect its supermers and still send
+    // it theirs: a rank that simply returned would leave them blocked in ncclRecv for ever (the reference dies together there:
+    // MPI_Abort, src/kmerops.cpp:1477).  So the rank drains its own work, hands every device block the failed count allocated
+    // (`keep`: the live blocks before it, i.e. the supermer store stays) back to the pool -- a failed allocation is the usual
+    // reason to be here -- and posts the remaining groups one by one, receiving into buffers it drops at once.  The ranks then
+    // agree on the outcome (run_pipeline) and all return an error.
+    bool draining = false;
+    int drain_after_failure(const std::vector<void *> &keep)
+    {
+        draining = true;
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream);
+        for (int g = 0; g < ngroups; ++g) { xb[g] = ExchangeBuffers(); packs[g].clear(); if (arrived[g]) { ev_put(c, arrived[g]); arrived[g] = nullptr; } }
+        released = posted;
+        c->pool.release_all_but(keep);
+        for (; posted < ngroups; ++posted) {
+            const int g = posted;
+            int rc = post(g); if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+            xb[g].release(c->pool);
+            for (auto &pj : packs[g]) expand_release(c, pj.x);
+            packs[g].clear();
+            if (arrived[g]) { ev_put(c, arrived[g]); arrived[g] = nullptr; }
+            released = g + 1;
+        }
+        return HSK_OK;
     }
     // every rank must take part in every group even when it owns no task of it
     int finish()
@@ -319,7 +358,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         return HSK_OK;
     };
     {
-        const int arc = alloc_sort_buffers();
+        int arc = alloc_sort_buffers();
+        if (!arc && feeder && test_fail(c, "sortbuf")) arc = fail(c, HSK_ERR_OOM, "sort buffers (injected)");
         if (feeder && !feeder->st_all && c->comm.active()) {
             // the largest allocations of the call are behind us: make sure EVERY rank got them before the first task group
             // travels (a rank that gave up here alone would leave its peers blocked in their first send / receive)
@@ -327,6 +367,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             const int st_ = c->comm.allreduce_with_status(none, RCCL_MAX, arc != 0, c->stream, c->pool);
             if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(status) failed: %d (%s)", st_, c->comm.last_error.c_str());
             if (st_ > 0) return arc ? arc : fail(c, HSK_ERR_COMM, "another rank ran out of memory before the supermer exchange");
+            feeder->live = true;                          // from here on a failing rank drains the exchange and the ranks agree at the end (run_pipeline)
         } else if (arc) return arc;
     }
     u64 n_total = 0, pay_total = 0;
@@ -434,6 +475,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
     for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
         const int sl = lag ? (int)(b & 1) : 0;
+        if (b == 1 && feeder && test_fail(c, "late")) return fail(c, HSK_ERR_OOM, "second batch (injected)");
         if (pend[sl].active) { int rc = finish_stage2(sl, false); if (rc) return rc; }       // (only after hsk_ctx::agg_off ended the aggregation in the middle of the call: the slot's buffers are about to be reused)
         if (feeder) {                                   // exposed (not overlapped) part of the exchange
             pt.begin(PH_EXCH);
@@ -802,24 +844,25 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             if (st_ > 0) { for (auto &hv : hin) c->pool.release(hv.d_entries); hin.clear(); return oom ? fail(c, HSK_ERR_OOM, "heavy-hitter receive buffers") : fail(c, HSK_ERR_COMM, "another rank ran out of memory before the heavy-hitter exchange"); }
         }
         Comm &cm = c->comm;
-        if ((rc = cm.check(cm.api->GroupStart(), "ncclGroupStart"))) return fail(c, HSK_ERR_COMM, "%s", cm.last_error.c_str());
         size_t hi = 0;
-        for (size_t i = 0; i < nh && rc == 0; ++i) {
-            const u32 t = hv_tasks[i];
-            if (owner[t] == rank) {
-                HeavyIn &hv = hin[hi++];
-                u64 o = 0;
-                for (int p = 0; p < nranks && rc == 0; ++p) {
-                    const u64 n = Hn[(size_t)p * nh + i];
-                    if (n && p != rank) rc = cm.check(cm.api->Recv((char *)hv.d_entries + o * ew, n * ew, RCCL_UINT8, p, cm.comm, c->stream), "ncclRecv(heavy list)");
-                    o += n;
+        {
+            P2PGroup grp(cm);
+            for (size_t i = 0; i < nh && !grp.rc; ++i) {
+                const u32 t = hv_tasks[i];
+                if (owner[t] == rank) {
+                    HeavyIn &hv = hin[hi++];
+                    u64 o = 0;
+                    for (int p = 0; p < nranks; ++p) {
+                        const u64 n = Hn[(size_t)p * nh + i];
+                        if (n && p != rank) grp.recv((char *)hv.d_entries + o * ew, n * ew, p, c->stream, "ncclRecv(heavy list)");
+                        o += n;
+                    }
+                } else if (hlists[t].n) {
+                    grp.send(hlists[t].entries, hlists[t].n * ew, owner[t], c->stream, "ncclSend(heavy list)");
                 }
-            } else if (hlists[t].n) {
-                rc = cm.check(cm.api->Send(hlists[t].entries, hlists[t].n * ew, RCCL_UINT8, owner[t], cm.comm, c->stream), "ncclSend(heavy list)");
             }
+            if (grp.end()) return fail(c, HSK_ERR_COMM, "heavy-hitter list exchange failed: %s", cm.last_error.c_str());
         }
-        const int rc2 = cm.check(cm.api->GroupEnd(), "ncclGroupEnd");
-        if (rc || rc2) return fail(c, HSK_ERR_COMM, "heavy-hitter list exchange failed: %s", cm.last_error.c_str());
         hi = 0;
         for (size_t i = 0; i < nh; ++i) {                                   // own share: device copy
             const u32 t = hv_tasks[i];
@@ -833,7 +876,23 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     }
     pt.end(PH_EXCH);
     ProcExtra ex; ex.heavy_in = &hin;
+    const std::vector<void *> before_rank = (fed && c->comm.active()) ? c->pool.snapshot() : std::vector<void *>();
     int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
+    if (fed && feeder.live) {
+        // Leaving together, part two (part one: the all-reduces with status up to the first task group).  A rank whose count failed
+        // while the groups were travelling has kept its side of the exchange going (drain_after_failure); now the ranks tell each
+        // other how it went, and if one of them failed they all return an error -- the failed rank its own, the others HSK_ERR_COMM.
+        if (rc != HSK_OK) {
+            char keep_msg[sizeof c->err]; memcpy(keep_msg, c->err, sizeof keep_msg);
+            const int drc = feeder.drain_after_failure(before_rank);
+            if (drc) return drc;                                                   // the transport itself is broken: nothing more to agree on
+            memcpy(c->err, keep_msg, sizeof keep_msg);
+        }
+        std::vector<u64> none;
+        const int st_ = c->comm.allreduce_with_status(none, RCCL_MAX, rc != HSK_OK, c->stream, c->pool);
+        if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(final status) failed: %d (%s)", st_, c->comm.last_error.c_str());
+        if (st_ > 0 && rc == HSK_OK) rc = fail(c, HSK_ERR_COMM, "another rank failed while the supermers were travelling; this rank's result is dropped");
+    }
     for (auto &hv : hin) c->pool.release(hv.d_entries);
     if (nranks > 1 && !fed) xb.release(c->pool); else free_store(c, st);
     return rc;

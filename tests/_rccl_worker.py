@@ -1,9 +1,12 @@
-"""Worker of tests/test_gpu_rccl.py: one of WORLD_SIZE processes, one GPU each.  Runs the PRODUCT path end to end --
-hsk_comm_init (RCCL communicator; the id travels over a gloo group) and hsk_count on this rank's share of the reads --
-and dumps the rank's list.  Nothing here touches the oracle: the parent test compares."""
+"""Worker of tests/test_gpu_rccl.py: one of WORLD_SIZE processes.  Runs the PRODUCT path end to end -- hsk_comm_init (RCCL
+communicator, or the stand-in transport named by HSK_RCCL_LIB when the ranks share one GPU; the id travels over a gloo
+group) and hsk_count on this rank's share of the reads -- and dumps the rank's list.  With spec["fail"] = "<rank>:<site>"
+the first count runs with that failure injected (HSK_TEST_FAIL) and must fail on EVERY rank; the count is then repeated on
+the same contexts and communicator without it.  Nothing here touches the oracle: the parent test compares."""
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -25,12 +28,26 @@ def main():
     dna = H.DnaBuffer.from_sequences(mine)
     rid_base = comm.exscan_sum(dna.size())
     assert rid_base == first
-    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], EXT=spec["EXT"], ntasks=spec["ntasks"], device=comm.local_rank)
+    device = int(os.environ.get("HSK_FORCE_DEVICE", comm.local_rank))      # several ranks on one GPU (stand-in transport)
+    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], EXT=spec["EXT"], ntasks=spec["ntasks"], device=device)
     ctx.comm_init(comm)
-    res = ctx.count(dna, rid_base=rid_base)
+    failure = None
+    if spec.get("fail"):
+        os.environ["HSK_TEST_FAIL"] = spec["fail"]
+        t0 = time.time()
+        try:
+            ctx.count(dna, rid_base=rid_base)
+            failure = dict(code=0, msg="", seconds=time.time() - t0)
+        except H.HskError as e:
+            failure = dict(code=int(e.status), msg=str(e), seconds=time.time() - t0)
+        del os.environ["HSK_TEST_FAIL"]
+        comm.barrier()
+    res = ctx.count(dna, rid_base=rid_base)                                # (after a failure: same context, same communicator)
     st = ctx.stats()
     out = dict(kmers=res.kmers, cnt=res.cnt, task_off=res.task_off, histo=res.histo, heavy=np.array([st["heavy_tasks"]]),
                total_kmers=np.array([res.info["total_kmers"]]))
+    if failure is not None:
+        out.update(fail_code=np.array([failure["code"]]), fail_seconds=np.array([failure["seconds"]]), fail_msg=np.array([failure["msg"]]))
     if spec["EXT"]:
         out.update(payload_off=res.payload_off, pos=res.pos, rid=res.rid)
     np.savez(spec["out"] % rank, **out)

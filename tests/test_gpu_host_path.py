@@ -49,6 +49,34 @@ def test_invalid_read_index_is_rejected_on_the_device():
     assert np.array_equal(good.kmers, again.kmers) and np.array_equal(good.cnt, again.cnt)
 
 
+def test_pinned_index_past_the_buffer_is_rejected():
+    """The same two bad indices from PINNED arrays (offsets derived from the lengths on the device, the caller's offsets compared on
+    host threads): a back-to-back index whose last read runs past packed_bytes used to pass that comparison and be counted
+    truncated; it must be rejected like the pageable one."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 1000
+    packed, off, lens = synth.packed_reads(500000, 150, n, 9)             # 38 bytes per read: 40 MB, zero-copy ingest
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=8) as c:
+        good = c.count((pp, po, pl))
+        pl[-1] = 4000                                            # leaves the packed buffer (the offsets still lie back to back)
+        with pytest.raises(H.HskError):
+            c.count((pp, po, pl))
+        pl[-1] = lens[-1]
+        po[n // 2] = po[n // 2 - 1]                              # overlaps its predecessor
+        with pytest.raises(H.HskError):
+            c.count((pp, po, pl))
+        po[:] = off
+        again = c.count((pp, po, pl))                            # the context stays usable
+        ref = c.count((packed, off, lens))
+    for y in (pp, po, pl):
+        H.pinned_free(y)
+    assert np.array_equal(good.kmers, again.kmers) and np.array_equal(good.cnt, again.cnt)
+    assert np.array_equal(good.kmers, ref.kmers) and np.array_equal(good.cnt, ref.cnt)
+
+
 def test_pinned_input_with_gaps_between_reads():
     """hsk_count() on a pinned buffer derives the read offsets from the read lengths on the device (only the lengths travel ahead of
     the scan) and compares them with the caller's offsets afterwards; a buffer whose reads do NOT lie back to back (the C ABI allows

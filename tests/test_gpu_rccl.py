@@ -1,8 +1,12 @@
-"""The real N>1 transport: two fresh processes, one GPU each, form an RCCL communicator (hsk_comm_init) and run hsk_count
-on their halves of the reads -- grouped ncclSend/ncclRecv per task group on the second stream (post_exchange,
-csrc/hsk_comm.h), all-reduces of task sizes / size matrix, heavy-hitter list exchange.  Per-rank lists must equal what
-the virtual-rank driver (hsk_count_loopback, device copies in place of RCCL) gives on one GPU, and their union the
-reference's 2-rank output.  Needs two GPUs: SKIPPED (not passed) on a one-GPU box."""
+"""The real N>1 path: two fresh processes form a communicator (hsk_comm_init) and run hsk_count on their halves of the reads
+-- grouped ncclSend/ncclRecv per task group on the second stream (post_exchange, csrc/hsk_comm.h), all-reduces of task sizes
+/ size matrix with the ranks' status, heavy-hitter list exchange, leaving together after a failure.  Per-rank lists must equal
+what the virtual-rank driver (hsk_count_loopback, device copies in place of the transport) gives on one GPU, and their union
+the reference's 2-rank output.
+
+With two GPUs the ranks take one each and RCCL carries the data.  On a ONE-GPU box (RCCL refuses two ranks on one device) both
+ranks open the same GPU (HSK_FORCE_DEVICE=0) and HSK_RCCL_LIB points csrc/hsk_comm.h at tests/fakerccl, a stand-in for the
+nine entry points it binds that moves the messages through shared memory: the product code that runs is the same."""
 import json
 import os
 import subprocess
@@ -21,18 +25,28 @@ def _ngpu():
     return torch.cuda.device_count()
 
 
-def _run_ranks(world, spec, tmp_path, port):
+def _transport_env():
+    """{} with two GPUs (RCCL); the stand-in transport and a shared device otherwise."""
+    if _ngpu() >= 2 and not os.environ.get("HSK_TEST_FORCE_FAKERCCL"):
+        return {}
+    from tests import fakerccl
+    return {"HSK_RCCL_LIB": fakerccl.build(), "HSK_FORCE_DEVICE": "0", "HSK_FAKERCCL_TIMEOUT": "90"}
+
+
+def _run_ranks(world, spec, tmp_path, port, extra_env=None):
     procs = []
+    tenv = _transport_env()
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **tenv)
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(util.ROOT, "tests", "_rccl_worker.py"), json.dumps(spec)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=600)[0].decode())
-        except subprocess.TimeoutExpired:
+            outs.append(p.communicate(timeout=420)[0].decode())
+        except subprocess.TimeoutExpired:                  # the watchdog: a hang of the ranks fails the test, the children are killed by pid
             for q in procs:
                 q.kill()
             raise
@@ -69,8 +83,6 @@ CASES = {
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_two_ranks_over_rccl(case, tmp_path):
-    if _ngpu() < 2:
-        pytest.skip("needs two GPUs (this box shows %d): the RCCL exchange between ranks cannot run" % _ngpu())
     import hysortk_amd as H
     from hysortk_amd import synth
     cfg = dict(CASES[case])
@@ -110,3 +122,58 @@ def test_two_ranks_over_rccl(case, tmp_path):
         for g in got:
             lines += ["%s\t%d" % (s, int(c_)) for s, c_ in zip(util.result_strings(g["kmers"], 31), g["cnt"])]
         assert sorted(lines) == open(util.GOLDEN + "/count_k31_np2.txt").read().splitlines()
+
+
+def _small_case(tmp_path):
+    from hysortk_amd import synth
+    seqs = list(synth.reads(150000, 150, 12000, 23))
+    reads_json = str(tmp_path / "reads.json")
+    json.dump(seqs, open(reads_json, "w"))
+    return seqs, reads_json
+
+
+@pytest.mark.parametrize("site", ["sortbuf", "group1", "late"])
+def test_failing_together(site, tmp_path):
+    """One rank's allocation fails -- before the first task group travels (sortbuf), after it (group1: the exchange buffers of
+    the second group) or in the middle of the batches (late).  BOTH ranks must return an error, quickly, nobody hangs, and the
+    same contexts and communicator count correctly afterwards (reference: the ranks die together, src/kmerops.cpp:1477)."""
+    import hysortk_amd as H
+    cfg = dict(K=31, M=17, L=2, U=50, EXT=0, ntasks=40)          # 20 tasks per rank: three task groups, three batches
+    seqs, reads_json = _small_case(tmp_path)
+    spec = dict(cfg, reads=reads_json, out=str(tmp_path / "rank%d.npz"), fail="1:" + site)
+    got = _run_ranks(2, spec, tmp_path, 29650 + ["sortbuf", "group1", "late"].index(site))
+    assert int(got[1]["fail_code"][0]) == 4, str(got[1]["fail_msg"])                                   # HSK_ERR_OOM: its own error
+    assert "injected" in str(got[1]["fail_msg"][0])
+    assert int(got[0]["fail_code"][0]) == 7 and "another rank" in str(got[0]["fail_msg"][0]), str(got[0]["fail_msg"])     # HSK_ERR_COMM
+    assert float(got[0]["fail_seconds"][0]) < 60 and float(got[1]["fail_seconds"][0]) < 60
+    with H.Context(**cfg) as c:
+        want, _ = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in _split(H, seqs, 2)])
+    for r in range(2):
+        assert np.array_equal(got[r]["task_off"], want[r].task_off) and np.array_equal(got[r]["kmers"], want[r].kmers) and np.array_equal(got[r]["cnt"], want[r].cnt), (site, r)
+
+
+def test_long_messages_travel_in_pieces(tmp_path):
+    """HSK_RCCL_MSG_MAX: every send / receive longer than 64 KB is cut into several (what 80 Gbp without the group overlap needs
+    beyond 2^31 bytes per message); same lists."""
+    import hysortk_amd as H
+    cfg = dict(K=31, M=17, L=2, U=50, EXT=1, ntasks=16)
+    seqs, reads_json = _small_case(tmp_path)
+    spec = dict(cfg, reads=reads_json, out=str(tmp_path / "rank%d.npz"))
+    for overlap in ("1", "0"):
+        got = _run_ranks(2, spec, tmp_path, 29660 + int(overlap), {"HSK_RCCL_MSG_MAX": "65536", "HSK_OVERLAP": overlap})
+        with H.Context(**cfg) as c:
+            want, _ = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in _split(H, seqs, 2)])
+        for r in range(2):
+            assert np.array_equal(got[r]["kmers"], want[r].kmers) and np.array_equal(got[r]["cnt"], want[r].cnt), (overlap, r)
+
+
+def test_bench_launcher_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` starts its ranks itself (torch.distributed.run child) and prints one JSON line with n_gpus = 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **_transport_env())
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--scale", "0.01", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    js = json.loads(line)
+    assert js["n_gpus"] == 2 and js["value"] > 0 and js["config"]["exchange"].startswith("RCCL")
+    assert js["phases_ms_per_step"]["ms_exchange"] >= 0
