@@ -357,7 +357,7 @@ def main():
                                                          "algorithm's byte count, not bytes this build moves (2 passes + LDS aggregation, ~49 B per k-mer) and so not a roofline fraction"}},
             "kernels": kernels,
             "host_syncs_per_step": st["host_syncs"] / S, "host_waits_covered_per_step": st["host_waits_covered"] / S,
-            "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks", "onepass_misses") if k_ in st},
+            "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks") if k_ in st},
             "phases_ms_per_step": {k_: v / S for k_, v in sorted(phase.items())},
         }
         ctx.synth_free(dp, do, dl)

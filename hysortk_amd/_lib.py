@@ -47,6 +47,9 @@ class Stats(C.Structure):
 
 FLAG_PROFILE = 1
 FLAG_KEEP_DEVICE = 2
+FLAG_PLAIN_CLASSIFIER = 4
+FLAG_NO_AGGREGATION = 8
+FLAG_FULL_SORT = 16
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/hsk.h declares (tests/test_abi.py checks the library exports all of them)

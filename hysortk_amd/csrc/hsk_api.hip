@@ -369,6 +369,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
 {
     if (!c || !out || (nreads && (!off || !len)) || (packed_bytes && !packed)) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     tmark(nullptr); tmark("hsk_count enter");
     const bool device_check = nreads >= (1u << 20);          // a serial host loop over 10^8 reads costs more than the whole count
     int rc = device_check ? HSK_OK : check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
@@ -409,6 +410,7 @@ extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packe
     if (!c || !out || (nreads && (!d_off || !d_len)) || (packed_bytes && !d_packed)) return HSK_ERR_INVALID_ARG;
     if (((uintptr_t)d_packed & 3) != 0) return fail(c, HSK_ERR_INVALID_ARG, "d_packed must be 4-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     // the kernels index roff[r+1]: build the (nreads+1)-entry offset array
     u64 *roff; DALLOC(c, roff, u64 *, (nreads + 1) * 8);
     if (nreads) HIPCHK(c, hipMemcpyAsync(roff, d_off, nreads * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -425,6 +427,7 @@ extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *
 {
     if (!c || nranks < 1 || nranks > 64 || !packed || !packed_bytes || !off || !len || !nreads || !outs) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     std::vector<DevInput> in(nranks);
     int rc = HSK_OK;
     for (int r = 0; r < nranks && rc == HSK_OK; ++r) {

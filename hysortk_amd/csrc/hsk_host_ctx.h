@@ -131,6 +131,10 @@ struct hsk_ctx {
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 
+// HSK_FLAG_NO_AGGREGATION / HSK_FLAG_FULL_SORT of the context whose call is running on this thread (set by the counting entry
+// points): the plan switches below (agg_enabled, hybrid_enabled, finish_enabled) are asked in places that have no context at hand
+static thread_local int g_plan_flags = 0;
+
 static int fail(hsk_ctx *c, int code, const char *fmt, ...)
 {
     if (c) {

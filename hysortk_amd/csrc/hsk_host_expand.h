@@ -100,10 +100,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_kernel<NW, false>, EXP_THREADS, dyn);
         occ = (e == hipSuccess && nb > 0) ? nb : 4;
     }
-    // pipelined with the sort of the previous batch (second stream): take only part of every CU, the rest is the sort's
-    static const int share_pct = getenv("HSK_EXPAND_SHARE") ? atoi(getenv("HSK_EXPAND_SHARE")) : 100;
-    const int occ_use = (stream != c->stream) ? std::max(1, occ * share_pct / 100) : occ;
-    u32 rw = (u32)std::max(1, occ_use * 256 / (8 * nt));
+    u32 rw = (u32)std::max(1, occ * 256 / (8 * nt));
     rw = (u32)std::min<u64>(rw, (max_tiles + 7) / 8);
     a.row_workers = std::max<u32>(rw, 1);
     a.nrows = max_tiles;

@@ -83,31 +83,12 @@ static void host_release(hsk_ctx *c, ResultPriv *rp, void *p)
 
 static bool finish_enabled();
 static bool agg_enabled();
-// One scatter pass + aggregation over 8-bit prefix bins (hsk_agg.h: agg_big_kernel) for tasks of up to ONEPASS_MAX_TASK
-// k-mers; HSK_ONEPASS=0 keeps two passes + 16-bit bins for every task.
-constexpr u64 ONEPASS_TASK_KMERS = 1ULL << 24;          // auto_ntasks aims at this many base positions per task
-constexpr u64 ONEPASS_MAX_TASK = 3ULL << 23;            // larger tasks: bins with too many distinct keys for the LDS table
-// EXPERIMENTAL, off unless HSK_ONEPASS=1: at 10 Gbp it means ~600 tasks of 13 M k-mers, processed in batches of 64
-// (one scatter launch per batch).  It removes 16 B of HBM traffic per k-mer and the scatter phase drops from 57 to 36
-// ms, but the whole step is slower today (226 ms against 168 ms): the aggregation over 51 000-record bins runs one
-// 1024-thread workgroup per CU (112 KB of LDS) and only reaches 20 % issue utilisation (82 ms against 27 ms), placing
-// supermers into 600 tasks costs +8 ms and 76 small expand launches +8 ms.
-static bool onepass_enabled()
-{
-    static const bool on = getenv("HSK_ONEPASS") && atoi(getenv("HSK_ONEPASS")) != 0;
-    return on;
-}
-
 static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
 {
     // one task per ~2^28 k-mers (2 GB of 8-byte keys): large enough to saturate the chip, small
     // enough that key + ping-pong + look-back buffers of one task stay a small share of HBM
     u64 est = packed_bytes * 4 * (u64)std::max(nranks, 1);
     u64 t = (est + (1ULL << 28) - 1) >> 28;
-    // one-word keys without payload: tasks small enough for ONE scatter pass + aggregation over 8-bit prefix bins
-    // (as many as HSK_MAX_TASKS allows; beyond that the tasks grow and the two-pass plan takes over by itself)
-    if (c->nw == 1 && c->cfg.extension == 0 && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled())
-        t = std::max(t, std::min<u64>((est + ONEPASS_TASK_KMERS - 1) / ONEPASS_TASK_KMERS, HSK_MAX_TASKS / 8 * 8));
     t = std::max<u64>(t, (u64)std::max(nranks, 1));
     // tasks are sorted eight at a time (one per XCD): give every rank a multiple of eight when there are that many -- and eight
     // as soon as the rank has ~2^25 base positions: from there on the batch path (expand fused with the first pass, aggregation)
@@ -124,7 +105,7 @@ static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
 static bool finish_enabled()
 {
     static const bool on = !(getenv("HSK_FUSED_FINISH") && atoi(getenv("HSK_FUSED_FINISH")) == 0);
-    return on;
+    return on && !(g_plan_flags & HSK_FLAG_FULL_SORT);
 }
 
 template <int NW>
@@ -199,7 +180,7 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
 static bool agg_enabled()
 {
     static const bool on = !(getenv("HSK_AGG") && atoi(getenv("HSK_AGG")) == 0);
-    return on;
+    return on && !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
 }
 
 // The aggregating finish of a batch in two stages, so that the host never has to wait for the GPU with nothing queued
@@ -209,9 +190,7 @@ static bool agg_enabled()
 //   agg_stage2  (called after the NEXT batch's expand / scatter / stage 1 have been enqueued) waits for that event,
 //               retries the tasks whose bins overflowed with the large table, sizes the outputs exactly, launches the
 //               compaction and sends tasks the tables cannot take the long way.
-// prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way;
-// prefix_bits = 8: bins of the top 8 bits (one scatter pass), agg_big_kernel; a task it cannot take is reported in
-// outs[i].failed (the caller orders it on 8 more bits and comes back with prefix_bits = 16).
+// prefix_bits = 16: bins of the top 16 bits (two scatter passes), small tables with a retry ladder and the long way.
 struct AggHostRead { u32 flags[AG_BATCH]; u32 maxd[AG_BATCH]; u32 ovf[2][AG_BATCH]; u64 total[AG_BATCH]; };   // mirrors the device control block (+ totals)
 struct AggPending {
     bool active = false;
@@ -293,7 +272,7 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     p = AggPending();
     const u32 L = (u32)c->cfg.lower_freq;
     p.slot_shift = L >= 2 ? 1 : 0;                      // a bin of n records keeps at most n / L entries
-    p.big = prefix_bits == 8;
+    p.big = false;                                      // (8-bit bins: the one-pass experiment of rounds 1-2, removed)
     p.nbins = 1u << prefix_bits; p.K = K;
     p.h = (AggHostRead *)((char *)c->pinned + c->pinned_bytes - 4096 + (size_t)slot * 512);
     memset(p.h, 0, sizeof *p.h);
@@ -453,15 +432,6 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_off); c->pool.release(p.d_flags); c->pool.release(p.d_list[0]); c->pool.release(p.d_list[1]);
     p.active = false;
     return rc;
-}
-
-// both stages back to back (callers that do not pipeline their batches)
-template <int NW>
-static int agg_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 /*max_task*/, u64 *d_histo, u32 histo_len, TaskOut *outs, int prefix_bits = AG_PREFIX_BITS)
-{
-    AggPending p;
-    int rc = agg_stage1<NW>(c, bt, K, prefix_bits, 0, p); if (rc) return rc;
-    return agg_stage2<NW>(c, p, d_histo, histo_len, outs, false);
 }
 
 // ---- EXTENSION: two passes + grouping aggregation (hsk_agg.h: agg_ext_kernel) ---------------------------------------

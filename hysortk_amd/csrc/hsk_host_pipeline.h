@@ -239,71 +239,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const u32 EMPTY_TASK = ~0u;
     TaskSegs empty_segs;
     std::vector<TaskOut> touts(ntasks);
-    std::vector<u32> mine_done;                          // tasks finished by the one-pass loop below
-    // ---- the one-pass plan (HSK_ONEPASS=1): batches of up to 64 small tasks -------------------------------------
-    // expand (8 tasks per launch, digit histogram of the top 8 bits) -> ONE scatter pass over all tasks of the batch in
-    // one launch -> aggregation over 8-bit prefix bins (8 tasks per launch); tasks whose bins overflow the LDS table are
-    // ordered on the next 8 bits too and finished over 16-bit bins.  Single GPU only (the exchange feeds groups of 8).
-    if constexpr (NW == 1) {
-        const bool op = !ext && !feeder && batch_enabled && onepass_enabled() && hybrid_enabled() && finish_enabled() && agg_enabled() &&
-                        max_task <= ONEPASS_MAX_TASK && !mine.empty() && !(ex && ex->heavy_in && !ex->heavy_in->empty());
-        if (op) {
-            const int nbmax = (int)std::min<size_t>(MANY_MAX, (mine.size() + 7) / 8 * 8);
-            std::vector<u64 *> kAm(nbmax, nullptr), kBm(nbmax, nullptr);
-            for (int i = 0; i < nbmax; ++i) { DALLOC(c, kAm[i], u64 *, max_task * 8 + 64); DALLOC(c, kBm[i], u64 *, max_task * 8 + 64); }
-            u64 *d_gh; DALLOC(c, d_gh, u64 *, (size_t)nbmax * MAX_PASSES * 256 * 8);
-            PassDesc plan1[MAX_PASSES];
-            const int np1 = make_hybrid_plan(plan1, 8, 0);
-            TaskInput dflt1; dflt1.len = x_len; dflt1.src = x_src; dflt1.pos = x_pos; dflt1.rid = x_rid;
-            for (size_t mb = 0; mb < mine.size(); mb += MANY_MAX) {
-                const int nreal = (int)std::min<size_t>(MANY_MAX, mine.size() - mb);
-                const int nb = (nreal + 7) / 8 * 8;
-                BatchTask bt[MANY_MAX];
-                pt.begin(PH_EXTRACT);
-                HIPCHK(c, hipMemsetAsync(d_gh, 0, (size_t)nb * MAX_PASSES * 256 * 8, c->stream));
-                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
-                    ExpandJob jobs[XCD_BATCH];
-                    for (int i = 0; i < XCD_BATCH; ++i) {
-                        BatchTask &b = bt[c0 + i]; b = BatchTask(); b.kA = kAm[c0 + i]; b.kB = kBm[c0 + i];
-                        jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs;
-                        if (c0 + i >= nreal) continue;
-                        const u32 t = mine[mb + c0 + i];
-                        b.n = segs[t].nkmers;
-                        jobs[i].ts = &segs[t]; jobs[i].sm_len = dflt1.len; jobs[i].src = dflt1.src; jobs[i].sm_pos = dflt1.pos; jobs[i].sm_rid = dflt1.rid;
-                        jobs[i].keys = b.kA; jobs[i].vals = nullptr; jobs[i].ghist = d_gh + (size_t)(c0 + i) * MAX_PASSES * 256;
-                    }
-                    int rc = expand_batch<NW>(c, jobs, XCD_BATCH, np1, plan1); if (rc) return rc;
-                }
-                pt.end(PH_EXTRACT);
-                pt.begin(PH_SORT);
-                { int rc = sort_many_onepass<NW>(c, bt, nb, d_gh); if (rc) return rc; }
-                pt.end(PH_SORT);
-                pt.begin(PH_COUNT);
-                for (int c0 = 0; c0 < nb; c0 += XCD_BATCH) {
-                    TaskOut fo[XCD_BATCH];
-                    int rc = agg_finish_batch_device<1>(c, bt + c0, K, max_task, d_histo, histo_len, fo, 8); if (rc) return rc;
-                    BatchTask b2[XCD_BATCH]; bool any_miss = false;
-                    for (int i = 0; i < XCD_BATCH; ++i) {
-                        b2[i] = BatchTask();
-                        if (!fo[i].failed) continue;
-                        any_miss = true; c->stats.onepass_misses++;
-                        b2[i].n = bt[c0 + i].n; b2[i].kA = bt[c0 + i].out_k; b2[i].kB = (bt[c0 + i].out_k == bt[c0 + i].kA) ? bt[c0 + i].kB : bt[c0 + i].kA;
-                    }
-                    if (any_miss) {
-                        rc = sort_batch_device<NW>(c, b2, K, true, AG_PREFIX_BITS, nullptr); if (rc) return rc;
-                        TaskOut f2[XCD_BATCH];
-                        rc = agg_finish_batch_device<1>(c, b2, K, max_task, d_histo, histo_len, f2, AG_PREFIX_BITS); if (rc) return rc;
-                        for (int i = 0; i < XCD_BATCH; ++i) if (fo[i].failed) fo[i] = f2[i];
-                    }
-                    for (int i = 0; i < XCD_BATCH; ++i) if (c0 + i < nreal) touts[mine[mb + c0 + i]] = fo[i];
-                }
-                pt.end(PH_COUNT);
-            }
-            for (int i = 0; i < nbmax; ++i) { c->pool.release(kAm[i]); c->pool.release(kBm[i]); }
-            c->pool.release(d_gh);
-            mine_done.swap(mine);                            // nothing left for the two-pass loops
-        }
-    }
     const bool forced = ex && ex->force_batch && batch_enabled;
     // a caller's task count below eight (the reference's default for one rank is five): three to seven tasks of some size still
     // go faster as one padded batch (5/8 of the batch path's rate) than one by one on the single-task path (about 1/3 of it)
@@ -380,7 +315,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // should the list outgrow it, the early copies are abandoned and everything is copied again at the end.
     const bool keep = keep_dev;
     static const bool early_enabled = !(getenv("HSK_EARLY_D2H") && atoi(getenv("HSK_EARLY_D2H")) == 0);
-    bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty()) && mine_done.empty();
+    bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty());
     u64 *early_buf = nullptr; u64 early_cap = 0, early_used = 0, early_kmers = 0;
     std::vector<u8> copied(ntasks, 0);
     std::vector<EvPair> d2h_ev;
@@ -504,15 +439,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 // the previous batch first: this batch's expand and scatter pass are queued behind its aggregation, so the
                 // wait for its totals does not idle the GPU, and its compaction (and result copy) starts one kernel earlier
                 // (stage 2 of the previous batch BEFORE this batch's stage 1 would start its result copy one kernel earlier, but a
-                // device-to-host copy running beside agg_finish_kernel stretches a batch from 19 to 32 ms: measured, off)
-                static const bool s2first = getenv("HSK_STAGE2_FIRST") && atoi(getenv("HSK_STAGE2_FIRST")) != 0;
-                if (lag && b > 0 && s2first && pend[sl ^ 1].active) { int rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                // device-to-host copy running beside agg_finish_kernel stretches a batch from 19 to 32 ms: measured in round 2, gone)
                 pt.begin(PH_COUNT);
                 int rc = agg_stage1<NW>(c, bt, K, prefix_bits, sl, pend[sl]);
                 pt.end(PH_COUNT);
                 if (rc) return rc;
                 pend_pos[sl] = pos;
-                if (lag && b > 0 && !s2first && pend[sl ^ 1].active) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
+                if (lag && b > 0 && pend[sl ^ 1].active) { rc = finish_stage2(sl ^ 1, true); if (rc) return rc; }
                 if (!lag) { rc = finish_stage2(sl, false); if (rc) return rc; }
             }
         } else if (fused && NW == 1 && !ext) {
@@ -562,7 +495,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.end(PH_COUNT);
     }
     for (u32 t : mine) { if (t == EMPTY_TASK) continue; touts[t].pay_base = pay_before[t]; n_total += touts[t].n; pay_total += touts[t].npay; }
-    for (u32 t : mine_done) { n_total += touts[t].n; pay_total += touts[t].npay; }
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
     free_sort_scratch(c, sc);

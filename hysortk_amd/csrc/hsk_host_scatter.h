@@ -89,9 +89,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
         occ = (e == hipSuccess && nb > 0) ? nb : 2;
     }
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * (ext ? 16 : 8 * NW); (void)hipEventRecord(ep.a, stream); }
-    // beside the sort of the previous batch (second stream): HSK_SCATTER_SHARE percent of the resident workgroups
-    static const int share_pct = getenv("HSK_SCATTER_SHARE") ? atoi(getenv("HSK_SCATTER_SHARE")) : 100;
-    const u32 grid = (stream != c->stream) ? std::max(8u, (u32)occ * 256u * (u32)share_pct / 100u) : (u32)occ * 256u;
+    const u32 grid = (u32)occ * 256u;
     static const bool xs_generic = getenv("HSK_SCATTER_GENERIC") && atoi(getenv("HSK_SCATTER_GENERIC")) != 0;        // (tests: the default k through the generic instance)
     if constexpr (NW == 1) {
         if (ext) hipLaunchKernelGGL((expand_scatter_kernel<1, true>), dim3(grid), dim3(XS_THREADS), 0, stream, a);

@@ -33,7 +33,7 @@ static int make_hybrid_plan(PassDesc *out, int prefix_bits = 64 - HYBRID_SHIFT, 
 static bool hybrid_enabled()
 {
     static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
-    return on;
+    return on && !(g_plan_flags & HSK_FLAG_FULL_SORT);
 }
 // Two- and three-word keys take the prefix plan when the aggregating finish follows.  Where the most significant word carries
 // fewer than the 16 prefix bits (K - 32 (NW - 1) < 8 bases), the prefix continues in the top bits of the word below it
@@ -80,8 +80,7 @@ struct SortScratch {
 template <int NW, bool HAS_VAL, typename LB>
 static void launch_onesweep(hsk_ctx *c, const SortArgs &a, u32 ntiles)
 {
-    static const int pad = getenv("HSK_SORT_LDS_PAD") ? atoi(getenv("HSK_SORT_LDS_PAD")) : 0;   // experiment knob: extra LDS per workgroup lowers residency
-    hipLaunchKernelGGL((onesweep_kernel<NW, HAS_VAL, LB>), dim3(ntiles), dim3(SORT_THREADS), (size_t)pad, c->stream, a);
+    hipLaunchKernelGGL((onesweep_kernel<NW, HAS_VAL, LB>), dim3(ntiles), dim3(SORT_THREADS), 0, c->stream, a);
 }
 
 // Sorts n records in bufA (keys) / valA using bufB / valB as the ping-pong buffer.  On return
@@ -308,74 +307,6 @@ static int sort_batch_device(hsk_ctx *c, BatchTask *bt, int K, bool finish_follo
         }
     }
     c->pool.release(d_lookback); if (!d_ghist_pre) c->pool.release(d_ghist); c->pool.release(d_gbase); c->pool.release(d_tickets);
-    return rc;
-}
-
-// ---- the one-pass plan: ONE scatter pass (top 8 bits) over `nb` tasks in ONE launch (onesweep_many_kernel) ------
-// d_ghist: [nb][MAX_PASSES][256], histogram of pass 0 (bits 56..63) counted by expand_batch.  nb is a multiple of 8.
-constexpr int MANY_MAX = 64;
-template <int NW>
-static int sort_many_onepass(hsk_ctx *c, BatchTask *bt, int nb, u64 *d_ghist)
-{
-    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
-    constexpr int TILE = SortTile<NW>::TILE;
-    const int per_xcd = nb / 8;
-    std::vector<u64> hh((size_t)nb * MAX_PASSES * 256), hb((size_t)nb * 256, 0);
-    HIPCHK(c, hipMemcpyAsync(hh.data(), d_ghist, hh.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));
-    u64 ntiles[MANY_MAX]; size_t lb_off[MANY_MAX + 1]; lb_off[0] = 0;
-    u64 ntot = 0;
-    for (int i = 0; i < nb; ++i) {
-        bt[i].out_k = bt[i].kA; bt[i].out_v = bt[i].vA;
-        u64 run = 0; bool trivial = false;
-        for (int d = 0; d < 256; ++d) { const u64 v = hh[((size_t)i * MAX_PASSES) * 256 + d]; if (v == bt[i].n) trivial = true; hb[(size_t)i * 256 + d] = run; run += v; }
-        ntiles[i] = (bt[i].n < 2 || trivial) ? 0 : (bt[i].n + TILE - 1) / TILE;      // one digit value only: already "sorted"
-        if (bt[i].n >= (1ULL << 30)) return fail(c, HSK_ERR_INTERNAL, "one-pass plan on a task of 2^30 keys");
-        lb_off[i + 1] = lb_off[i] + (size_t)ntiles[i] * 256 * 4;
-        if (ntiles[i]) ntot += bt[i].n;
-    }
-    if (lb_off[nb] == 0) return HSK_OK;
-    u64 *d_gbase; u32 *d_tk, *d_pre; void *d_lb; SortArgs *d_tasks;
-    DALLOC(c, d_gbase, u64 *, (size_t)nb * 256 * 8);
-    DALLOC(c, d_tk, u32 *, (size_t)(nb + 8) * 4 + 64);                 // task tickets, then the 8 XCD counters
-    DALLOC(c, d_pre, u32 *, (size_t)8 * (per_xcd + 1) * 4);
-    DALLOC(c, d_lb, void *, lb_off[nb] + 256);
-    DALLOC(c, d_tasks, SortArgs *, sizeof(SortArgs) * nb);
-    HIPCHK(c, hipMemsetAsync(d_tk, 0, (size_t)(nb + 8) * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(d_lb, 0, lb_off[nb], c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_gbase, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream));
-    std::vector<SortArgs> ta(nb); std::vector<u32> pre((size_t)8 * (per_xcd + 1), 0);
-    u64 max_xcd = 0;
-    for (int x = 0; x < 8; ++x) {
-        u32 run = 0;
-        for (int j = 0; j < per_xcd; ++j) { pre[(size_t)x * (per_xcd + 1) + j] = run; run += (u32)ntiles[x + 8 * j]; }
-        pre[(size_t)x * (per_xcd + 1) + per_xcd] = run;
-        max_xcd = std::max<u64>(max_xcd, run);
-    }
-    for (int i = 0; i < nb; ++i) {
-        SortArgs &a = ta[i]; memset(&a, 0, sizeof a);
-        a.keys_in = bt[i].kA; a.keys_out = bt[i].kB; a.vals_in = nullptr; a.vals_out = nullptr; a.n = bt[i].n; a.ntiles = ntiles[i];
-        a.word = NW - 1; a.shift = 56; a.bits = 8; a.unstable = unstable_first_pass() ? 1 : 0;      // a single pass before an aggregation
-        a.gbase = d_gbase + (size_t)i * 256; a.lookback = (char *)d_lb + lb_off[i]; a.ticket = d_tk + i; a.err = c->d_err;
-    }
-    HIPCHK(c, hipMemcpyAsync(d_tasks, ta.data(), sizeof(SortArgs) * nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_pre, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));                       // ta / pre / hb are host stack memory
-    ManySortArgs m; m.tasks = d_tasks; m.xcd_prefix = d_pre; m.xcd_counter = d_tk + nb; m.per_xcd = per_xcd;
-    const u32 grid = (u32)(8 * (max_xcd + max_xcd / 8) + 64);
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 0; ep.keys = ntot; ep.bytes = 2 * ntot * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
-    hipLaunchKernelGGL((onesweep_many_kernel<NW, false, u32>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, m);
-    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-    HIPCHK(c, hipGetLastError());
-    std::vector<u32> tk(nb + 8);
-    HIPCHK(c, hipMemcpyAsync(tk.data(), d_tk, (size_t)(nb + 8) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));
-    int rc = HSK_OK;
-    for (int i = 0; i < nb && rc == HSK_OK; ++i) {
-        if (tk[i] < ntiles[i]) rc = fail(c, HSK_ERR_INTERNAL, "XCD %d did not drain sort task %d (%u of %llu tiles)", i & 7, i, tk[i], (unsigned long long)ntiles[i]);
-        if (ntiles[i]) bt[i].out_k = bt[i].kB;
-    }
-    c->pool.release(d_gbase); c->pool.release(d_tk); c->pool.release(d_pre); c->pool.release(d_lb); c->pool.release(d_tasks);
     return rc;
 }
 

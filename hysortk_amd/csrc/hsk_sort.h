@@ -318,33 +318,6 @@ __global__ __launch_bounds__(SORT_THREADS) void onesweep_multi_kernel(MultiSortA
 }
 
 
-// Many small tasks in one launch (the one-pass plan sorts tasks of ~2^24 keys: eight of them do not fill the chip for
-// long enough, a launch of 64 does).  XCD x owns the tasks x, x+8, x+16, ... and takes them in turn: a workgroup draws
-// a number g from its XCD's counter, g picks the task through the XCD's tile prefix (exactly ntiles workgroups land on
-// every task), and onesweep_tile draws the tile inside that task as before.  Look-back words stay XCD-local.
-struct ManySortArgs {
-    const SortArgs *tasks;      // [8 * per_xcd], task of XCD x at index x + 8 * j
-    const u32 *xcd_prefix;      // [8][per_xcd + 1] exclusive tile prefix of the XCD's tasks
-    u32 *xcd_counter;           // [8] zeroed
-    int per_xcd;
-};
-
-template <int NW, bool HAS_VAL, typename LB>
-__global__ __launch_bounds__(SORT_THREADS) void onesweep_many_kernel(ManySortArgs m)
-{
-    __shared__ u32 s_pick;
-    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
-    if (threadIdx.x == 0) s_pick = atomicAdd(&m.xcd_counter[xcc], 1u);
-    __syncthreads();
-    const u32 g = s_pick;
-    const u32 *pre = m.xcd_prefix + xcc * (m.per_xcd + 1);
-    if (g >= pre[m.per_xcd]) return;                         // this XCD's tasks are fully claimed
-    int j = 0;
-    while (pre[j + 1] <= g) ++j;
-    __syncthreads();                                         // s_pick is not needed any more (onesweep_tile has its own LDS)
-    onesweep_tile<NW, HAS_VAL, LB, true>(m.tasks[xcc + 8 * j]);
-}
-
 
 // ------------------------------------------------------------------------------------------------------
 // Hybrid finish for one-word keys: after LSD passes over the TOP bits only (hi_shift..63) the array is

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HSK_ABI_VERSION 2
+#define HSK_ABI_VERSION 3
 
 typedef enum {
     HSK_OK = 0,
@@ -59,6 +59,14 @@ typedef struct {
 #define HSK_FLAG_PROFILE      1   /* HIP-event timing of every radix scatter launch (hsk_stats) */
 #define HSK_FLAG_KEEP_DEVICE  2   /* hsk_count_device leaves the result in HBM (entries_dev) */
 #define HSK_FLAG_PLAIN_CLASSIFIER 4 /* PLAIN_CLASSIFIER: no heavy-hitter pre-aggregation (kmerops.cpp:109-113) */
+/* Which algorithm orders and counts the k-mers of a task (ABI 3).  Default: two radix scatter passes on the top 16 key bits,
+ * then one LDS hash aggregation per 16-bit prefix bin -- the fast plan for sequencing data, where every k-mer repeats about
+ * `coverage` times; the library leaves it by itself when the input turns out to hold (nearly) only unique k-mers. */
+#define HSK_FLAG_NO_AGGREGATION 8   /* never aggregate in LDS tables: four scatter passes on the top 32 bits + an in-LDS finish per
+                                       tile (one-word keys), the full sort below for every other record shape */
+#define HSK_FLAG_FULL_SORT     16   /* the reference's own algorithm: LSD radix sort over ALL key bytes of every task
+                                       (sort_task, kmerops.cpp:1382) + adjacent-equal merge-count over the sorted array
+                                       (count_sorted_kmers, kmerops.cpp:1410); nothing fused, nothing skipped */
 
 typedef struct hsk_ctx hsk_ctx;
 
@@ -118,7 +126,7 @@ typedef struct {
     int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
     int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
     int64_t  heavy_tasks;         /* heavy-hitter tasks this rank pre-aggregated and shipped as k-mer lists (multi-GPU) */
-    int64_t  onepass_misses;      /* tasks the one-pass plan (8-bit prefix bins) could not finish; they took two more passes */
+    int64_t  onepass_misses;      /* always 0 (the one-pass experiment of rounds 1-2 is gone; the field keeps the struct layout) */
     /* --- ABI 2 --- */
     uint64_t scan_launches;       /* scan_kernel (minimizers + supermer records): launches, packed read bytes, duration */
     uint64_t scan_bytes;
