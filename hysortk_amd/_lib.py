@@ -59,7 +59,7 @@ SYMBOLS = [
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
     "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
     "hsk_comm_get_unique_id", "hsk_comm_init", "hsk_comm_destroy", "hsk_comm_selftest",
-    "hsk_synth_reads", "hsk_synth_reads_err", "hsk_synth_free", "hsk_memcpy_d2h", "hsk_pack_fasta",
+    "hsk_synth_reads", "hsk_synth_reads_err", "hsk_synth_free", "hsk_memcpy_d2h", "hsk_pack_fasta", "hsk_copy_peak",
 ]
 
 _lib = None
@@ -128,5 +128,6 @@ def load():
     L.hsk_pack_fasta.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hsk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]
+    L.hsk_copy_peak.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L

@@ -289,6 +289,12 @@ class Context:
         buf = (C.c_char * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
         self._check(self.lib.hsk_comm_init(self.h, comm.size, comm.rank, buf))
 
+    def copy_peak(self, nbytes=1 << 32, iters=3):
+        """GB/s (read + written) of a plain 16-byte-per-lane HBM copy on this GPU: the measured yardstick beside the 8 TB/s spec."""
+        g = C.c_double(0)
+        self._check(self.lib.hsk_copy_peak(self.h, nbytes, iters, C.byref(g)))
+        return float(g.value)
+
     def comm_selftest(self):
         """One-rank RCCL communicator on this GPU: all-reduce and grouped send/recv to self, results checked."""
         self._check(self.lib.hsk_comm_selftest(self.h))

@@ -881,6 +881,50 @@ extern "C" int hsk_memcpy_d2h(hsk_ctx *c, void *dst, const void *d_src, uint64_t
     return HSK_OK;
 }
 
+// The yardstick for "fraction of what HBM delivers": a plain copy, 16 bytes per lane, every workgroup streaming its own
+// contiguous slice (MI355X_MICROARCH.md measures 6.29 TB/s = 79 % of the 8 TB/s spec this way).  bytes read + bytes written
+// per launch; the best of `iters` launches counts.
+__global__ __launch_bounds__(256) void copy_peak_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, u64 n16)
+{
+    const u64 per = (n16 + gridDim.x - 1) / gridDim.x;
+    const u64 lo = (u64)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    u64 i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {                    // four loads in flight per lane
+        const uint4 a = src[i], b = src[i + 256], c_ = src[i + 512], d = src[i + 768];
+        dst[i] = a; dst[i + 256] = b; dst[i + 512] = c_; dst[i + 768] = d;
+    }
+    for (; i < hi; i += 256) dst[i] = src[i];
+}
+
+extern "C" int hsk_copy_peak(hsk_ctx *c, uint64_t bytes, int iters, double *gbs)
+{
+    if (!c || !gbs || bytes < (1u << 20) || iters < 1) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    *gbs = 0;
+    const u64 n16 = bytes / 16;
+    uint4 *a, *b;
+    DALLOC(c, a, uint4 *, n16 * 16); DALLOC(c, b, uint4 *, n16 * 16);
+    HIPCHK(c, hipMemsetAsync(a, 0x5a, n16 * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(b, 0, n16 * 16, c->stream));
+    hipEvent_t e0 = ev_get(c), e1 = ev_get(c);
+    double best = 0;
+    for (int grid : {2048, 4096, 8192, 16384}) {
+        for (int it = 0; it < iters; ++it) {
+            (void)hipEventRecord(e0, c->stream);
+            hipLaunchKernelGGL(copy_peak_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, n16);
+            (void)hipEventRecord(e1, c->stream);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) best = std::max(best, 2.0 * (double)n16 * 16 / (ms * 1e-3) / 1e9);
+        }
+    }
+    ev_put(c, e0); ev_put(c, e1);
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(a); c->pool.release(b);
+    *gbs = best;
+    return HSK_OK;
+}
+
 // diagnostic build only: phase clock sums of the onesweep kernel (zeros in the product build)
 extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
 {

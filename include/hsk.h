@@ -275,6 +275,10 @@ int hsk_pack_fasta(hsk_ctx *ctx, const char *text, uint64_t text_bytes, const ui
                    const uint32_t *line_bases, const uint32_t *line_width, uint64_t nrec,
                    void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
 int hsk_memcpy_d2h(hsk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+/* Measurement aid (ABI 3): what a plain HBM copy reaches on this GPU -- a hand-written kernel, 16 bytes per lane, `bytes` read and
+ * `bytes` written per launch, best of `iters` launches over four grid sizes; *gbs = 2 * bytes / time.  bench.py quotes the
+ * kernels' achieved GB/s against the 8 TB/s spec AND against this figure. */
+int hsk_copy_peak(hsk_ctx *ctx, uint64_t bytes, int iters, double *gbs);
 
 #ifdef __cplusplus
 }
