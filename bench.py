@@ -15,16 +15,24 @@ N=8: 80 Gbp), so the minimizer exchange is real; scaling is weak.
 python -m torch.distributed.run, one process per GPU); under a launcher (WORLD_SIZE set) this file is a rank.
 
 Rank 0 prints ONE JSON line:
-  value / ms_per_step   the device-resident rate above (`value` never includes PCIe)
-  roofline              the HBM-bound kernel (radix scatter pass): algorithmic bytes per launch (2 x 8 B x keys)
-                        / average launch duration from HIP events on the launch stream inside the timed region;
-                        .whole_path: the step against the PMC-measured traffic of profiles/traffic.json
-  kernels               the five kernels that make up the step, ms per step and what bounds each
-  e2e_host              (N = 1) the metric as SURVEY 8(d) defines it: wall time of hsk_count() from a DnaBuffer in
-                        (pinned) host RAM to the KmerListS entries in host RAM, L=15/U=40, with its PCIe shares
-  cpu_baseline          the CPU path on the host cores on a bounded sample (1/`--cpu-div` of the workload): the
-                        real reference binary built by oracle/build_ref.sh when it travelled ("reference"; best of
-                        several ranks x threads layouts, its entry count checked), else the C restatement ("port")
+  value / ms_per_step   the device-resident rate above (inputs resident in HBM when the timed region starts, as the bench
+                        contract asks; `value` never includes PCIe).  The same figure again under `device_resident`.
+  host_to_host          (N = 1) the metric exactly as SURVEY 8(d) and the reference's own timer define it (src/hysortk.cpp:58,91,
+                        "Overall kmer counting (Excluding I/O)"): wall time of hsk_count() from a DnaBuffer in (pinned) host RAM
+                        to the KmerListS entries in host RAM, L=15/U=40, with its PCIe shares
+  roofline              the TIME-DOMINANT kernel of this run: algorithmic bytes per launch / average launch duration from HIP
+                        events on the launch stream inside the timed region, against the 8 TB/s spec and against the copy rate
+                        measured in this run (hsk_copy_peak: hand-written 16-byte-per-lane copy); .whole_path: the step against
+                        the PMC-measured traffic of profiles/traffic.json
+  kernels               the kernels that make up the step, ms per step and what bounds each
+  variants              (N = 1) short legs of the other record shapes and plans, 3 steps each, device-resident: K=51 (two-word
+                        keys), EXTENSION=1, the same workload without the LDS aggregation, with the reference's own algorithm
+                        (LSD over all key bytes + merge-count: the path BASELINE.json's north_star names, against SURVEY 8(d)'s
+                        fixed 152.3 B per k-mer), and uniform random reads (every k-mer once, L=1: the worst case for output)
+  cpu_baseline          the CPU path on the host cores on a bounded sample (1/`--cpu-div` of the workload): the real reference
+                        binary built by oracle/build_ref.sh with the same L=15/U=40 when it travelled ("reference"; best of
+                        several ranks x threads layouts), else the C restatement ("port").  The GPU counts the same sample and
+                        its histogram must equal the reference's (`sample_check`).
 """
 import argparse
 import json
@@ -57,6 +65,7 @@ def parse_args():
     ap.add_argument("--cpu-div", type=int, default=20, help="cpu_baseline sample = workload / this")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (N = 1)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the legs of the other record shapes and plans (N = 1)")
     ap.add_argument("--error-rate", type=float, default=0.0, help="substitution errors per base in the synthetic reads (informational runs; the headline workload is error-free)")
     ap.add_argument("--ext", type=int, default=0)
     ap.add_argument("--k", type=int, default=31, help="k-mer size (informational runs; the headline metric is K=31)")
@@ -86,27 +95,41 @@ def write_fasta_sample(path, packed, nreads):
             f.write("".join("r\t%d\t%d\t%d\t%d\n" % (READ_LEN, i * w + 3, READ_LEN, READ_LEN + 1) for i in range(a, min(a + step, nreads))))
 
 
-def cpu_baseline(ctx, genome_len, nreads, seed, ncores, fraction):
-    """Times the CPU path on a bounded sample of the same workload; returns the JSON object."""
+def parse_histogram(text):
+    m = re.search(r"#count\tnumkmers\n((?:\d+\t\d+\n)*)", text)
+    return {int(l.split("\t")[0]): int(l.split("\t")[1]) for l in m.group(1).splitlines()} if m else None
+
+
+def cpu_baseline(H, local, genome_len, nreads, seed, ncores, fraction):
+    """Times the CPU path on a bounded sample of the same workload (same K, M, L, U as the GPU leg) and counts the sample on the
+    GPU as well: the three histograms (reference binary, C restatement, HIP) must be equal.  Returns the JSON object."""
     from oracle import hsk_oracle as O
+    ctx = H.Context(K=K, M=M, L=L, U=U, device=local)
     dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed)
+    gres = ctx.count_device(dp, nb, do, dl, nreads)
+    gpu_hist = {int(c): int(v) for c, v in enumerate(gres.histo) if v and c >= 1}
+    gpu_entries = len(gres)
+    del gres
     packed = ctx.d2h(dp, nb)
     ctx.synth_free(dp, do, dl)
+    ctx.close()
     nbr = (READ_LEN + 3) // 4
     off = np.arange(nreads, dtype=np.uint64) * np.uint64(nbr)
     lens = np.full(nreads, READ_LEN, dtype=np.uint32)
     nk = nreads * (READ_LEN - K + 1)
-    sample = "S-reads(G=%d, c=%d): %d x %d-bp reads, %d k-mers = 1/%d of the GPU workload" % (genome_len, COVERAGE, nreads, READ_LEN, nk, round(1 / fraction))
-    # --- the C restatement (OpenMP over reads and tasks), filter off like the reference build below
+    sample = "S-reads(G=%d, c=%d): %d x %d-bp reads, %d k-mers = 1/%d of the GPU workload, L=%d U=%d" % (genome_len, COVERAGE, nreads, READ_LEN, nk, round(1 / fraction), L, U)
+    # --- the C restatement (OpenMP over reads and tasks)
     t0 = time.time()
-    ores = O.count(packed, off, lens, k=K, m=M, L=1, U=65535, ntasks=max(ncores * 2, 8), fast=True)
+    ores = O.count(packed, off, lens, k=K, m=M, L=L, U=U, ntasks=max(ncores * 2, 8), fast=True)
     t_port = time.time() - t0
-    n_distinct = int(ores.cnt.size)
+    port_hist = parse_histogram(O.histogram_text(ores.cnt)) or {}
+    n_entries = int(ores.cnt.size)
     del ores
+    check = {"gpu_entries": gpu_entries, "port_entries": n_entries, "gpu_equals_port": gpu_hist == port_hist and gpu_entries == n_entries}
     port = {"value": nk / t_port, "unit": "k-mers/s", "cores": ncores, "kind": "port", "sample": sample, "sample_fraction": fraction,
-            "seconds": round(t_port, 3), "entries": n_distinct}
+            "seconds": round(t_port, 3), "entries": n_entries, "sample_check": check}
     # --- the real reference, if its binary travelled and runs here
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "k31", "hysortk_ref")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "k31b", "hysortk_ref")          # oracle/build_ref.sh k31b 31 17 15 40 0 2
     mpiexec = "/opt/conda/bin/mpiexec"
     if os.path.exists(ref_bin) and os.path.exists(mpiexec):
         try:
@@ -118,28 +141,42 @@ def cpu_baseline(ctx, genome_len, nreads, seed, ncores, fraction):
             layouts = [(r, max(1, ncores // r)) for r in (8, 16, 32, 64) if r <= ncores]
             if ncores < 16:
                 layouts.append((max(1, ncores // 2), 2))
-            tried, best = [], None
+            tried, best, ref_hist = [], None, None
             t_leg = time.time()
-            for ranks, thr in dict.fromkeys(layouts):
-                if ranks > nreads or time.time() - t_leg > 150:
-                    continue
+
+            def run_ref(ranks, thr, bind):
+                nonlocal best, ref_hist
                 e = dict(env, OMP_NUM_THREADS=str(thr))
-                p = subprocess.run([mpiexec, "-n", str(ranks), ref_bin, fa], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                cmd = [mpiexec] + (["-bind-to", bind] if bind else []) + ["-n", str(ranks), ref_bin, fa]
+                p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
                 m = re.search(r"Overall kmer counting \(Excluding I/O\):\s*\n\s*total time \(user seconds\):\s*([0-9.]+)", p.stdout)
-                hist = re.search(r"#count\tnumkmers\n((?:\d+\t\d+\n)*)", p.stdout)
-                entries = sum(int(l.split("\t")[1]) for l in hist.group(1).splitlines()) if hist else -1
-                ok = p.returncode == 0 and m is not None and entries == n_distinct      # oversubscribed, the reference silently drops entries
-                tried.append({"ranks": ranks, "threads": thr, "seconds": float(m.group(1)) if m else None, "entries": entries, "entries_ok": entries == n_distinct})
+                hist = parse_histogram(p.stdout)
+                ok = p.returncode == 0 and m is not None and hist == gpu_hist     # oversubscribed, the reference silently drops entries
+                tried.append({"ranks": ranks, "threads": thr, "bind": bind or "none", "seconds": float(m.group(1)) if m else None,
+                              "entries": sum(hist.values()) if hist else -1, "histogram_equals_gpu": hist == gpu_hist})
                 if ok and (best is None or float(m.group(1)) < best[0]):
-                    best = (float(m.group(1)), ranks, thr)
+                    best = (float(m.group(1)), ranks, thr, bind or "none")
+                    ref_hist = hist
+
+            for ranks, thr in dict.fromkeys(layouts):
+                if ranks <= nreads and time.time() - t_leg < 100:
+                    run_ref(ranks, thr, None)
+            if best:                                   # the best layout again with its ranks pinned (hydra + hwloc): NUMA placement is what the layouts differ by
+                b_ranks, b_thr = best[1], best[2]
+                for bind in ("hwthread:%d" % b_thr, "core:%d" % max(1, b_thr // 2)):
+                    if time.time() - t_leg < 140:
+                        run_ref(b_ranks, b_thr, bind)
             for f_ in (fa, fa + ".fai"):
                 os.remove(f_)
             os.rmdir(tmp)
             if best:
+                check["reference_entries"] = sum(ref_hist.values())
+                check["gpu_equals_reference"] = ref_hist == gpu_hist
+                check["histogram_bins"] = len(gpu_hist)
                 return {"value": nk / best[0], "unit": "k-mers/s", "cores": ncores, "kind": "reference", "sample_fraction": fraction,
-                        "sample": sample + "; reference built with L=1 U=65535 (filter off), RADULS, best of the layouts below: %d ranks x %d threads, "
-                        "its own 'Overall kmer counting (Excluding I/O)' timer (src/hysortk.cpp:58,91); entry count checked against the C restatement" % (best[1], best[2]),
-                        "seconds": best[0], "entries": n_distinct, "layouts": tried, "port": port}
+                        "sample": sample + "; reference built with the same L / U, RADULS, best of the layouts below: %d ranks x %d threads (mpiexec -bind-to %s), "
+                        "its own 'Overall kmer counting (Excluding I/O)' timer (src/hysortk.cpp:58,91)" % (best[1], best[2], best[3]),
+                        "seconds": best[0], "entries": n_entries, "layouts": tried, "sample_check": check, "port": port}
             port["reference_layouts"] = tried
         except Exception as e:  # the baseline must never break the bench line
             port["reference_error"] = str(e)[:200]
@@ -186,23 +223,35 @@ def launch_ranks(a):
     return rc
 
 
-def measured_copy_peak(torch):
-    """Device-to-device copy of 4 GiB, best of 5: GB/s of bytes read + written (the 'measured copy peak' of SURVEY 8d)."""
-    n = 1 << 32
-    a = torch.empty(n, dtype=torch.uint8, device="cuda")
-    b = torch.empty(n, dtype=torch.uint8, device="cuda")
-    a.zero_()
-    best = 0.0
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        best = max(best, 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del a, b
-    torch.cuda.empty_cache()
-    return best
+def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads, seed, error_rate, steps, ref_bytes_per_kmer):
+    """One short device-resident leg of another record shape / plan: k-mers/s, ms per step, the scatter passes' GB/s."""
+    ctx = H.Context(K=KK, M=M, L=Lv, U=Uv, EXT=ext, device=local, profile=True, keep_device=True, plan=plan)
+    dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed, error_rate=error_rate)
+    r = ctx.count_device(dp, nb, do, dl, nreads)          # warm-up: pools, the adaptive choices (first table, aggregation on / off)
+    del r
+    ctx.stats(reset=True)
+    t0 = time.perf_counter()
+    info = None
+    for _ in range(steps):
+        r = ctx.count_device(dp, nb, do, dl, nreads)
+        info = dict(r.info, n=len(r))
+        del r
+    dt = (time.perf_counter() - t0) / steps
+    st = ctx.stats(reset=True)
+    ctx.synth_free(dp, do, dl)
+    ctx.close()
+    nk = nreads * (READ_LEN - KK + 1)
+    out = {"name": name, "what": note, "K": KK, "EXT": ext, "L": Lv, "U": Uv, "plan": plan or "default", "error_rate": error_rate, "kmers": nk, "steps": steps,
+           "value": nk / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3, "device_ms_total": info["ms_total"], "entries": info["n"], "ntasks": info["ntasks"],
+           "phases_ms": {k_: round(v, 2) for k_, v in info.items() if k_.startswith("ms_")},
+           "scatter_pass": {"launches_per_step": st["scatter_launches"] / steps, "ms_per_step": st["scatter_ms"] / steps,
+                            "GBs": (st["scatter_bytes"] / (st["scatter_ms"] * 1e-3) / 1e9) if st["scatter_ms"] > 0 else None},
+           "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks") if k_ in st}}
+    if ref_bytes_per_kmer:
+        out["reference_algorithm_GBs"] = ref_bytes_per_kmer * nk / dt / 1e9
+        out["reference_algorithm_frac_of_hbm_peak"] = out["reference_algorithm_GBs"] / HBM_PEAK_GBS
+        out["reference_algorithm_bytes_per_kmer"] = ref_bytes_per_kmer
+    return out
 
 
 def e2e_host_leg(H, KK, ext, ntasks, local, genome_len, nreads, seed, steps):
@@ -313,17 +362,33 @@ def main():
             except Exception:
                 pass
         rec = 8 * ((KK + 31) // 32)
-        copy_peak = measured_copy_peak(torch) if world == 1 else None
+        copy_peak = ctx.copy_peak(1 << 32, 3) if world == 1 else None      # hand-written 16-byte-per-lane copy (hsk_copy_peak), measured in this run
+        tkern = {}
+        try:
+            tkern = json.load(open(tfile)).get("kernels", {}) if os.path.exists(tfile) else {}
+        except Exception:
+            pass
+
+        def pmc_bytes(prefix):
+            """HBM bytes per launch of the kernel from the committed PMC passes (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or None"""
+            for name, d in tkern.items():
+                if name.startswith(prefix):
+                    return (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
+            return None
 
         def kern(name, ms, n, alg_bytes, bound, note):
-            d = {"kernel": name, "ms_per_step": ms / S, "launches_per_step": n / S, "bound": bound, "note": note}
+            d = {"kernel": name, "ms_per_step": ms / S, "launches_per_step": n / S, "avg_launch_ms": (ms / n) if n else None, "bound": bound, "note": note}
             if alg_bytes and ms > 0:
+                d["algorithmic_bytes_per_launch"] = alg_bytes / max(n, 1)
                 d["algorithmic_GBs"] = alg_bytes / (ms * 1e-3) / 1e9
                 d["frac_of_hbm_peak"] = d["algorithmic_GBs"] / HBM_PEAK_GBS
+                if copy_peak:
+                    d["frac_of_copy_peak"] = d["algorithmic_GBs"] / copy_peak
+            d["pmc_traffic_bytes_per_launch"] = pmc_bytes(name)
             return d
         kernels = [
             kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
-                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: 97 VALU instructions per base position by the SQ counters (116 at the start of round 2), 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records"),
+                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: ~97 VALU instructions per base position, 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records, so its HBM fraction says nothing about it"),
             kern("expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins"),
             kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
@@ -332,29 +397,38 @@ def main():
                  "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
         ]
         kernels.sort(key=lambda d: -d["ms_per_step"])
+        dom = kernels[0]                                   # the time-dominant kernel of THIS run
         ms_total = phase.get("ms_total", 0) / S
+        ref_b = 152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)
+        dev = {"value": value, "unit": "k-mers/s", "ms_per_step": ms_step, "input": "resident in HBM", "output": "left in HBM"}
         out = {
             "metric": "k-mers counted/sec at K=%d" % KK, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": S, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_is": "device_resident (inputs already in HBM when the timed region starts, as the bench contract asks); `host_to_host` in this line is the same "
+                        "workload through hsk_count() from host memory to host memory = the metric as SURVEY 8(d) and the reference's timer define it",
             "dtype": ("u64" if KK <= 32 else "u128") + ("" if not a.ext else "+u64 payload"), "data": "synthetic",
             "config": {"workload": "S-reads(G=%d bp x %d GPU, c=%d): %d x %d-bp reads per GPU = %.3g bp, %d k-mers per GPU" % (
                 int(GENOME_PER_GPU * a.scale), world, COVERAGE, nreads, READ_LEN, nreads * READ_LEN, nk_rank),
                 "K": KK, "M": M, "L": L, "U": U, "EXT": a.ext, "ntasks": info["ntasks"], "scale": a.scale, "error_rate": a.error_rate,
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "onesweep_multi_kernel (radix scatter pass, 8 tasks per launch, one per XCD; with the first pass fused into the expand this is the one remaining pass, over chunk tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "device_resident": dev,
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"] + " (the time-dominant kernel of this run: %.1f of %.1f ms per step; its bound: %s)" % (dom["ms_per_step"], ms_total, dom["bound"]),
+                         "achieved": dom.get("algorithmic_GBs", 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom.get("frac_of_hbm_peak", 0.0), "traffic": dom["pmc_traffic_bytes_per_launch"],
                          "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this build (tools/gpu_round_artifacts.sh), NOT measured in this run",
-                         "launches": int(st["scatter_launches"]), "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch,
-                         "measured_copy_peak_GBs": copy_peak, "frac_of_copy_peak": (achieved / copy_peak) if copy_peak else None,
+                         "launches": int(dom["launches_per_step"] * S), "avg_launch_ms": dom["avg_launch_ms"], "bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
+                         "measured_copy_peak_GBs": copy_peak, "measured_copy_peak_source": "hsk_copy_peak in this run: hand-written kernel, 16 B per lane, 4 GiB read + 4 GiB written, best of 12 launches",
+                         "frac_of_copy_peak": dom.get("frac_of_copy_peak"),
                          "whole_path": {
                              "traffic_bytes_per_step": path_traffic, "traffic_source": "profiles/traffic.json (PMC, earlier run of this build; not this run)",
                              "GBs": (path_traffic / (ms_total * 1e-3) / 1e9) if path_traffic and ms_total else None,
                              "frac_of_hbm_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_traffic and ms_total else None,
                              "frac_of_copy_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / copy_peak) if path_traffic and ms_total and copy_peak else None,
-                             "reference_algorithm_GBs": ((152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)) * nk_rank) / (ms_total * 1e-3) / 1e9 if ms_total else None,
+                             "reference_algorithm_GBs": (ref_b * nk_rank) / (ms_total * 1e-3) / 1e9 if ms_total else None,
                              "reference_algorithm_note": "SURVEY 8(d) fixed accounting (8-bit LSD over all key bytes: 152.3 B per 31-mer) x k-mers / device time: the REFERENCE "
-                                                         "algorithm's byte count, not bytes this build moves (2 passes + LDS aggregation, ~49 B per k-mer) and so not a roofline fraction"}},
+                                                         "algorithm's byte count, not bytes this build moves (2 passes + LDS aggregation, ~49 B per k-mer) and so not a roofline fraction; "
+                                                         "variants[full_sort] runs that algorithm for real"}},
             "kernels": kernels,
             "host_syncs_per_step": st["host_syncs"] / S, "host_waits_covered_per_step": st["host_waits_covered"] / S,
             "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks") if k_ in st},
@@ -364,16 +438,34 @@ def main():
         ctx.close()
         if world == 1 and not a.no_e2e:
             try:
-                out["e2e_host"] = e2e_host_leg(H, KK, a.ext, a.ntasks, local, genome_len, nreads, seed, max(a.steps, 3))
+                out["host_to_host"] = e2e_host_leg(H, KK, a.ext, a.ntasks, local, genome_len, nreads, seed, max(a.steps, 3))
             except Exception as e:
-                out["e2e_host"] = {"error": str(e)[:300]}
+                out["host_to_host"] = {"error": str(e)[:300]}
+        if world == 1 and not a.no_variants:
+            G = int(GENOME_PER_GPU * a.scale)
+            legs = [
+                ("k51", "BASELINE configs[3]'s record shape (two-word keys) on the same reads", 51, 0, None, L, U, G, nreads, 0.0, 464.4),
+                ("ext", "BASELINE configs[4]'s record shape (EXTENSION=1: pos + rid carried through the sort and grouped per k-mer)", 31, 1, None, L, U, G, nreads, 0.0, 304.3),
+                ("no_aggregation", "the headline workload with HSK_FLAG_NO_AGGREGATION: four scatter passes on the top 32 bits + in-LDS tile finish", 31, 0, "no_aggregation", L, U, G, nreads, 0.0, 152.3),
+                ("full_sort", "the headline workload with HSK_FLAG_FULL_SORT = the algorithm north_star names: LSD radix sort over all 8 key bytes "
+                              "(reference sort_task, src/kmerops.cpp:1383) + adjacent-equal merge-count (count_sorted_kmers, :1410)", 31, 0, "full_sort", L, U, G, nreads, 0.0, 152.3),
+                ("uniform", "uniform random reads (error rate 0.75 makes every base uniform: all counts 1), L=1 U=65535: SURVEY 8(d)'s worst case for output volume, "
+                            "half the headline's bases so that the 16 B per k-mer of output stay in HBM", 31, 0, None, 1, 65535, G // 2, nreads // 2, 0.75, 152.3),
+            ]
+            out["variants"] = []
+            for (name, note, vk, vext, plan, Lv, Uv, vg, vn, er, refb) in legs:
+                try:
+                    out["variants"].append(run_variant(H, local, name, note, vk, vext, plan, Lv, Uv, vg, vn, seed, er, 3, refb))
+                except Exception as e:
+                    out["variants"].append({"name": name, "error": str(e)[:300]})
         if world == 1 and not a.no_cpu:
             ncores = os.cpu_count() or 1
             div = max(a.cpu_div, 1)
             g_s = max(int(GENOME_PER_GPU * a.scale) // div, 10000)
-            c2 = H.Context(K=K, M=M, device=local)
-            out["cpu_baseline"] = cpu_baseline(c2, g_s, g_s * COVERAGE // READ_LEN, seed + 1, ncores, 1.0 / div)
-            c2.close()
+            try:
+                out["cpu_baseline"] = cpu_baseline(H, local, g_s, g_s * COVERAGE // READ_LEN, seed + 1, ncores, 1.0 / div)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:300]}
         print(json.dumps(out))
         sys.stdout.flush()
     else:

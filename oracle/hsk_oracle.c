@@ -650,6 +650,93 @@ void hsko_result_free(hsko_result *r)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Per-task digests of the k-mer INSTANCES a rank extracts (test infrastructure for inputs far beyond what hsko_count
+ * can hold: 10 Gbp = 8e9 k-mers).  Streaming, no sort, no count, memory O(ntasks) per thread:
+ *   n[t]   = number of k-mers whose minimizer sends them to task t          (a4: kmerops.cpp:1010-1047)
+ *   mix[t] = sum over those k-mers of digest_mix(canonical k-mer[, pos, rid])   (mod 2^64)
+ * For an unfiltered result list the same numbers follow from the entries: n[t] = sum of cnt, mix[t] = sum of
+ * cnt * digest_mix(key) (with EXTENSION: sum over every payload), so a strictly ascending list with equal digests IS
+ * the task's k-mer multiset.  The arithmetic restates the same reference definitions as the functions above, rolling
+ * instead of from scratch (GetExtension kmer.hpp:248-263 forwards; the twin rolled the other way; canonical = smaller
+ * under operator<, kmer.hpp:217,299); tests/test_oracle_golden.py pins it against hsko_count on every golden input.
+ * task_sel (optional, [ntasks]): digest only the tasks with a non-zero byte (the others stay 0).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t fmix64_d(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+uint64_t hsko_digest_mix(const uint64_t *w, int nw, int ext, uint32_t pos, int32_t rid)
+{
+    uint64_t x = 0;
+    for (int j = 0; j < nw; ++j) x = fmix64_d(x ^ (w[j] + 0x9e3779b97f4a7c15ULL * (uint64_t)(j + 1)));
+    if (ext) x = fmix64_d(x ^ fmix64_d((((uint64_t)(uint32_t)rid) << 32 | pos) + 0x632be59bd9b4e019ULL));
+    return x;
+}
+
+/* multi-word helpers on `nw` words, base i at word i/32, shift 2*(31 - i%32) */
+static inline void mw_shl2(uint64_t *w, int nw) { for (int j = 0; j < nw; ++j) w[j] = (w[j] << 2) | (j + 1 < nw ? w[j + 1] >> 62 : 0); }
+static inline void mw_shr2(uint64_t *w, int nw) { for (int j = nw - 1; j >= 0; --j) w[j] = (w[j] >> 2) | (j > 0 ? w[j - 1] << 62 : 0); }
+static inline int mw_less(const uint64_t *a, const uint64_t *b, int nw) { for (int j = 0; j < nw; ++j) { if (a[j] < b[j]) return 1; if (a[j] > b[j]) return 0; } return 0; }
+
+int hsko_task_digests(const uint8_t *packed, const uint64_t *read_off, const uint32_t *read_len, uint64_t nreads,
+                      int k, int m, int ext, int ntasks, int64_t rid_base, const uint8_t *task_sel, uint64_t *n_out, uint64_t *mix_out)
+{
+    if (k <= 2 || k >= 96 || m >= k || m < 1 || ntasks < 1 || k % 32 == 0 || m % 32 == 0) return -1;
+    const int nw = hsko_nw(k), nwm = hsko_nw(m), W = k - m + 1;
+    memset(n_out, 0, sizeof(uint64_t) * (size_t)ntasks); memset(mix_out, 0, sizeof(uint64_t) * (size_t)ntasks);
+    const int klast = (k - 1) / 32, kshift = 2 * (31 - (k - 1) % 32);          /* where base k-1 sits */
+    const int mlast = (m - 1) / 32, mshift = 2 * (31 - (m - 1) % 32);
+    const uint64_t kmask = ~0ULL << kshift, mmask = ~0ULL << mshift;           /* valid bits of the last word */
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        uint64_t *ln = (uint64_t *)calloc((size_t)ntasks, sizeof(uint64_t)), *lm = (uint64_t *)calloc((size_t)ntasks, sizeof(uint64_t));
+        uint64_t *dqh = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(W + 2)); int64_t *dqp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 2));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (uint64_t r = 0; r < nreads; ++r) {
+            const uint64_t len = read_len[r];
+            if (len < (uint64_t)k) continue;                                   /* kmerops.cpp:1019 */
+            const uint8_t *mem = packed + read_off[r];
+            uint64_t kf[HSKO_MAXW] = {0, 0, 0}, kr[HSKO_MAXW] = {0, 0, 0}, mf[HSKO_MAXW] = {0, 0, 0}, mr[HSKO_MAXW] = {0, 0, 0};
+            /* ring deque of (hash, m-mer position), capacity W + 1 */
+            int64_t qf = 0, qb = 0;                                            /* logical indices, slot = idx % (W + 1) */
+            const int64_t QC = W + 1;
+            for (uint64_t i = 0; i < len; ++i) {
+                const uint64_t c = (uint64_t)hsko_base(mem, i);
+                /* forward strands: drop the oldest base, append c at base position k-1 / m-1 */
+                mw_shl2(kf, nw); kf[klast] = (kf[klast] & kmask & ~(3ULL << kshift)) | (c << kshift); for (int j = klast + 1; j < nw; ++j) kf[j] = 0;
+                mw_shl2(mf, nwm); mf[mlast] = (mf[mlast] & mmask & ~(3ULL << mshift)) | (c << mshift);
+                /* twins: everything one base to the right, the complement of c in front */
+                mw_shr2(kr, nw); kr[0] |= (3 - c) << 62; kr[klast] &= kmask;
+                mw_shr2(mr, nwm); mr[0] |= (3 - c) << 62; mr[mlast] &= mmask;
+                if (i + 1 >= (uint64_t)m) {                                    /* m-mer ending at base i: position j = i - m + 1 */
+                    const int64_t j = (int64_t)i - m + 1;
+                    const uint64_t *cm = mw_less(mr, mf, nwm) ? mr : mf;       /* GetRep */
+                    const uint64_t h = hsko_murmur64(cm, (uint32_t)(8 * nwm));
+                    while (qb > qf && dqh[(qb - 1) % QC] > h) --qb;            /* Minimizer_Deque::insert kmerops.cpp:1058 */
+                    dqh[qb % QC] = h; dqp[qb % QC] = j; ++qb;
+                }
+                if (i + 1 >= (uint64_t)k) {                                    /* k-mer ending at base i: position p = i - k + 1, m-mers p .. p + k - m */
+                    const int64_t p = (int64_t)i - k + 1;
+                    while (qb > qf && dqp[qf % QC] < p) ++qf;                  /* remove what left the window */
+                    const int task = (int)(dqh[qf % QC] % (uint64_t)ntasks);   /* GetMinimizerOwner kmerops.cpp:1044 */
+                    if (task_sel && !task_sel[task]) continue;
+                    const uint64_t *ck = mw_less(kr, kf, nw) ? kr : kf;
+                    ln[task] += 1;
+                    lm[task] += hsko_digest_mix(ck, nw, ext, (uint32_t)p, (int32_t)(rid_base + (int64_t)r));
+                }
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        { for (int t = 0; t < ntasks; ++t) { n_out[t] += ln[t]; mix_out[t] += lm[t]; } }
+        free(ln); free(lm); free(dqh); free(dqp);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a16. print_kmer_histogram (src/hysortk.cpp:98-136): text "#count\tnumkmers\n" then
  * "i\thisto[i]\n" for non-zero i>=1, then an empty line.  64-bit bins here (the reference's
  * int bins overflow above 2^31-1; documented divergence).  Returns bytes written (excluding NUL)

@@ -206,6 +206,61 @@ def count(packed, read_off, read_len, k=31, m=17, L=1, U=65535, ext=0, ntasks=5,
     return CountResult(keys, cnt, task_off, payoff, pos, rid, stats)
 
 
+def task_digests(packed, read_off, read_len, k=31, m=17, ext=0, ntasks=5, rid_base=0, task_sel=None):
+    """(n[ntasks], mix[ntasks]): number of k-mer instances per task and the sum of digest_mix over them (hsko_task_digests):
+    streaming, for inputs far too large for count()."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    read_len = np.ascontiguousarray(read_len, dtype=np.uint32)
+    n = np.zeros(ntasks, dtype=np.uint64); mix = np.zeros(ntasks, dtype=np.uint64)
+    sel = None if task_sel is None else np.ascontiguousarray(task_sel, dtype=np.uint8)
+    lib().hsko_task_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib().hsko_task_digests(_p(packed), _p(read_off), _p(read_len), read_len.size, k, m, ext, ntasks, rid_base, _p(sel) if sel is not None else None, _p(n), _p(mix))
+    if rc != 0:
+        raise ValueError("hsko_task_digests: bad arguments")
+    return n, mix
+
+
+def _fmix64(x):
+    x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd); x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+    return x ^ (x >> np.uint64(33))
+
+
+def digest_mix(keys, pos=None, rid=None):
+    """numpy twin of hsko_digest_mix: keys uint64 [n, nw] (+ per-row pos / rid for EXTENSION) -> uint64 [n]."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    x = np.zeros(keys.shape[0], dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for j in range(keys.shape[1]):
+            x = _fmix64(x ^ (keys[:, j] + np.uint64((0x9e3779b97f4a7c15 * (j + 1)) & 0xFFFFFFFFFFFFFFFF)))
+        if pos is not None:
+            pr = (np.asarray(rid).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF)) << np.uint64(32) | np.asarray(pos, dtype=np.uint64)
+            x = _fmix64(x ^ _fmix64(pr + np.uint64(0x632be59bd9b4e019)))
+    return x
+
+
+def entries_digests(keys, cnt, task_off, payload=None):
+    """Per-task (n, mix) of a result list: n = sum of cnt, mix = sum of cnt * digest_mix(key) (mod 2^64); payload = (payload_off, pos,
+    rid) with EXTENSION: mix = sum over every payload of digest_mix(key, pos, rid)."""
+    nt = len(task_off) - 1
+    n = np.zeros(nt, dtype=np.uint64); mix = np.zeros(nt, dtype=np.uint64)
+    cnt = np.asarray(cnt, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for t in range(nt):
+            a, b = int(task_off[t]), int(task_off[t + 1])
+            if a == b:
+                continue
+            n[t] = cnt[a:b].sum(dtype=np.uint64)
+            if payload is None:
+                mix[t] = (digest_mix(keys[a:b]) * cnt[a:b]).sum(dtype=np.uint64)
+            else:
+                po, pos, rid = payload
+                p0, p1 = int(po[a]), int(po[b])
+                rep = np.repeat(np.asarray(keys[a:b], dtype=np.uint64), cnt[a:b].astype(np.int64), axis=0)
+                mix[t] = digest_mix(rep, pos[p0:p1], rid[p0:p1]).sum(dtype=np.uint64)
+    return n, mix
+
+
 def histogram_text(cnt):
     a = np.ascontiguousarray(cnt, dtype=np.uint64)
     need = lib().hsko_histogram_text(_p(a), a.size, None, 0)

@@ -411,6 +411,40 @@ def test_full_size_properties_both_expand_paths():
     assert int(outs[0][0]) > 300_000_000 and int(outs[0][3]) == 40 and int(outs[0][4]) == 40
 
 
+def _oracle_digests_of_device_reads(c, dp, nb, do, dl, NR, RL, k, ext, ntasks, rid_base=0):
+    """per-task (n, mix) of the reads resident in HBM, computed by the CPU oracle's streaming digests (oracle/hsk_oracle.c
+    hsko_task_digests: every k-mer instance of every read, ~20 M positions/s per host thread)"""
+    from oracle import hsk_oracle as O
+    packed = c.d2h(dp, nb)
+    off = np.arange(NR, dtype=np.uint64) * np.uint64((RL + 3) // 4)
+    lens = np.full(NR, RL, dtype=np.uint32)
+    return O.task_digests(packed, off, lens, k=k, m=17, ext=ext, ntasks=ntasks, rid_base=rid_base)
+
+
+def test_full_size_equals_oracle_digests_k31(H):
+    """BASELINE.json configs[1] at FULL size against the oracle, not only against itself: for each of the 40 tasks the number of
+    k-mers and the multiset digest of the list (sum of cnt * mix(key) mod 2^64) equal what the CPU oracle streams out of the
+    same 10 Gbp of reads (8.0e9 k-mer instances, record offsets far beyond 2^32).  With every task strictly ascending (checked
+    here too) equal digests mean the list IS the task's k-mer multiset."""
+    from oracle import hsk_oracle as O
+    G, RL = 312_500_000, 150
+    NR = G * 32 // RL
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=0) as c:
+        dp, nb, do, dl = c.synth_reads(G, RL, NR, 20251003)
+        r = c.count_device(dp, nb, do, dl, NR)
+        nt = r.info["ntasks"]
+        want_n, want_mix = _oracle_digests_of_device_reads(c, dp, nb, do, dl, NR, RL, 31, 0, nt)
+        c.synth_free(dp, do, dl)
+    assert nt == 40 and int(want_n.sum()) == NR * (RL - 31 + 1) == r.info["total_kmers"]
+    got_n, got_mix = O.entries_digests(r.kmers, r.cnt, r.task_off)
+    assert np.array_equal(got_n, want_n), (got_n, want_n)
+    assert np.array_equal(got_mix, want_mix)
+    k = r.kmers[:, 0]
+    d = k[1:] > k[:-1]; starts = r.task_off[1:-1].astype(np.int64)
+    d[starts[(starts > 0) & (starts < len(k))] - 1] = True
+    assert bool(d.all())
+
+
 def test_full_size_properties_k51(H):
     """BASELINE.md section 3, second record shape at full size: the 10 Gbp of reads at K=51 (two-word keys, 6.67e9 51-mers,
     unfiltered).  Size-independent properties: checksum of counts = number of k-mers, histogram consistent, every task strictly
@@ -439,6 +473,14 @@ def test_full_size_properties_k51(H):
         h = np.bitwise_xor.reduce((w0 * np.uint64(0x9E3779B97F4A7C15)) ^ (w1 * np.uint64(0xC2B2AE3D27D4EB4F)) ^ cnt)
         sums.append((len(cnt), int(h), int(w0.sum(dtype=np.uint64)), r.info["ntasks"]))
         if len(sums) == 1:
+            # ... and against the CPU oracle: per task, number of 51-mers and multiset digest of the list (6.67e9 instances streamed on the host)
+            from oracle import hsk_oracle as O
+            with H.Context(K=51, M=17) as c2:
+                dp, nb, do, dl = c2.synth_reads(G, RL, NR, 20251003)
+                want_n, want_mix = _oracle_digests_of_device_reads(c2, dp, nb, do, dl, NR, RL, 51, 0, r.info["ntasks"])
+                c2.synth_free(dp, do, dl)
+            got_n, got_mix = O.entries_digests(r.kmers, r.cnt, r.task_off)
+            assert np.array_equal(got_n, want_n) and np.array_equal(got_mix, want_mix)
             sel = np.arange(0, len(cnt), 97)
             pairs = np.stack([w1[sel], w0[sel]], axis=1)
             assert np.unique(pairs, axis=0).shape[0] == sel.size         # sampled: a k-mer lives in exactly one task
@@ -455,16 +497,26 @@ def test_full_size_properties_extension(H):
     NR = G * 32 // RL
     total = NR * (RL - 31 + 1)
     rid_base = 1000
+    from oracle import hsk_oracle as O
     with H.Context(K=31, M=17, L=1, U=65535, EXT=1, ntasks=0, keep_device=True) as c:
         dp, nb, do, dl = c.synth_reads(G, RL, NR, 20251003)
         with H.DeviceDna(c, dp, nb, do, dl, NR).count_resident_device(rid_base=rid_base) as dev:
+            # the CPU oracle's digests of every (k-mer, pos, rid) instance, per task: the payload of EVERY entry is checked against them
+            want_n, want_mix = _oracle_digests_of_device_reads(c, dp, nb, do, dl, NR, RL, 31, 1, dev.ntasks, rid_base=rid_base)
             seen_pay, seen_cnt, n_entries = 0, 0, 0
             pos_hist = np.zeros(RL - 31 + 1, dtype=np.int64)
             for t in range(dev.ntasks):
                 d = dev.fetch(t)
                 if not d["n"]:
+                    assert want_n[t] == 0
                     continue
                 k, cnt = d["kmers"][:, 0], d["cnt"]
+                if t % 8 == 3 or t == dev.ntasks - 1:            # (expanding 2e8 keys per task on the host takes a while: five of the 40 tasks get the full digest)
+                    rep = np.repeat(d["kmers"], cnt.astype(np.int64), axis=0)
+                    with np.errstate(over="ignore"):
+                        assert int(O.digest_mix(rep, d["pos"], d["rid"]).sum(dtype=np.uint64)) == int(want_mix[t]), t
+                    del rep
+                assert int(cnt.sum(dtype=np.uint64)) == int(want_n[t]), t
                 assert np.all(k[1:] > k[:-1]) and not np.any(k & np.uint64(3))
                 assert int(cnt.sum(dtype=np.uint64)) == d["npay"]
                 po = d["payload_off"].astype(np.int64) - d["payload_base"]

@@ -114,3 +114,20 @@ def test_multirank_union_and_dispatch(nprocs):
         n = sum(int(res.task_off[t + 1] - res.task_off[t]) for t in ids)
         assert n == d["entries_per_rank"][r]
     assert O.histogram_text(res.cnt) == d["histogram"]
+
+
+@pytest.mark.parametrize("k,m,ext,nt", [(31, 17, 0, 5), (31, 17, 1, 7), (51, 17, 0, 40), (51, 35, 0, 5), (77, 65, 0, 6), (21, 9, 0, 3), (77, 17, 1, 9), (35, 17, 0, 8)])
+def test_streaming_task_digests_equal_the_counted_lists(k, m, ext, nt):
+    """hsko_task_digests (rolling, streaming: the checker of the full-size GPU tests, where hsko_count cannot hold the k-mers) against
+    the digests of hsko_count's own lists -- itself pinned by the goldens above -- on the golden reads plus edge cases (reads
+    shorter than / equal to K, homopolymers, tandem repeats, N / lower case in the golden file)."""
+    seqs = util.read_fasta(util.GOLDEN + "/reads_small.fa") + ["ACGT" * 3, "A" * 200, "ACGTTGCA" * 30, "C" * (k - 1), "G" * k, ""]
+    pk, off, ln = O.pack_reads(seqs)
+    r = O.count(pk, off, ln, k=k, m=m, L=1, U=65535, ext=ext, ntasks=nt, rid_base=11)
+    n1, m1 = O.entries_digests(r.keys, r.cnt, r.task_off, (r.payoff, r.pos, r.rid) if ext else None)
+    n2, m2 = O.task_digests(pk, off, ln, k=k, m=m, ext=ext, ntasks=nt, rid_base=11)
+    assert np.array_equal(n1, n2) and np.array_equal(m1, m2)
+    assert int(n2.sum()) == r.stats["total_kmers"]
+    sel = np.zeros(nt, np.uint8); sel[nt // 2] = 1
+    n3, m3 = O.task_digests(pk, off, ln, k=k, m=m, ext=ext, ntasks=nt, rid_base=11, task_sel=sel)
+    assert n3[nt // 2] == n2[nt // 2] and m3[nt // 2] == m2[nt // 2] and int(n3.sum()) == int(n2[nt // 2])
