@@ -194,4 +194,18 @@ __global__ void payload_split_kernel(const u64 *vals, u64 n, u32 *pos, int32_t *
     }
 }
 
+// Result egress over PCIe (hsk_count() to host memory): an entry {k-mer words, u64 count} whose count fits 16 bits (the config
+// contract: UPPER_KMER_FREQ <= 65535, reference include/compiletime.h:21) travels as k-mer words + u16 -- 10 instead of 16 bytes
+// for one-word keys -- and is widened to the KmerListEntryS layout (reference include/kmer.hpp:368) by host threads.
+// keys_out: n * nw words, cnt_out: n values; one launch per task.
+__global__ __launch_bounds__(256) void pack_entries_kernel(const u64 *entries, u64 n, int nw, u64 *keys_out, unsigned short *cnt_out)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 *e = entries + i * (u64)(nw + 1);
+        for (int w = 0; w < nw; ++w) keys_out[i * (u64)nw + w] = e[w];
+        cnt_out[i] = (unsigned short)e[nw];
+    }
+}
+
 } // namespace hsk

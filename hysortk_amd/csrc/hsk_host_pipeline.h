@@ -204,6 +204,42 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
     return HSK_OK;
 }
 
+// Host threads that widen compact result batches (pack_entries_kernel's k-mer words + 16-bit counts, copied into pinned staging)
+// into the caller-visible entries while the GPU counts the next batches.  Every thread of a batch waits for the batch's copy
+// event, then takes its slice.  The destructor joins: no thread outlives the call that started it.
+struct WidenPool {
+    hsk_ctx *c;
+    std::vector<std::thread> th;
+    std::vector<hipEvent_t> evs;
+    explicit WidenPool(hsk_ctx *c_) : c(c_) {}
+    static int nthreads()
+    {
+        static const int n = []() {
+            if (const char *e = getenv("HSK_WIDEN_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 64); }
+            const unsigned hc = std::thread::hardware_concurrency();
+            return (int)std::min<unsigned>(16, std::max<unsigned>(2, hc / 2));
+        }();
+        return n;
+    }
+    // keys: n * nw words, cnts: n values (pinned staging, valid once `copied` has happened); dst: n entries of nw + 1 words
+    void add(hipEvent_t copied, const u64 *keys, const unsigned short *cnts, u64 *dst, u64 n, int nw)
+    {
+        evs.push_back(copied);
+        const int nt = nthreads(), dev = c->cfg.device;
+        for (int t = 0; t < nt; ++t) {
+            const u64 lo = n * (u64)t / nt, hi = n * (u64)(t + 1) / nt;
+            th.emplace_back([=]() {
+                (void)hipSetDevice(dev);
+                (void)hipEventSynchronize(copied);
+                if (nw == 1) for (u64 i = lo; i < hi; ++i) { dst[2 * i] = keys[i]; dst[2 * i + 1] = cnts[i]; }
+                else for (u64 i = lo; i < hi; ++i) { for (int w = 0; w < nw; ++w) dst[i * (nw + 1) + w] = keys[i * nw + w]; dst[i * (nw + 1) + nw] = cnts[i]; }
+            });
+        }
+    }
+    void join() { for (auto &t : th) if (t.joinable()) t.join(); th.clear(); for (auto e : evs) ev_put(c, e); evs.clear(); }
+    ~WidenPool() { join(); }
+};
+
 struct HeavyIn { u32 task; u64 *d_entries; u64 n; };       // a heavy task this rank owns: concatenated lists of all ranks
 struct ProcExtra {
     bool force_batch = false;                              // every task through the batch kernels (partial batches padded)
@@ -317,6 +353,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     static const bool early_enabled = !(getenv("HSK_EARLY_D2H") && atoi(getenv("HSK_EARLY_D2H")) == 0);
     bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty());
     u64 *early_buf = nullptr; u64 early_cap = 0, early_used = 0, early_kmers = 0;
+    // compact copies (HSK_COMPACT_D2H=0: entries travel as they are): counts fit 16 bits whenever the filter's upper bound does
+    static const bool compact_enabled = !(getenv("HSK_COMPACT_D2H") && atoi(getenv("HSK_COMPACT_D2H")) == 0);
+    const bool compact = compact_enabled && c->cfg.upper_freq <= 65535;
+    WidenPool widen(c);
+    u64 compact_bytes = 0, compact_entries = 0;
+    std::vector<void *> pk_dev, pk_host;                  // device / pinned staging of the compact batches (handed back when the call ends)
     std::vector<u8> copied(ntasks, 0);
     std::vector<EvPair> d2h_ev;
     const bool profile_ev = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
@@ -332,16 +374,42 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             if (!early_buf) { early = false; return HSK_OK; }
         }
         if (early_used + nb > early_cap) { early = false; return HSK_OK; }                       // the guess was too small: copy at the end
+        // compact: the batch's entries are packed on the main stream (k-mer words, then the 16-bit counts), copied as ONE block into
+        // pinned staging and widened into early_buf by host threads while the next batch is counted
+        u8 *d_pk = nullptr, *h_pk = nullptr;
+        if (compact && nb) {
+            const size_t pk_bytes = (size_t)nb * (NW * 8 + 2) + 64;
+            d_pk = (u8 *)c->pool.alloc(pk_bytes); h_pk = (u8 *)host_alloc(c, rp, pk_bytes);
+            if (!d_pk || !h_pk) { c->pool.release(d_pk); if (h_pk) host_release(c, rp, h_pk); d_pk = nullptr; h_pk = nullptr; }      // (no room: this batch travels as it is)
+            else {
+                pk_dev.push_back(d_pk); pk_host.push_back(h_pk);
+                u64 o = 0;
+                for (int i = 0; i < ntk; ++i) {
+                    if (tasks[i] == EMPTY_TASK || !touts[tasks[i]].n) continue;
+                    const TaskOut &to = touts[tasks[i]];
+                    hipLaunchKernelGGL(pack_entries_kernel, dim3((u32)std::min<u64>((to.n + 255) / 256, 2048)), dim3(256), 0, c->stream, to.entries, to.n, NW,
+                                       (u64 *)d_pk + o * NW, (unsigned short *)(d_pk + (size_t)nb * NW * 8) + o);
+                    o += to.n;
+                }
+            }
+        }
         hipEvent_t done = ev_get(c);
         HIPCHK(c, hipEventRecord(done, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, done, 0));
         ev_put(c, done);
         EvPair ep{}; if (profile_ev) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 6; (void)hipEventRecord(ep.a, c->d2h_stream); }
+        if (d_pk) {
+            HIPCHK(c, hipMemcpyAsync(h_pk, d_pk, (size_t)nb * (NW * 8 + 2), hipMemcpyDeviceToHost, c->d2h_stream));
+            hipEvent_t cp = ev_get(c);
+            HIPCHK(c, hipEventRecord(cp, c->d2h_stream));
+            widen.add(cp, (const u64 *)h_pk, (const unsigned short *)(h_pk + (size_t)nb * NW * 8), early_buf + early_used * (NW + 1), nb, NW);
+            compact_bytes += (u64)nb * (NW * 8 + 2); compact_entries += nb;
+        }
         for (int i = 0; i < ntk; ++i) {
             const u32 t = tasks[i];
             if (t == EMPTY_TASK) continue;
             TaskOut &to = touts[t];
-            if (to.n) HIPCHK(c, hipMemcpyAsync(early_buf + early_used * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->d2h_stream));
+            if (to.n && !d_pk) HIPCHK(c, hipMemcpyAsync(early_buf + early_used * (NW + 1), to.entries, to.n * (NW + 1) * 8, hipMemcpyDeviceToHost, c->d2h_stream));
             early_used += to.n; copied[t] = 1;
         }
         if (profile_ev) { (void)hipEventRecord(ep.b, c->d2h_stream); d2h_ev.push_back(ep); }
@@ -514,7 +582,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         // the early copies are good if they stayed inside the block and cover a prefix of the list (tasks in ascending id)
         bool early_ok = early_buf != nullptr && early && n_total <= early_cap;
         if (early_ok) { bool gap = false; for (u32 t = 0; t < ntasks && early_ok; ++t) { if (!touts[t].n) continue; if (!copied[t]) gap = true; else if (gap) early_ok = false; } }
-        if (early_buf && !early_ok) { HIPCHK(c, hsk_sync(c, c->d2h_stream)); host_release(c, rp, early_buf); early_buf = nullptr; std::fill(copied.begin(), copied.end(), 0); }
+        if (early_buf && !early_ok) { HIPCHK(c, hsk_sync(c, c->d2h_stream)); widen.join(); host_release(c, rp, early_buf); early_buf = nullptr; std::fill(copied.begin(), copied.end(), 0); compact_bytes = compact_entries = 0; }
         out->entries = early_buf ? early_buf : (uint64_t *)host_alloc(c, rp, n_total * (NW + 1) * 8);
         if (!out->entries) return fail(c, HSK_ERR_OOM, "pinned host allocation of %llu bytes failed", (unsigned long long)(n_total * (NW + 1) * 8));
         if (ext) {
@@ -541,7 +609,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     }
     out->task_off[ntasks] = o;
     if (profile_ev && !keep) { (void)hipEventRecord(d2h_tail.b, c->stream); d2h_ev.push_back(d2h_tail); }
-    if (!keep) c->stats.d2h_bytes += n_total * (NW + 1) * 8 + (ext ? (n_total + 1) * 8 + pay_total * 8 : 0);
+    if (!keep) c->stats.d2h_bytes += (n_total - compact_entries) * (NW + 1) * 8 + compact_bytes + (ext ? (n_total + 1) * 8 + pay_total * 8 : 0);
     pt.end(PH_D2H);
     if (pt_total_open) pt.end(PH_TOTAL);
     tmark("result copies enqueued");
@@ -549,6 +617,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     tmark("main stream drained");
     if (early_buf) HIPCHK(c, hsk_sync(c, c->d2h_stream));
     tmark("copy stream drained");
+    widen.join();                                         // the last batch's entries are being widened
+    for (void *p : pk_dev) c->pool.release(p);
+    for (void *p : pk_host) host_release(c, rp, p);
+    tmark("entries widened");
     for (auto &e : d2h_ev) c->ev_pending.push_back(e);
     if (*h_err) {
         const u32 w = *h_err;
