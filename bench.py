@@ -234,7 +234,7 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
     info = None
     for _ in range(steps):
         r = ctx.count_device(dp, nb, do, dl, nreads)
-        info = dict(r.info, n=len(r))
+        info = dict(r.info)
         del r
     dt = (time.perf_counter() - t0) / steps
     st = ctx.stats(reset=True)
@@ -242,7 +242,7 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
     ctx.close()
     nk = nreads * (READ_LEN - KK + 1)
     out = {"name": name, "what": note, "K": KK, "EXT": ext, "L": Lv, "U": Uv, "plan": plan or "default", "error_rate": error_rate, "kmers": nk, "steps": steps,
-           "value": nk / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3, "device_ms_total": info["ms_total"], "entries": info["n"], "ntasks": info["ntasks"],
+           "value": nk / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3, "device_ms_total": info["ms_total"], "entries": info.get("n"), "ntasks": info["ntasks"],
            "phases_ms": {k_: round(v, 2) for k_, v in info.items() if k_.startswith("ms_")},
            "scatter_pass": {"launches_per_step": st["scatter_launches"] / steps, "ms_per_step": st["scatter_ms"] / steps,
                             "GBs": (st["scatter_bytes"] / (st["scatter_ms"] * 1e-3) / 1e9) if st["scatter_ms"] > 0 else None},

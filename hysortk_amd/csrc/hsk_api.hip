@@ -769,7 +769,7 @@ extern "C" int hsk_synth_reads(hsk_ctx *c, uint64_t genome_len, uint32_t read_le
 extern "C" int hsk_synth_reads_err(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read, double error_rate,
                                    void **d_packed, uint64_t *packed_bytes, void **d_off, void **d_len)
 {
-    if (!(error_rate >= 0.0 && error_rate <= 0.5)) return HSK_ERR_INVALID_ARG;
+    if (!(error_rate >= 0.0 && error_rate <= 0.75)) return HSK_ERR_INVALID_ARG;      // 0.75: every base uniform over ACGT whatever the genome says
     return synth_reads_impl(c, genome_len, read_len, nreads, seed, first_read, error_rate, d_packed, packed_bytes, d_off, d_len);
 }
 static int synth_reads_impl(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read, double error_rate,

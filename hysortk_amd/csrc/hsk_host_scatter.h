@@ -78,6 +78,26 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     }
     a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.chunk = XS_CHUNK; a.err = c->d_err;
     const bool ext = c->cfg.extension != 0;
+    // HSK_XS_TPB=256 (experiment, see hsk_scatter.h): 256-thread workgroups, four per CU, for one-word keys without payload whose
+    // supermers are one in-place segment per task (one GPU); tiles are then counted in units of 256 supermers
+    static const int xs_tpb = getenv("HSK_XS_TPB") ? atoi(getenv("HSK_XS_TPB")) : XS_THREADS;
+    bool small_wg = xs_tpb == 256 && NW == 1 && !ext;
+    for (int i = 0; i < XCD_BATCH && small_wg; ++i) if (xi[i] >= 0 && !(jobs[i].ts->segs.size() == 1 && jobs[i].src.gpos != nullptr)) small_wg = false;
+    if constexpr (NW == 1) {
+        if (small_wg) {
+            for (int i = 0; i < XCD_BATCH; ++i) if (xi[i] >= 0) a.t[i].ntiles = (jobs[i].ts->segs[0].n_sup + 255) / 256;
+            static int occ256 = 0;
+            if (!occ256) { int nb = 0; occ256 = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<1, false, 31, 256>, 256, 0) == hipSuccess && nb > 0) ? nb : 4; }
+            EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
+            const u32 grid = (u32)occ256 * 256u;
+            if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56) hipLaunchKernelGGL((expand_scatter_kernel<1, false, 31, 256>), dim3(grid), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((expand_scatter_kernel<1, false, 0, 256>), dim3(grid), dim3(256), 0, stream, a);
+            if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
+            HIPCHK(c, hipGetLastError());
+            sb.active = true;
+            return HSK_OK;
+        }
+    }
     static int occ_c[2] = {0, 0};                             // (per instantiation of this template: per NW)
     int &occ = occ_c[ext ? 1 : 0];
     if (!occ) {

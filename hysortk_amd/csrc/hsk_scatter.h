@@ -80,7 +80,8 @@ struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1, chunk; u32 *err; }
 // critical path).  Everything the waves of this kernel hand to each other between barriers goes through LDS.
 __device__ __forceinline__ void xs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 */, u32 *total)
+template <int NWAVES>
+__device__ __forceinline__ u32 block_excl_scan_xs(u32 v, u32 *scratch /* >= NWAVES */, u32 *total)
 {
     const int lane = lane_id(), w = threadIdx.x >> 6;
     u32 inc = wave_incl_scan(v);
@@ -88,7 +89,7 @@ __device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32 *scratch /* >= 8 *
     xs_barrier();
     u32 base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < XS_WAVES; ++i) { u32 s = scratch[i]; if (i < w) base += s; tot += s; }
+    for (int i = 0; i < NWAVES; ++i) { u32 s = scratch[i]; if (i < w) base += s; tot += s; }
     xs_barrier();
     if (total) *total = tot;
     return base + inc - v;
@@ -113,26 +114,34 @@ __device__ unsigned long long g_xs_diag[16];
 // keeps (lane, round) per slot and the lanes' base values sit in LDS, so the payload is rebuilt when the run is written.
 // KT: k as a compile-time constant with the two digits in the top 16 key bits (0: k and the digit shifts come from the
 // arguments).  The reference fixes k at compile time (KMER_SIZE); here the default k gets its own instance.
-template <int NW, bool EXT, int KT = 0>
-__global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterArgs a)
+// TPB: threads per workgroup = supermers per tile.  512 (two workgroups per CU) everywhere; the 256-thread instance -- four
+// workgroups per CU at the same wave count: twice as many independent barrier domains to fill the gaps of the phase chain,
+// half the flush, a stage of half a chunk -- exists for one-word keys without payload whose bases are read in place from ONE
+// segment (one GPU), where the host counts tiles in units of TPB supermers (HSK_XS_TPB, hsk_host_scatter.h).
+template <int NW, bool EXT, int KT = 0, int TPB = XS_THREADS>
+__global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
 {
-    constexpr int XS_RUN = XsCfg<NW>::RUN, XS_MAX_ITEMS = XsCfg<NW>::MAX_ITEMS, XS_CHUNK = XsCfg<NW>::CHUNK;
+    constexpr int XS_RUN = XsCfg<NW>::RUN, XS_CHUNK = XsCfg<NW>::CHUNK;
+    constexpr int XS_T = TPB, XS_NWAVE = TPB / WAVE, XS_TL = TPB, XS_MAX_ITEMS = TPB * (128 / XS_RUN);
+    constexpr int XS_STG = TPB == XS_THREADS ? XS_CHUNK : XS_CHUNK / 2;       // keys the LDS stage holds (one window of a flush)
+    static_assert(TPB == XS_THREADS || (NW == 1 && !EXT), "the small-workgroup instance is built for one-word keys without payload");
+    static_assert(TPB >= 256 && TPB % WAVE == 0, "256 digit lanes");
     static_assert(!(EXT && NW != 1), "the payload variant is built for one-word keys");
 #ifdef HSK_DIAG
     __shared__ unsigned long long xs_acc[16];                 // (LDS: sixteen 64-bit accumulators in registers would cost the kernel its occupancy)
     if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) xs_acc[i] = 0; xs_acc[15] = __builtin_amdgcn_s_memtime(); }
 #endif
-    __shared__ u32 s_boff[XS_TILE + 1];
-    __shared__ u32 s_koff[XS_TILE + 1];
-    __shared__ u32 s_ioff[XS_TILE + 1];
+    __shared__ u32 s_boff[XS_TL + 1];
+    __shared__ u32 s_koff[XS_TL + 1];
+    __shared__ u32 s_ioff[XS_TL + 1];
     __shared__ u16 s_isup[XS_MAX_ITEMS];
-    __shared__ u64 s_gpos[XS_TILE];
-    __shared__ u64 s_stage[XS_CHUNK * NW];
-    __shared__ u64 s_vb[EXT ? XS_THREADS : 1];
-    __shared__ u16 s_src[EXT ? XS_CHUNK : 1];
+    __shared__ u64 s_gpos[XS_TL];
+    __shared__ u64 s_stage[XS_STG * NW];
+    __shared__ u64 s_vb[EXT ? XS_T : 1];
+    __shared__ u16 s_src[EXT ? XS_STG : 1];
     __shared__ u32 s_cnt[256], s_start[256], s_hist[256];
     __shared__ uint4 s_dl[256];                                         // per digit {split, d0, d1, d2}: staged slot g goes to g + d0 (g < split), g + d1 (g < split + chunk), else g + d2
-    __shared__ u32 s_scr[XS_WAVES];
+    __shared__ u32 s_scr[XS_NWAVE];
     __shared__ u32 s_blk[2];
     __shared__ u64 s_seg[4][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile, first byte} of the task's segments
     typedef __attribute__((address_space(1))) u32 G32;
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0; p_vb = 0;
         if (p_have) {
             if (single) {
-                const u64 sidx = tl * XS_TILE + tid;
+                const u64 sidx = tl * XS_TL + tid;
                 if (sidx < s0_n) {
                     p_len = t.sm_len[s0_sup + sidx]; if (inplace) p_gpos = sup_pos(s0_sup + sidx, s0_byte);
                     if (EXT) p_vb = (u64)t.sm_pos[s0_sup + sidx] | ((u64)(u32)t.sm_rid[s0_sup + sidx] << 32);
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
             } else {
                 int sg = 0;
                 while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
-                const u64 sidx = (tl - s_seg[2][sg]) * XS_TILE + tid;
+                const u64 sidx = (tl - s_seg[2][sg]) * XS_TL + tid;
                 if (sidx < s_seg[1][sg]) {
                     p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = sup_pos(s_seg[0][sg] + sidx, s_seg[3][sg]);
                     if (EXT) p_vb = (u64)t.sm_pos[s_seg[0][sg] + sidx] | ((u64)(u32)t.sm_rid[s_seg[0][sg] + sidx] << 32);
@@ -212,8 +221,8 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
             while (sg + 1 < nseg && s_seg[2][sg + 1] <= tile) ++sg;
             sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg]; sg_byte = s_seg[3][sg];
         } else { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; sg_byte = sp->byte_off; }
-        const u64 first = (tile - sg_t0) * XS_TILE;
-        const u32 ns = (u32)((sg_n - first) < (u64)XS_TILE ? (sg_n - first) : (u64)XS_TILE);
+        const u64 first = (tile - sg_t0) * XS_TL;
+        const u32 ns = (u32)((sg_n - first) < (u64)XS_TL ? (sg_n - first) : (u64)XS_TL);
 
         // ---- prologue: thread s owns supermer s of the tile ---------------------------------------------------
         u32 len = p_len; u64 gp = p_gpos;
@@ -233,16 +242,16 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         if (nk > 128u) { atomicOr(a.err, 4u); nk = 0; }               // not a supermer of this library (at most 128 k-mers, at least one): the item tables would overflow
         const u32 ni = (nk + XS_RUN - 1) / XS_RUN;
         u32 tot2;
-        const u32 e2 = block_excl_scan_512((nk << 13) | ni, s_scr, &tot2);   // sums: items <= 4096, k-mers <= 65536
+        const u32 e2 = block_excl_scan_xs<XS_NWAVE>((nk << 13) | ni, s_scr, &tot2);   // sums: items <= 4096, k-mers <= 65536
         const u32 ek = e2 >> 13, ei = e2 & 8191u, toti = tot2 & 8191u;
         u32 eb = 0;
-        if (!inplace) eb = block_excl_scan_512(nb, s_scr, nullptr);
+        if (!inplace) eb = block_excl_scan_xs<XS_NWAVE>(nb, s_scr, nullptr);
         prefetch_meta(ntile);                                         // (after the last use of the values it replaces)
         XS_STAMP(13);
         s_boff[tid] = eb; s_koff[tid] = ek; s_ioff[tid] = ei;
         if (inplace) s_gpos[tid] = gp;
         for (u32 q = 0; q < ni; ++q) s_isup[ei + q] = (u16)tid;
-        if (tid == XS_THREADS - 1) { s_boff[XS_TILE] = eb + nb; s_koff[XS_TILE] = ek + nk; s_ioff[XS_TILE] = ei + ni; }
+        if (tid == XS_T - 1) { s_boff[XS_TL] = eb + nb; s_koff[XS_TL] = ek + nk; s_ioff[XS_TL] = ei + ni; }
         const u64 byte_abs = inplace ? 0 : (had_meta ? gp : t.tile_off[2 * tile]);
         xs_barrier();
         XS_STAMP(14);
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
         } else fetch(tid);
         bool win_sent = false;
         XS_STAMP(0);                                                  // tile claim + prologue
-        for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
+        for (u32 it0 = 0; it0 < toti; it0 += XS_T) {
             const u32 cnt = n_cnt;
             if (EXT) s_vb[tid] = n_vb;                                // (the previous flush has been written: its last barrier is behind us)
             u64 win[NW + 1];
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
 #pragma unroll
                 for (int x = 0; x < NW + 1; ++x) win[x] = n_sh ? ((aw[x] << n_sh) | (aw[x + 1] >> (64 - n_sh))) : aw[x];
             }
-            if (it0 + XS_THREADS < toti) fetch(it0 + XS_THREADS + tid);
+            if (it0 + XS_T < toti) fetch(it0 + XS_T + tid);
             // ---- roll the item's k-mers; rank every key inside its digit (arrival order: the pass is not stable) ----
             u64 key[XS_RUN][NW]; u32 rk[XS_RUN];
             Mer<NW> fw, rc;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
             // ---- flush: reserve the digits' ranges, permute through LDS, write runs ---------------------------
             const u32 c = tid < 256 ? s_cnt[tid] : 0;
             u32 tot;
-            const u32 st = block_excl_scan_512(c, s_scr, &tot);
+            const u32 st = block_excl_scan_xs<XS_NWAVE>(c, s_scr, &tot);
             u64 p = 0;
             if (tid < 256) {
                 s_start[tid] = st; s_cnt[tid] = 0;
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                 if ((u32)r >= cnt) continue;
                 const u32 pos = s_start[((u32)(key[r][NW - 1] >> 32) >> sh0) & 255u] + rk[r];
                 rk[r] = pos;                                           // position in the sorted order of the flush
-                if (pos < (u32)XS_CHUNK) {
+                if (pos < (u32)XS_STG) {
 #pragma unroll
                     for (int x = 0; x < NW; ++x) s_stage[pos * NW + x] = key[r][x];
                     if (EXT) s_src[pos] = (u16)((tid << 4) | r);
@@ -373,19 +382,19 @@ __global__ __launch_bounds__(XS_THREADS, 4) void expand_scatter_kernel(ScatterAr
                                        ((ph[2] ? ph[2] : 1u) - 1) * (u32)XS_CHUNK - (split + (u32)XS_CHUNK));
             }
             XS_STAMP(5);                                              // reservation returned, chunk resolved
-            for (u32 w0 = 0; w0 < tot; w0 += XS_CHUNK) {
+            for (u32 w0 = 0; w0 < tot; w0 += XS_STG) {
                 if (w0) {
 #pragma unroll
                     for (int r = 0; r < XS_RUN; ++r)
-                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_CHUNK) {
+                        if ((u32)r < cnt && rk[r] >= w0 && rk[r] < w0 + (u32)XS_STG) {
 #pragma unroll
                             for (int x = 0; x < NW; ++x) s_stage[(rk[r] - w0) * NW + x] = key[r][x];
                             if (EXT) s_src[rk[r] - w0] = (u16)((tid << 4) | r);
                         }
                 }
                 xs_barrier();
-                const u32 wn = tot - w0 < (u32)XS_CHUNK ? tot - w0 : (u32)XS_CHUNK;
-                for (u32 i = tid; i < wn; i += XS_THREADS) {
+                const u32 wn = tot - w0 < (u32)XS_STG ? tot - w0 : (u32)XS_STG;
+                for (u32 i = tid; i < wn; i += XS_T) {
                     u64 kw[NW];
 #pragma unroll
                     for (int x = 0; x < NW; ++x) kw[x] = s_stage[i * NW + x];

@@ -257,7 +257,7 @@ int hsk_comm_selftest(hsk_ctx *ctx);
 int hsk_synth_reads(hsk_ctx *ctx, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed,
                     uint64_t first_read, /* index of read 0 in the global read stream (rank * nreads for weak scaling) */
                     void **d_packed, uint64_t *packed_bytes, void **d_read_byte_off, void **d_read_len);
-/* Same with substitution errors: every base is replaced by one of the other three with probability error_rate (0 .. 0.5).
+/* Same with substitution errors: every base is replaced by one of the other three with probability error_rate (0 .. 0.75; at 0.75 every base is uniform over ACGT).
  * Error-free reads are the best case of the LDS hash aggregation (distinct keys per prefix bin = records / coverage); with
  * ~1 % errors most bins hold several times more distinct keys. */
 int hsk_synth_reads_err(hsk_ctx *ctx, uint64_t genome_len, uint32_t read_len, uint64_t nreads, uint64_t seed, uint64_t first_read,
