@@ -379,6 +379,10 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
         if (hipPointerGetAttributes(&at, packed) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) zc = (const u8 *)at.devicePointer;
         else (void)hipGetLastError();
     }
+    // pinned input of some size: slab ingest (DMA copies pipelined with the scan, parse_count) instead of reads over PCIe in place;
+    // HSK_H2D_SLABS=0: in place as in round 2, =n: n slabs
+    static const int slabs_env = getenv("HSK_H2D_SLABS") ? atoi(getenv("HSK_H2D_SLABS")) : 8;
+    const bool slab_ingest = zc != nullptr && slabs_env > 1 && packed_bytes >= (32u << 20);
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     static const bool derive_enabled = !(getenv("HSK_DERIVE_OFFSETS") && atoi(getenv("HSK_DERIVE_OFFSETS")) == 0);
     const bool derive = zc != nullptr && device_check && derive_enabled;       // only the read lengths travel ahead of the scan (see roff_tilesum_kernel)
@@ -393,11 +397,12 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
         hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, d.roff, d.rlen, nreads, packed_bytes, c->d_err);
         c->index_unchecked = true;
     }
-    c->zc_src = zc;
+    c->zc_src = slab_ingest ? nullptr : zc;
+    c->h2d_src = slab_ingest ? packed : nullptr; c->h2d_slabs = slabs_env;
     tmark(zc ? (derive ? "input enqueued (zero-copy packed, offsets derived from the lengths)" : "input enqueued (zero-copy packed)") : "input enqueued (copies)");
     if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
     tmark("pipeline returned");
-    c->zc_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr;
+    c->zc_src = nullptr; c->h2d_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr;
     if (c->roff_check.valid()) (void)c->roff_check.get();          // (the pipeline failed before it collected the verdict)
     c->pool.release(d_given); c->pool.release(d_tsum);
     free_input(c, d);

@@ -63,17 +63,27 @@ static bool place_bytes_enabled(bool supermers_travel)
     return env < 0 ? supermers_travel : env != 0;
 }
 
+// nslabs > 1 (scan_kernel / place_kernel / place_bytes_kernel only): every workgroup owns one run of tiles per slab, see ParseArgs
 static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen,
-                                 u64 nreads, int64_t rid_base, u32 ntasks, u32 *nblocks_out)
+                                 u64 nreads, int64_t rid_base, u32 ntasks, u32 *nblocks_out, u32 nslabs = 1)
 {
     ParseArgs a; memset(&a, 0, sizeof a);
     a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
     a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks);
     a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
     u32 nblocks = (u32)std::min<u64>(a.ntiles, 1024);
+    a.rid_base = rid_base;
+    if (nslabs > 1 && a.ntiles >= (u64)nblocks * nslabs) {
+        const u64 per_slab = (a.ntiles + nslabs - 1) / nslabs;
+        a.tiles_per_block = (u32)((per_slab + nblocks - 1) / nblocks);
+        a.slab_tiles = (u64)a.tiles_per_block * nblocks;
+        a.nslabs = (u32)((a.ntiles + a.slab_tiles - 1) / a.slab_tiles);
+        *nblocks_out = nblocks;
+        return a;
+    }
     a.tiles_per_block = (u32)((a.ntiles + nblocks - 1) / nblocks);
     nblocks = (u32)((a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block);
-    a.rid_base = rid_base;
+    a.nslabs = 1; a.slab = 0; a.slab_tiles = 0;
     *nblocks_out = nblocks;
     return a;
 }
@@ -125,12 +135,16 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     j.task_tot.assign((size_t)ntasks * 3, 0);
     if (nreads == 0 || packed_bytes == 0) return HSK_OK;            // nothing to parse on this rank
     j.empty = false;
-    j.a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
+    j.fast = parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
+    // slab ingest (hsk_count() from pinned memory): only the fast path hashes slab by slab; everything else wants the reads in HBM first
+    const u8 *h2d_src = c->h2d_src; c->h2d_src = nullptr;
+    if (h2d_src && !j.fast) { HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), h2d_src, packed_bytes, hipMemcpyHostToDevice, c->stream)); h2d_src = nullptr; }
+    j.a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks, h2d_src ? (u32)c->h2d_slabs : 1);
     ParseArgs &a = j.a;
-    DALLOC(c, j.d_blk_cnt, u64 *, (size_t)j.nblocks * ntasks * 3 * 8);
+    if (h2d_src && a.nslabs <= 1) { HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), h2d_src, packed_bytes, hipMemcpyHostToDevice, c->stream)); h2d_src = nullptr; }   // (too small for slabs)
+    DALLOC(c, j.d_blk_cnt, u64 *, (size_t)1024 * ntasks * 3 * 8);
     a.blk_cnt = j.d_blk_cnt;
     u64 *d_task_tot; DALLOC(c, d_task_tot, u64 *, (size_t)ntasks * 3 * 8 + 64);
-    j.fast = parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
     u32 *h_ovf = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
     *h_ovf = 0;
     if (j.fast) {
@@ -146,9 +160,33 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
         static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;      // (tests: the default (k, m) through the generic instance)
-        if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
-        else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
-        else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        auto launch_scan = [&]() {
+            if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+            else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+            else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        };
+        if (h2d_src) {
+            // The packed reads cross PCIe as DMA copies, slab by slab, on the copy stream; the scan of slab s is launched behind the
+            // copy of slab s + 1 (a tile's windows reach a few words into the next tile), so the link and the VALUs work side by side:
+            // the parse takes about as long as the transfer (a kernel reading the host buffer in place gets ~40 GB/s out of the link,
+            // the DMA engine ~55).
+            std::vector<hipEvent_t> landed(a.nslabs);
+            EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, c->d2h_stream); }
+            for (u32 sl = 0; sl < a.nslabs; ++sl) {
+                const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
+                if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, c->d2h_stream));
+                landed[sl] = ev_get(c);
+                HIPCHK(c, hipEventRecord(landed[sl], c->d2h_stream));
+            }
+            if (profile) { (void)hipEventRecord(hp.b, c->d2h_stream); c->ev_pending.push_back(hp); }
+            for (u32 sl = 0; sl < a.nslabs; ++sl) {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, landed[std::min(sl + 1, a.nslabs - 1)], 0));
+                a.slab = sl;
+                launch_scan();
+            }
+            a.slab = 0;
+            for (auto e : landed) ev_put(c, e);
+        } else launch_scan();
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         a.packed = d_packed; a.packed_copy = nullptr; c->zc_src = nullptr;                                  // everything after the scan reads the copy in HBM
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
@@ -175,6 +213,11 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         }
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
+            if (a.nslabs > 1) {                                       // the general kernels know one tile range per workgroup
+                ParseArgs b = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
+                b.blk_cnt = a.blk_cnt; b.rec_cap = a.rec_cap; b.place_group = a.place_group;
+                a = b;
+            }
             c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; a.tile_r0 = nullptr;
             c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); j.d_tile_rec = j.d_tile_nrec = nullptr;
             a.tile_rec = a.tile_nrec = nullptr;

@@ -217,7 +217,7 @@ struct WidenPool {
         static const int n = []() {
             if (const char *e = getenv("HSK_WIDEN_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 64); }
             const unsigned hc = std::thread::hardware_concurrency();
-            return (int)std::min<unsigned>(16, std::max<unsigned>(2, hc / 2));
+            return (int)std::min<unsigned>(32, std::max<unsigned>(2, hc / 2));
         }();
         return n;
     }
@@ -231,7 +231,11 @@ struct WidenPool {
             th.emplace_back([=]() {
                 (void)hipSetDevice(dev);
                 (void)hipEventSynchronize(copied);
-                if (nw == 1) for (u64 i = lo; i < hi; ++i) { dst[2 * i] = keys[i]; dst[2 * i + 1] = cnts[i]; }
+                // one-word keys: an entry is one aligned 16-byte store that nobody reads back soon -- non-temporal (no read for ownership:
+                // a plain store loop is bound by the cache lines it first has to fetch)
+                typedef unsigned long long v2u64 __attribute__((vector_size(16)));
+                if (nw == 1 && ((uintptr_t)dst & 15) == 0) for (u64 i = lo; i < hi; ++i) { const v2u64 e = {keys[i], (unsigned long long)cnts[i]}; __builtin_nontemporal_store(e, (v2u64 *)dst + i); }
+                else if (nw == 1) for (u64 i = lo; i < hi; ++i) { dst[2 * i] = keys[i]; dst[2 * i + 1] = cnts[i]; }
                 else for (u64 i = lo; i < hi; ++i) { for (int w = 0; w < nw; ++w) dst[i * (nw + 1) + w] = keys[i * nw + w]; dst[i * (nw + 1) + nw] = cnts[i]; }
             });
         }

@@ -50,6 +50,12 @@ struct ParseArgs {
     FastMod fm;
     u64 ntiles;
     u32 tiles_per_block;
+    // Slabs (hsk_count() from pinned host memory: the packed reads arrive slab by slab over PCIe while the slabs before are
+    // hashed): workgroup b owns, inside every slab s, the tiles [s * slab_tiles + b * tiles_per_block, + tiles_per_block).
+    // nslabs <= 1: one range per workgroup as ever.  scan_kernel takes slab `slab` per launch and adds its counts to blk_cnt
+    // (slab > 0); the placement kernels walk all slabs of the workgroup in the same order.
+    u32 nslabs, slab;
+    u64 slab_tiles;
     int64_t rid_base;
     // COUNT: blk_cnt[block][task][3] = {supermers, bytes, kmers}
     u64 *blk_cnt;
@@ -510,7 +516,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     const int K = KT ? KT : a.k, M = MT ? MT : a.m, W = K - M + 1;
     const u64 mmask = ~0ULL << (64 - 2 * M);
     for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
-    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
+    const u64 tile0 = (u64)a.slab * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
+    const u64 tile_end = (a.nslabs > 1 && ((u64)a.slab + 1) * a.slab_tiles < a.ntiles) ? ((u64)a.slab + 1) * a.slab_tiles : a.ntiles;   // this launch's tiles end here
     if (tid == 0) s_rng[1] = (tile0 < a.ntiles) ? find_read(a.roff, 0, a.nreads - 1, (tile0 * PARSE_TILE) >> 2) : 0;
     __syncthreads();
     const u64 RINF = ~0ULL >> 2;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 #endif
     for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
         const u64 tile = tile0 + ti;
-        if (tile >= a.ntiles) break;
+        if (tile >= tile_end) break;
         const u64 gbase = tile * PARSE_TILE;
         const u64 bbase = gbase >> 2;
 #ifdef HSK_DIAG
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         // barrier of the loop is an LDS-only barrier: none of them waits for these loads or for the record stores)
         {
             const u64 nb = bbase + PARSE_TILE / 4;
-            pf_have = (ti + 1 < a.tiles_per_block) && (tile + 1 < a.ntiles) && (nb + (u64)PARSE_WORDS * 4 <= a.packed_bytes);
+            pf_have = (ti + 1 < a.tiles_per_block) && (tile + 1 < tile_end) && (nb + (u64)PARSE_WORDS * 4 <= a.packed_bytes);
             if (pf_have) {
                 if (tid < PARSE_RWIN) {
                     const u64 idx = s_rng[1] + tid;                   // the read holding this tile's last byte is the next tile's first
@@ -741,7 +748,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
         u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
         const u64 pk = s_cur[2 * t];
-        o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
+        if (a.slab == 0) { o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1); }
+        else { o[0] += pk >> 40; o[1] += s_cur[2 * t + 1]; o[2] += pk & ((1ULL << 40) - 1); }      // (same workgroup, launches in stream order)
     }
 }
 
@@ -761,13 +769,16 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
     u32 *s_tpre = s_tcnt + a.ntasks;
     u32 *s_srt = s_tpre + a.ntasks;
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] = a.blk_base[((u64)blockIdx.x * a.ntasks + t) * 2];
-    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
     const u32 G = a.place_group;
+    const u32 nsl = a.nslabs > 1 ? a.nslabs : 1;
+    for (u32 sl = 0; sl < nsl; ++sl) {
+    const u64 tile0 = (u64)sl * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
+    const u64 tile_end = (nsl > 1 && ((u64)sl + 1) * a.slab_tiles < a.ntiles) ? ((u64)sl + 1) * a.slab_tiles : a.ntiles;
     for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
         const u64 tfirst = tile0 + t0;
-        if (tfirst >= a.ntiles) break;
+        if (tfirst >= tile_end) break;
         u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
-        if (tfirst + ng > a.ntiles) ng = (u32)(a.ntiles - tfirst);
+        if (tfirst + ng > tile_end) ng = (u32)(tile_end - tfirst);
         __syncthreads();                                                // previous step done with s_go / s_tcnt / s_srt
         if (tid == 0) {
             u32 run = 0;
@@ -815,6 +826,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
         __syncthreads();
         for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
     }
+    }                                                                   // slabs
 }
 
 // Byte-store placement.  Same job as place_kernel, and in addition every supermer's bases are copied out of the packed
@@ -848,14 +860,17 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
         s_curb[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2 + 1];
         s_tbase[t] = a.task_base3[3 * t + 1];
     }
-    const u64 tile0 = (u64)blockIdx.x * a.tiles_per_block;
     const u32 G = a.place_group;
     const u32 *p32 = reinterpret_cast<const u32 *>(a.packed);
+    const u32 nsl = a.nslabs > 1 ? a.nslabs : 1;
+    for (u32 sl = 0; sl < nsl; ++sl) {
+    const u64 tile0 = (u64)sl * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
+    const u64 tile_end = (nsl > 1 && ((u64)sl + 1) * a.slab_tiles < a.ntiles) ? ((u64)sl + 1) * a.slab_tiles : a.ntiles;
     for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
         const u64 tfirst = tile0 + t0;
-        if (tfirst >= a.ntiles) break;
+        if (tfirst >= tile_end) break;
         u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
-        if (tfirst + ng > a.ntiles) ng = (u32)(a.ntiles - tfirst);
+        if (tfirst + ng > tile_end) ng = (u32)(tile_end - tfirst);
         __syncthreads();                                                // previous step done with s_go / s_tc / s_srt / s_words
         if (tid == 0) {
             u32 run = 0;
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
         __syncthreads();
         for (u32 t = tid; t < nt; t += PARSE_THREADS) { const u64 c = s_tc[t]; s_cur[t] += c >> 32; s_curb[t] += c & 0xFFFFFFFFu; }
     }
+    }                                                                   // slabs
 }
 
 // EXTENSION: (PosInRead, ReadId) of every supermer from its base position (one index search per supermer;

@@ -104,3 +104,27 @@ def test_pinned_input_with_gaps_between_reads():
     assert len(ref) > 100000
     for x in (a, b):
         assert np.array_equal(ref.kmers, x.kmers) and np.array_equal(ref.cnt, x.cnt) and np.array_equal(ref.task_off, x.task_off)
+
+
+def test_slab_ingest_equals_reads_in_place():
+    """Pinned input above 32 MB: the packed reads arrive as DMA copies slab by slab while the scan hashes the slabs before
+    (HSK_H2D_SLABS=8 by default, 3 here as well; the last slab is short and a read straddles every slab edge); =0: the scan reads
+    the host buffer in place as in round 2.  Same list, same histogram, and equal to the pageable path.  Subprocesses: the
+    switch is read once."""
+    import subprocess, sys, os
+    from tests import util
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "from hysortk_amd import synth\n"
+            "n = (1 << 20) + 77777\n"
+            "packed, off, lens = synth.packed_reads(2000000, 150, n, 21)\n"
+            "pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)\n"
+            "pp[:] = packed; po[:] = off; pl[:] = lens\n"
+            "c = H.Context(K=31, M=17, L=2, U=200, ntasks=16)\n"
+            "for src in ((pp, po, pl), (packed, off, lens), (pp, po, pl)):\n"
+            "    r = c.count(src)\n"
+            "    print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
+    outs = []
+    for env in ({}, {"HSK_H2D_SLABS": "3"}, {"HSK_H2D_SLABS": "0"}, {"HSK_H2D_SLABS": "8", "HSK_PARSE_REC_CAP": "300"}):
+        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
+    assert len(outs) == 12 and len({o[0] for o in outs}) == 1, outs
+    assert int(outs[0][1]) > 100000
