@@ -381,7 +381,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     }
     // pinned input of some size: slab ingest (DMA copies pipelined with the scan, parse_count) instead of reads over PCIe in place;
     // HSK_H2D_SLABS=0: in place as in round 2, =n: n slabs
-    static const int slabs_env = getenv("HSK_H2D_SLABS") ? atoi(getenv("HSK_H2D_SLABS")) : 8;
+    static const int slabs_env = getenv("HSK_H2D_SLABS") ? atoi(getenv("HSK_H2D_SLABS")) : 16;
     const bool slab_ingest = zc != nullptr && slabs_env > 1 && packed_bytes >= (32u << 20);
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     static const bool derive_enabled = !(getenv("HSK_DERIVE_OFFSETS") && atoi(getenv("HSK_DERIVE_OFFSETS")) == 0);

@@ -207,6 +207,7 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
 // Host threads that widen compact result batches (pack_entries_kernel's k-mer words + 16-bit counts, copied into pinned staging)
 // into the caller-visible entries while the GPU counts the next batches.  Every thread of a batch waits for the batch's copy
 // event, then takes its slice.  The destructor joins: no thread outlives the call that started it.
+struct WidenPiece { hipEvent_t copied; const u64 *keys; const unsigned short *cnts; u64 *dst; u64 n; };      // one task's share of a batch
 struct WidenPool {
     hsk_ctx *c;
     std::vector<std::thread> th;
@@ -221,22 +222,26 @@ struct WidenPool {
         }();
         return n;
     }
-    // keys: n * nw words, cnts: n values (pinned staging, valid once `copied` has happened); dst: n entries of nw + 1 words
-    void add(hipEvent_t copied, const u64 *keys, const unsigned short *cnts, u64 *dst, u64 n, int nw)
+    // A batch arrives task by task (one copy + one event per piece): thread t widens slice t of every piece in turn, so that all
+    // threads are done shortly after the LAST piece has landed -- the tail of the call is one piece's widening, not one batch's.
+    void add(const std::vector<WidenPiece> &pieces, int nw)
     {
-        evs.push_back(copied);
+        for (auto &p : pieces) evs.push_back(p.copied);
         const int nt = nthreads(), dev = c->cfg.device;
         for (int t = 0; t < nt; ++t) {
-            const u64 lo = n * (u64)t / nt, hi = n * (u64)(t + 1) / nt;
             th.emplace_back([=]() {
                 (void)hipSetDevice(dev);
-                (void)hipEventSynchronize(copied);
-                // one-word keys: an entry is one aligned 16-byte store that nobody reads back soon -- non-temporal (no read for ownership:
-                // a plain store loop is bound by the cache lines it first has to fetch)
-                typedef unsigned long long v2u64 __attribute__((vector_size(16)));
-                if (nw == 1 && ((uintptr_t)dst & 15) == 0) for (u64 i = lo; i < hi; ++i) { const v2u64 e = {keys[i], (unsigned long long)cnts[i]}; __builtin_nontemporal_store(e, (v2u64 *)dst + i); }
-                else if (nw == 1) for (u64 i = lo; i < hi; ++i) { dst[2 * i] = keys[i]; dst[2 * i + 1] = cnts[i]; }
-                else for (u64 i = lo; i < hi; ++i) { for (int w = 0; w < nw; ++w) dst[i * (nw + 1) + w] = keys[i * nw + w]; dst[i * (nw + 1) + nw] = cnts[i]; }
+                for (const WidenPiece &p : pieces) {
+                    (void)hipEventSynchronize(p.copied);
+                    const u64 lo = p.n * (u64)t / nt, hi = p.n * (u64)(t + 1) / nt;
+                    const u64 *keys = p.keys; const unsigned short *cnts = p.cnts; u64 *dst = p.dst;
+                    // one-word keys: an entry is one aligned 16-byte store that nobody reads back soon -- non-temporal (no read for
+                    // ownership: a plain store loop is bound by the cache lines it first has to fetch)
+                    typedef unsigned long long v2u64 __attribute__((vector_size(16)));
+                    if (nw == 1 && ((uintptr_t)dst & 15) == 0) for (u64 i = lo; i < hi; ++i) { const v2u64 e = {keys[i], (unsigned long long)cnts[i]}; __builtin_nontemporal_store(e, (v2u64 *)dst + i); }
+                    else if (nw == 1) for (u64 i = lo; i < hi; ++i) { dst[2 * i] = keys[i]; dst[2 * i + 1] = cnts[i]; }
+                    else for (u64 i = lo; i < hi; ++i) { for (int w = 0; w < nw; ++w) dst[i * (nw + 1) + w] = keys[i * nw + w]; dst[i * (nw + 1) + nw] = cnts[i]; }
+                }
             });
         }
     }
@@ -378,22 +383,25 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             if (!early_buf) { early = false; return HSK_OK; }
         }
         if (early_used + nb > early_cap) { early = false; return HSK_OK; }                       // the guess was too small: copy at the end
-        // compact: the batch's entries are packed on the main stream (k-mer words, then the 16-bit counts), copied as ONE block into
-        // pinned staging and widened into early_buf by host threads while the next batch is counted
+        // compact: every task's entries are packed on the main stream ([k-mer words][16-bit counts], 16-byte aligned per task), copied
+        // task by task into pinned staging and widened into early_buf by host threads while the next batch is counted
         u8 *d_pk = nullptr, *h_pk = nullptr;
+        size_t pk_off[XCD_BATCH + 1] = {0};
         if (compact && nb) {
-            const size_t pk_bytes = (size_t)nb * (NW * 8 + 2) + 64;
+            for (int i = 0; i < ntk; ++i) {
+                const u64 n_i = (tasks[i] == EMPTY_TASK) ? 0 : touts[tasks[i]].n;
+                pk_off[i + 1] = pk_off[i] + (((size_t)n_i * (NW * 8 + 2) + 15) & ~(size_t)15);
+            }
+            const size_t pk_bytes = pk_off[ntk] + 64;
             d_pk = (u8 *)c->pool.alloc(pk_bytes); h_pk = (u8 *)host_alloc(c, rp, pk_bytes);
             if (!d_pk || !h_pk) { c->pool.release(d_pk); if (h_pk) host_release(c, rp, h_pk); d_pk = nullptr; h_pk = nullptr; }      // (no room: this batch travels as it is)
             else {
                 pk_dev.push_back(d_pk); pk_host.push_back(h_pk);
-                u64 o = 0;
                 for (int i = 0; i < ntk; ++i) {
                     if (tasks[i] == EMPTY_TASK || !touts[tasks[i]].n) continue;
                     const TaskOut &to = touts[tasks[i]];
                     hipLaunchKernelGGL(pack_entries_kernel, dim3((u32)std::min<u64>((to.n + 255) / 256, 2048)), dim3(256), 0, c->stream, to.entries, to.n, NW,
-                                       (u64 *)d_pk + o * NW, (unsigned short *)(d_pk + (size_t)nb * NW * 8) + o);
-                    o += to.n;
+                                       (u64 *)(d_pk + pk_off[i]), (unsigned short *)(d_pk + pk_off[i] + (size_t)to.n * NW * 8));
                 }
             }
         }
@@ -403,10 +411,20 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         ev_put(c, done);
         EvPair ep{}; if (profile_ev) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 6; (void)hipEventRecord(ep.a, c->d2h_stream); }
         if (d_pk) {
-            HIPCHK(c, hipMemcpyAsync(h_pk, d_pk, (size_t)nb * (NW * 8 + 2), hipMemcpyDeviceToHost, c->d2h_stream));
-            hipEvent_t cp = ev_get(c);
-            HIPCHK(c, hipEventRecord(cp, c->d2h_stream));
-            widen.add(cp, (const u64 *)h_pk, (const unsigned short *)(h_pk + (size_t)nb * NW * 8), early_buf + early_used * (NW + 1), nb, NW);
+            std::vector<WidenPiece> pieces;
+            u64 o = 0;
+            for (int i = 0; i < ntk; ++i) {
+                if (tasks[i] == EMPTY_TASK || !touts[tasks[i]].n) continue;
+                const u64 n_i = touts[tasks[i]].n;
+                HIPCHK(c, hipMemcpyAsync(h_pk + pk_off[i], d_pk + pk_off[i], (size_t)n_i * (NW * 8 + 2), hipMemcpyDeviceToHost, c->d2h_stream));
+                WidenPiece wp; wp.copied = ev_get(c);
+                HIPCHK(c, hipEventRecord(wp.copied, c->d2h_stream));
+                wp.keys = (const u64 *)(h_pk + pk_off[i]); wp.cnts = (const unsigned short *)(h_pk + pk_off[i] + (size_t)n_i * NW * 8);
+                wp.dst = early_buf + (early_used + o) * (NW + 1); wp.n = n_i;
+                pieces.push_back(wp);
+                o += n_i;
+            }
+            widen.add(pieces, NW);
             compact_bytes += (u64)nb * (NW * 8 + 2); compact_entries += nb;
         }
         for (int i = 0; i < ntk; ++i) {
