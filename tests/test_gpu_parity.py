@@ -411,6 +411,37 @@ def test_full_size_properties_both_expand_paths():
     assert int(outs[0][0]) > 300_000_000 and int(outs[0][3]) == 40 and int(outs[0][4]) == 40
 
 
+def test_reported_supermer_totals_follow_the_documented_rule(H, O):
+    """hsk_result.total_supermers / total_supermer_bytes (the 1.1 B per k-mer of the roofline arithmetic) against an independent
+    restatement of THIS library's supermer rule (a supermer starts where a read's first k-mer starts, at every
+    position of the rank's base stream that is a multiple of 128, and wherever the window minimum -- the hash VALUE -- changes),
+    computed from the oracle's m-mer hashes.  The k-mers those supermers hold are compared elsewhere (per-task multisets)."""
+    from hysortk_amd import synth
+    for K, M, nreads, rl in ((31, 17, 3000, 150), (51, 17, 1500, 250), (21, 9, 2000, 101), (31, 17, 40, 5000)):
+        seqs = list(synth.reads(60000, rl, nreads, 17)) + ["ACGT" * 40, "A" * 300, "C" * (K - 1), "G" * K]
+        pk, off, ln = O.pack_reads(seqs)
+        nsup = nbytes = 0
+        W = K - M + 1
+        for r, s_ in enumerate(seqs):
+            n = len(s_)
+            if n < K:
+                continue
+            h = O.mmer_hashes(pk[int(off[r]):], n, M)
+            mins = np.lib.stride_tricks.sliding_window_view(h, W).min(axis=1)         # one per k-mer
+            g = 4 * int(off[r]) + np.arange(mins.size)
+            start = np.ones(mins.size, dtype=bool)
+            start[1:] = (mins[1:] != mins[:-1]) | (g[1:] % 128 == 0)
+            idx = np.flatnonzero(start)
+            nk = np.diff(np.append(idx, mins.size))
+            nsup += idx.size
+            nbytes += int(((nk + K - 1 + 3) // 4).sum())
+        with H.Context(K=K, M=M, L=1, U=65535, ntasks=7) as c:
+            res = c.count((pk, off, ln))
+        assert res.info["total_supermers"] == nsup, (K, M, res.info["total_supermers"], nsup)
+        assert res.info["total_supermer_bytes"] == nbytes + nsup, (K, M)
+        assert int(nk.max()) <= 128
+
+
 def _oracle_digests_of_device_reads(c, dp, nb, do, dl, NR, RL, k, ext, ntasks, rid_base=0):
     """per-task (n, mix) of the reads resident in HBM, computed by the CPU oracle's streaming digests (oracle/hsk_oracle.c
     hsko_task_digests: every k-mer instance of every read, ~20 M positions/s per host thread)"""
