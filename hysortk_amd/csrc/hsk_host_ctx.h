@@ -73,7 +73,7 @@ struct HostPool {
         { size_t g = 4096; while (g * 16 <= bytes) g <<= 1; bytes = (bytes + g - 1) & ~(g - 1); }
         auto it = free_blocks.lower_bound(bytes);
         if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
-            void *p = it->second; live[p] = it->first; free_blocks.erase(it); return p;
+            void *p = it->second; live[p] = it->first; bytes_cached -= it->first; free_blocks.erase(it); return p;
         }
         void *p = nullptr;
         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
@@ -84,14 +84,21 @@ struct HostPool {
         live[p] = bytes;
         return p;
     }
+    // cached (free) pinned blocks are capped: a 10 Gbp call leaves ~8 GB of result and staging blocks behind, which the next call of
+    // the same size takes again; beyond the cap the largest cached blocks go back to the system
+    static constexpr size_t CACHE_CAP = (size_t)24 << 30;
+    size_t bytes_cached = 0;
     void release(void *p)
     {
         auto it = live.find(p);
         if (it == live.end()) return;
-        free_blocks.insert({it->second, p}); live.erase(it);
+        free_blocks.insert({it->second, p}); bytes_cached += it->second; live.erase(it);
+        while (bytes_cached > CACHE_CAP && !free_blocks.empty()) { auto big = std::prev(free_blocks.end()); (void)hipHostFree(big->second); bytes_cached -= big->first; free_blocks.erase(big); }
     }
-    void trim() { for (auto &kv : free_blocks) (void)hipHostFree(kv.second); free_blocks.clear(); }
-    void destroy() { trim(); for (auto &kv : live) (void)hipHostFree(kv.first); live.clear(); }
+    void trim() { for (auto &kv : free_blocks) (void)hipHostFree(kv.second); free_blocks.clear(); bytes_cached = 0; }
+    // hsk_destroy: the cache goes; blocks of results the caller still holds are NOT freed here (they belong to the results:
+    // hsk_result_free(NULL, &res) releases them after the context is gone, include/hsk.h)
+    void destroy() { trim(); live.clear(); }
 };
 
 struct EvPair { hipEvent_t a, b; int kind; u64 keys; u64 bytes; };

@@ -184,6 +184,8 @@ int hsk_count_loopback(hsk_ctx *ctx, int nranks, const uint8_t *const *packed, c
                        const uint64_t *const *read_byte_off, const uint32_t *const *read_len, const uint64_t *nreads,
                        hsk_result *outs, int32_t *owner_out, int32_t owner_capacity);
 
+/* ctx == NULL is allowed when the context is already destroyed: a result outlives its context (its pinned host blocks belong to the
+ * result; hsk_destroy frees only the context's cache of released blocks). */
 void hsk_result_free(hsk_ctx *ctx, hsk_result *res);
 /* HSK_FLAG_KEEP_DEVICE: where task `task`'s share of the result lives in HBM -- entries (n records of nw + 1 words), and with
  * EXTENSION the CSR payload: payload_off (n values in the rank's payload numbering), pos / rid (npay values each, the

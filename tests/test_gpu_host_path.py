@@ -128,3 +128,25 @@ def test_slab_ingest_equals_reads_in_place():
         outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
     assert len(outs) == 12 and len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
+
+
+def test_result_outlives_its_context():
+    """hsk_destroy() before hsk_result_free(NULL, &res): the result's pinned blocks belong to the result (include/hsk.h); they must
+    stay readable after the context is gone and be released exactly once."""
+    import ctypes as C
+    import hysortk_amd as H
+    from hysortk_amd import _lib, synth
+    packed, off, lens = synth.packed_reads(200000, 150, 20000, 4)
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=5) as c:
+        want = c.count((packed, off, lens))
+    L = _lib.load()
+    ctx = H.Context(K=31, M=17, L=1, U=65535, ntasks=5)
+    res = _lib.Result()
+    assert L.hsk_count(ctx.h, packed.ctypes.data_as(C.c_void_p), packed.size, off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), lens.size, 0, C.byref(res)) == 0
+    ctx.close()                                                   # hsk_destroy
+    n = int(res.n)
+    e = np.ctypeslib.as_array(res.entries, shape=(n * 2,)).reshape(n, 2).copy()
+    histo = np.ctypeslib.as_array(res.histo, shape=(int(res.histo_len),)).copy()
+    L.hsk_result_free(None, C.byref(res))
+    assert not res.entries and int(res.n) == 0
+    assert np.array_equal(e[:, 0], want.kmers[:, 0]) and np.array_equal(e[:, 1], want.cnt) and np.array_equal(histo, want.histo)
