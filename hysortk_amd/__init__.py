@@ -6,6 +6,6 @@ Python host mirror of the reference's four public functions and types.
 """
 from .api import (Context, DnaBuffer, DnaSeq, HskError, KmerList, histogram_text, kmer_count, pack_sequence,  # noqa: F401
                   plan_classify, plan_dispatch, plan_exchange, plan_partition_reads, plan_tot_tasks, print_kmer_histogram,
-                  read_dna_buffer, read_fai, write_output_file, DeviceDna, DeviceResult, read_dna_buffer_device, pinned_empty, pinned_free)
+                  read_dna_buffer, read_fai, write_output_file, paradis_order, DeviceDna, DeviceResult, read_dna_buffer_device, pinned_empty, pinned_free)
 
 __version__ = "0.1.0"

@@ -646,6 +646,42 @@ def histogram_text(histo):
     return "\n".join(lines) + "\n\n"
 
 
+def paradis_order(kmers, cnt, task_off):
+    """The order a PARADIS build of the reference (SORT=1, or SORT=0 without SLURM_TASKS_PER_NODE: src/kmerops.cpp:1330-1360) leaves an
+    UNFILTERED task in, for multi-word keys (K > 32; for K <= 32 both sorters give ascending u64).  paradis::sort
+    (dependency/Paradis/paradissort.hpp:42-216) partitions by key byte from byte NBYTES-1 down -- the key as a little-endian multi-word
+    integer, which is the order this library returns -- and hands every bucket of 2..64 k-mer INSTANCES to std::sort with operator<
+    (longs[0] first, include/kmer.hpp:217), buckets of more than 64 to the next byte, nothing below byte 0.  Returns the permutation that
+    turns this library's list into that order.  The bucket sizes count instances, so the order of a FILTERED list depends on k-mers the
+    filter dropped and cannot be rebuilt from the list (L = 1, U = 65535 only)."""
+    kmers = np.asarray(kmers, dtype=np.uint64)
+    cnt = np.asarray(cnt, dtype=np.uint64)
+    n, nw = kmers.shape
+    perm = np.arange(n, dtype=np.int64)
+    kb = np.ascontiguousarray(kmers).view(np.uint8).reshape(n, nw * 8)        # byte b of the key = column b (little endian)
+    csum = np.concatenate([[0], np.cumsum(cnt.astype(np.int64))])
+
+    def rec(lo, hi, byte):
+        col = kb[lo:hi, byte]
+        cuts = np.flatnonzero(col[1:] != col[:-1]) + 1
+        bounds = [lo] + (cuts + lo).tolist() + [hi]
+        if byte == 0:
+            return
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            c = int(csum[b] - csum[a])
+            if c > 64:
+                rec(a, b, byte - 1)
+            elif c > 1 and b - a > 1:
+                order = np.lexsort(tuple(kmers[a:b, j] for j in range(nw - 1, -1, -1)))      # operator<: longs[0] most significant
+                perm[a:b] = a + order
+
+    for t in range(len(task_off) - 1):
+        a, b = int(task_off[t]), int(task_off[t + 1])
+        if b - a > 1:
+            rec(a, b, nw * 8 - 1)
+    return perm
+
+
 def print_kmer_histogram(kmerlist, comm=None, file=None):
     histo = np.asarray(kmerlist.histo, dtype=np.uint64)
     if comm is not None and comm.size > 1:

@@ -176,6 +176,10 @@ def test_count_golden_k51_paradis_multiset(H):
         res = c.count(dna)
     gold = util.load_count("count_k51p.txt")
     assert sorted(zip(res.strings(), res.cnt.tolist())) == sorted((g[0], g[1]) for g in gold)
+    # ... and element for element once the list is put into PARADIS order (unfiltered lists only, see hysortk_amd.paradis_order)
+    perm = H.paradis_order(res.kmers, res.cnt, res.task_off)
+    strs = res.strings()
+    assert [strs[i] for i in perm] == [g[0] for g in gold] and res.cnt[perm].tolist() == [g[1] for g in gold]
 
 
 def test_count_golden_extension(H):

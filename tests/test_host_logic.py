@@ -146,3 +146,20 @@ def test_plan_exchange_covers_everything_exactly():
             for p in range(nranks):                   # segment lies inside the region received from p
                 if segs[t, p, 1]:
                     assert sr[p, 6] <= segs[t, p, 0] and segs[t, p, 0] + segs[t, p, 1] <= sr[p, 6] + sr[p, 4]
+
+
+def test_paradis_order_rebuilds_the_reference_raw_vector_k51():
+    """K=51 built with PARADIS (golden count_k51p.txt, raw KmerListS order of the real reference): the oracle's list in this library's
+    order (little-endian multi-word, = RADULS) permuted by hysortk_amd.paradis_order must reproduce it element for element."""
+    import hysortk_amd as H
+    from oracle import hsk_oracle as O
+    from tests import util
+    seqs = util.read_fasta(util.GOLDEN + "/reads_small.fa")
+    pk, off, ln = O.pack_reads(seqs)
+    r = O.count(pk, off, ln, k=51, m=17, L=1, U=65535, ntasks=5, sorter=2)
+    gold = util.load_count("count_k51p.txt")
+    raduls = util.result_strings(r.keys, 51)
+    assert raduls != [g[0] for g in gold]                       # the two sorters do order K=51 differently
+    perm = H.paradis_order(r.keys, r.cnt, r.task_off)
+    assert [raduls[i] for i in perm] == [g[0] for g in gold]
+    assert r.cnt[perm].tolist() == [g[1] for g in gold]
