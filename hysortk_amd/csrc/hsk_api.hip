@@ -930,6 +930,62 @@ extern "C" int hsk_copy_peak(hsk_ctx *c, uint64_t bytes, int iters, double *gbs)
     return HSK_OK;
 }
 
+// Experiment (tools/parse_overlap.py; not part of include/hsk.h): can the placement of one set of reads run BESIDE the minimizer scan of
+// another?  out_ms: [0] scan with 1024 workgroups, [1] scan with `blocks` workgroups, [2] placement alone, [3] scan(`blocks`) on the
+// main stream and the placement on the second stream at the same time (start of both to end of both), [4] scan inside [3], [5] placement inside [3].
+extern "C" int hsk_debug_parse_overlap(hsk_ctx *c, const void *d_packed, uint64_t packed_bytes, const void *d_off, const void *d_len, uint64_t nreads,
+                                       uint32_t blocks, double *out_ms)
+{
+    if (!c || !out_ms) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
+    u64 *roff; DALLOC(c, roff, u64 *, (nreads + 1) * 8);
+    HIPCHK(c, hipMemcpyAsync(roff, d_off, nreads * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(roff + nreads, &packed_bytes, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : 40;
+    std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    hipEvent_t e[6]; for (auto &x : e) x = ev_get(c);
+    auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0; (void)hipEventElapsedTime(&f, a, b); return (double)f; };
+    int rc;
+    ParseJob j1, j2, j3; SupermerStore st1, st2;
+    (void)hipEventRecord(e[0], c->stream);
+    rc = parse_count(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, 0, ntasks, j1); if (rc) return rc;
+    (void)hipEventRecord(e[1], c->stream);
+    rc = parse_place(c, j1, order, st1); if (rc) return rc;
+    (void)hipEventRecord(e[2], c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out_ms[0] = ms(e[0], e[1]); out_ms[2] = ms(e[1], e[2]);
+    c->scan_blocks = blocks;
+    (void)hipEventRecord(e[0], c->stream);
+    rc = parse_count(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, 0, ntasks, j2);
+    (void)hipEventRecord(e[1], c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (rc) { c->scan_blocks = 0; return rc; }
+    out_ms[1] = ms(e[0], e[1]);
+    // both at once: the placement of j1's records (again, into a second store) on the second stream, the scan of j3 on the main stream
+    (void)hipEventRecord(e[0], c->stream);
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, e[0], 0));
+    hipStream_t main_s = c->stream;
+    c->stream = c->comm_stream;
+    (void)hipEventRecord(e[3], c->stream);
+    rc = parse_place(c, j1, order, st2);
+    (void)hipEventRecord(e[4], c->stream);
+    c->stream = main_s;
+    if (rc) { c->scan_blocks = 0; return rc; }
+    rc = parse_count(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, 0, ntasks, j3);
+    (void)hipEventRecord(e[1], c->stream);
+    c->scan_blocks = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (rc) return rc;
+    out_ms[4] = ms(e[0], e[1]); out_ms[5] = ms(e[3], e[4]);
+    out_ms[3] = std::max(ms(e[0], e[1]), ms(e[0], e[4]));
+    parse_release(c, j1); parse_release(c, j2); parse_release(c, j3); free_store(c, st1); free_store(c, st2);
+    c->pool.release(roff);
+    for (auto x : e) ev_put(c, x);
+    return HSK_OK;
+}
+
 // diagnostic build only: phase clock sums of the onesweep kernel (zeros in the product build)
 extern "C" int hsk_debug_diag(unsigned long long *out, int n, int reset)
 {

@@ -121,7 +121,8 @@ struct hsk_ctx {
     Comm comm;
     const u8 *zc_src = nullptr;        // hsk_count() with pinned input: device view of the caller's packed reads (scan_kernel reads them in place)
     const u8 *h2d_src = nullptr;       // hsk_count() with pinned input, slab ingest: the caller's packed reads (host pointer); parse_count copies them slab by
-    int h2d_slabs = 0;                 // slab (DMA, d2h_stream) and hashes slab s while slab s + 2 is on the link
+    int h2d_slabs = 0;
+    u32 scan_blocks = 0;               // experiments (hsk_debug_parse_overlap): workgroups of the parse kernels instead of 1024                 // slab (DMA, d2h_stream) and hashes slab s while slab s + 2 is on the link
     // hsk_count() with derived read offsets: host threads compare the caller's offsets with the back-to-back layout while the GPU
     // scans (result collected with the task totals); roff_host / roff_given: the caller's array and a device buffer for it, used
     // only when the comparison fails (a buffer with gaps)

@@ -71,7 +71,7 @@ static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_byte
     a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
     a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks);
     a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
-    u32 nblocks = (u32)std::min<u64>(a.ntiles, 1024);
+    u32 nblocks = (u32)std::min<u64>(a.ntiles, c->scan_blocks ? c->scan_blocks : 1024);
     a.rid_base = rid_base;
     if (nslabs > 1 && a.ntiles >= (u64)nblocks * nslabs) {
         const u64 per_slab = (a.ntiles + nslabs - 1) / nslabs;
