@@ -87,7 +87,7 @@ extern "C" void hsk_config_default(hsk_config *cfg)
     memset(cfg, 0, sizeof *cfg);
     cfg->kmer_size = 31; cfg->minimizer_size = 17; cfg->lower_freq = 15; cfg->upper_freq = 40;   // reference Makefile:1-8
     cfg->extension = 0; cfg->ntasks = 0; cfg->device = 0; cfg->plain_dispatcher = 0;
-    cfg->dispatch_upper_coe = 1.5; cfg->dispatch_step = 0.05; cfg->radix_bits = 8; cfg->flags = 0;
+    cfg->dispatch_upper_coe = 1.5; cfg->dispatch_step = 0.05; cfg->radix_bits = 8; cfg->flags = 0; cfg->unbalanced_ratio = 2.3;
 }
 
 static int validate_cfg(const hsk_config *cfg)
@@ -133,6 +133,7 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
     if (c->cfg.radix_bits == 0) c->cfg.radix_bits = 8;
     if (c->cfg.dispatch_upper_coe <= 0) c->cfg.dispatch_upper_coe = 1.5;
     if (c->cfg.dispatch_step <= 0) c->cfg.dispatch_step = 0.05;
+    if (!(c->cfg.unbalanced_ratio > 0)) c->cfg.unbalanced_ratio = 2.3;
     c->nw = (cfg->kmer_size + 31) / 32;
     memset(&c->stats, 0, sizeof c->stats);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||

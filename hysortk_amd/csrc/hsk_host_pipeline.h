@@ -669,10 +669,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
 // PLAIN_CLASSIFIER (kmerops.cpp:109-113).
 static bool heavy_enabled(hsk_ctx *c, int /*nw*/, int nranks)
 {
-    static const bool env_on = !(getenv("HSK_HEAVY") && atoi(getenv("HSK_HEAVY")) == 0);
-    return env_on && nranks > 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0;
+    return nranks > 1 && c->cfg.extension == 0 && (c->cfg.flags & HSK_FLAG_PLAIN_CLASSIFIER) == 0;
 }
-static double heavy_ratio() { static const double r = getenv("HSK_UNBALANCED_RATIO") ? atof(getenv("HSK_UNBALANCED_RATIO")) : 2.3; return r; }
 
 // Every rank turns its OWN supermers of the heavy tasks into unfiltered {k-mer, count} lists (ScatteredKmerList,
 // kmerops.cpp:363-398): only the heavy tasks are placed, then the ordinary expand / sort / aggregate kernels run with
@@ -775,7 +773,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
                 if (!local_rc) for (u32 t = 0; t < ntasks; ++t) kg[t] = job.task_tot[3 * t + 2];
                 rc = together(cm.allreduce_with_status(kg, RCCL_SUM, local_rc != 0, c->stream, c->pool), "task k-mers");
                 if (rc) { parse_release(c, job); return rc; }
-                plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+                plan_classify(kg.data(), (int)ntasks, c->cfg.unbalanced_ratio, types.data());
                 for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
             }
             if (any_heavy) {
@@ -958,7 +956,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     if (heavy_enabled(c, NW, R)) {
         std::vector<u64> kg(ntasks, 0); std::vector<int32_t> types(ntasks, 0);
         for (int r = 0; r < R; ++r) for (u32 t = 0; t < ntasks; ++t) kg[t] += jobs[r].task_tot[3 * t + 2];
-        plan_classify(kg.data(), (int)ntasks, heavy_ratio(), types.data());
+        plan_classify(kg.data(), (int)ntasks, c->cfg.unbalanced_ratio, types.data());
         for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
     }
     if (any_heavy) {

@@ -53,7 +53,8 @@ typedef struct {
     double  dispatch_step;      /* DISPATCH_STEP      (0.05) */
     int32_t radix_bits;       /* digit width of the LSD radix sort: 8 (default) */
     int32_t flags;            /* HSK_FLAG_* */
-    int64_t reserved[4];
+    double  unbalanced_ratio; /* UNBALANCED_RATIO (2.3): a task is a heavy hitter above ratio x the mean task (kmerops.cpp:1190); ABI 3 */
+    int64_t reserved[3];
 } hsk_config;
 
 #define HSK_FLAG_PROFILE      1   /* HIP-event timing of every radix scatter launch (hsk_stats) */
