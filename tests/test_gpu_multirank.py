@@ -69,7 +69,7 @@ def test_loopback_vs_oracle_with_owner_table(variant, R):
                 assert sorted(zip(rid.tolist(), pos.tolist())) == sorted(zip(ores.rid[a:b].tolist(), ores.pos[a:b].tolist()))
 
 
-@pytest.mark.parametrize("variant,R,ntasks", [("k31", 2, 40), ("k31ext", 3, 60), ("k51", 2, 34)])
+@pytest.mark.parametrize("variant,R,ntasks", [("k31", 2, 40), ("k31ext", 3, 60), ("k51", 2, 34), ("k31", 8, 320)])     # (8, 320): the shape of the 8-GPU bench, 40 tasks = 5 groups per rank
 def test_loopback_grouped_exchange(variant, R, ntasks):
     """Several task groups per rank: the exchange of group g+1 overlaps the sort of group g (GroupFeeder);
     per-rank lists must still equal the oracle restricted to the rank's tasks."""
