@@ -227,8 +227,9 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
     """One short device-resident leg of another record shape / plan: k-mers/s, ms per step, the scatter passes' GB/s."""
     ctx = H.Context(K=KK, M=M, L=Lv, U=Uv, EXT=ext, device=local, profile=True, keep_device=True, plan=plan)
     dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed, error_rate=error_rate)
-    r = ctx.count_device(dp, nb, do, dl, nreads)          # warm-up: pools, the adaptive choices (first table, aggregation on / off)
-    del r
+    for _ in range(2):                                    # warm-up: the adaptive choices (first table, aggregation on / off) settle in the first call,
+        r = ctx.count_device(dp, nb, do, dl, nreads)      # the memory pools for the path they settled on in the second
+        del r
     ctx.stats(reset=True)
     t0 = time.perf_counter()
     info = None
