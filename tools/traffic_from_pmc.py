@@ -30,7 +30,7 @@ for k, d in res.items():
     # not part of the counting path: the synthetic-read generator, and bench.py's own device-to-device copies (the measured
     # copy peak: torch copies of 2 x 4 GiB run as __amd_rocclr_copyBuffer / at::native kernels; the path's own copyBuffer
     # traffic, a 0.5 GB read-index copy per step, is dropped with them)
-    if k.startswith("synth_") or "at::native" in k or k.startswith("__amd_rocclr_copyBuffer"):
+    if k.startswith("synth_") or "at::native" in k or k.startswith("__amd_rocclr_copyBuffer") or k.startswith("copy_peak_kernel"):
         continue
     path += d["launches"] * (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
 o["path_bytes_per_step"] = path
