@@ -403,7 +403,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     tmark(zc ? (derive ? "input enqueued (zero-copy packed, offsets derived from the lengths)" : "input enqueued (zero-copy packed)") : "input enqueued (copies)");
     if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
     tmark("pipeline returned");
-    c->zc_src = nullptr; c->h2d_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr;
+    c->zc_src = nullptr; c->h2d_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr; c->roff_bad = false;
     if (c->roff_check.valid()) (void)c->roff_check.get();          // (the pipeline failed before it collected the verdict)
     c->pool.release(d_given); c->pool.release(d_tsum);
     free_input(c, d);

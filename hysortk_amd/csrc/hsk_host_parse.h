@@ -194,7 +194,9 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
-        if (c->roff_check.valid() && !c->roff_check.get()) {
+        bool gaps = c->roff_bad; c->roff_bad = false;
+        if (c->roff_check.valid() && !c->roff_check.get()) gaps = true;
+        if (gaps) {
             // the buffer's reads do not lie back to back (the host threads found a gap while the GPU scanned): everything again
             // with the caller's offsets, copied now and validated on the device
             u64 *given = c->roff_given;
@@ -311,6 +313,137 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     // every later user of these blocks is enqueued on the same stream)
     c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order); c->pool.release(d_skip);
     a.task_skip = nullptr;
+    return HSK_OK;
+}
+
+// hsk_count() from pinned host memory on one GPU (no payload): ingest, scan and placement as ONE pipeline over slabs.
+//   copy stream   DMA copy of slab s + 2          (the link: ~55 GB/s, the floor of the whole parse)
+//   main stream   scan_kernel of slab s            (behind the copy of slab s + 1; the VALUs have ~0.8 ms to spare per slab)
+//   second stream task totals, slot bases and place_kernel of slab s - 1   (fills those gaps: the placement, 8.6 ms when it
+//                 runs after the last scan, is off the critical path)
+// The store is laid out [slab][task] (a slab's slot bases need only the slabs before it: parse_scan_kernel carries the
+// running totals on the device), so a task's supermers are one segment per slab (`segs`), which the extraction takes like the
+// segments of several source ranks.  Returns HSK_OK, an error, or PARSE_FALLBACK: nothing has been decided, the packed reads
+// are in HBM, the caller takes parse_count / parse_place (a tile beyond the record capacity, an index that needs the
+// caller's offsets, a device-side index check that failed).
+constexpr int PARSE_FALLBACK = -1000;
+static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
+                                  int64_t rid_base, u32 ntasks, SupermerStore &st, std::vector<TaskSegs> &segs)
+{
+    u32 nblocks = 0;
+    ParseArgs a = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &nblocks, (u32)c->h2d_slabs);
+    if (a.nslabs <= 1) return PARSE_FALLBACK;
+    const u32 nsl = a.nslabs;
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    a.rec_cap = parse_rec_cap(c->cfg.kmer_size - c->cfg.minimizer_size + 1);
+    a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
+    a.place_one = 1;
+    u64 *d_blk_cnt, *d_blk_base, *d_tot, *d_task_base, *d_run; u32 *d_order, *d_tile_rec, *d_tile_nrec, *d_overflow;
+    const size_t mat = (size_t)nblocks * ntasks;
+    DALLOC(c, d_blk_cnt, u64 *, mat * 3 * 8 * nsl);
+    DALLOC(c, d_blk_base, u64 *, mat * 2 * 8);
+    DALLOC(c, d_tot, u64 *, (size_t)nsl * ntasks * 3 * 8 + 64);
+    DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
+    DALLOC(c, d_run, u64 *, 256);
+    DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
+    DALLOC(c, d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+    DALLOC(c, d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+    DALLOC(c, d_overflow, u32 *, 256);
+    // the store holds at most rec_cap supermers per tile (a tile beyond that falls back); its real size is known when the last slab is in
+    const u64 cap_sup = a.ntiles * (u64)a.rec_cap;
+    st = SupermerStore();
+    st.ntasks = ntasks; st.nblocks = nblocks;
+    DALLOC(c, st.sm_len, u8 *, cap_sup + 64);
+    DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64);
+    auto release_all = [&]() {
+        c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_tot); c->pool.release(d_task_base); c->pool.release(d_run);
+        c->pool.release(d_order); c->pool.release(d_tile_rec); c->pool.release(d_tile_nrec); c->pool.release(d_overflow);
+    };
+    std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    st.order = order;
+    u32 *h_order = (u32 *)((char *)c->pinned + (128u << 10));              // (pinned staging: the copy is asynchronous)
+    memcpy(h_order, order.data(), (size_t)ntasks * 4);
+    hipStream_t sA = c->stream, sB = c->comm_stream, sC = c->d2h_stream;
+    HIPCHK(c, hipMemsetAsync(d_overflow, 0, 4, sA));
+    HIPCHK(c, hipMemsetAsync(d_run, 0, 24, sA));
+    HIPCHK(c, hipMemcpyAsync(d_order, h_order, (size_t)ntasks * 4, hipMemcpyHostToDevice, sA));
+    a.tile_rec = d_tile_rec; a.tile_nrec = d_tile_nrec; a.overflow = d_overflow;
+    a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.blk_base = d_blk_base; a.task_base3 = d_task_base;
+    hipEvent_t ready = ev_get(c);                                          // the small buffers above are set up; the second stream may start
+    HIPCHK(c, hipEventRecord(ready, sA));
+    HIPCHK(c, hipStreamWaitEvent(sB, ready, 0));
+    ev_put(c, ready);
+    std::vector<hipEvent_t> landed(nsl), scanned(nsl);
+    EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, sC); }
+    for (u32 sl = 0; sl < nsl; ++sl) {
+        const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
+        if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, sC));
+        landed[sl] = ev_get(c);
+        HIPCHK(c, hipEventRecord(landed[sl], sC));
+    }
+    if (profile) { (void)hipEventRecord(hp.b, sC); c->ev_pending.push_back(hp); }
+    EvPair sp{}, pp{};
+    if (profile) { sp.a = ev_get(c); sp.b = ev_get(c); sp.kind = 3; sp.bytes = packed_bytes; (void)hipEventRecord(sp.a, sA);
+                   pp.a = ev_get(c); pp.b = ev_get(c); pp.kind = 4; (void)hipEventRecord(pp.a, sB); }
+    static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;
+    for (u32 sl = 0; sl < nsl; ++sl) {
+        HIPCHK(c, hipStreamWaitEvent(sA, landed[std::min(sl + 1, nsl - 1)], 0));
+        a.slab = sl; a.blk_cnt = d_blk_cnt + (size_t)sl * mat * 3;
+        if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        scanned[sl] = ev_get(c);
+        HIPCHK(c, hipEventRecord(scanned[sl], sA));
+        // the slab's placement on the second stream: totals, bases (behind everything the slabs before laid out), supermers to their slots
+        HIPCHK(c, hipStreamWaitEvent(sB, scanned[sl], 0));
+        hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, sB, (const u64 *)a.blk_cnt, nblocks, ntasks, (const u32 *)d_order, (const u8 *)nullptr,
+                           d_tot + (size_t)sl * ntasks * 3, d_task_base, d_blk_base, d_run);
+        hipLaunchKernelGGL(place_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, sB, a);
+    }
+    if (profile) { (void)hipEventRecord(sp.b, sA); c->ev_pending.push_back(sp); (void)hipEventRecord(pp.b, sB); }
+    // the verdicts and the totals
+    u32 *h_flags = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
+    std::vector<u64> tot((size_t)nsl * ntasks * 3);
+    u64 *h_tot = (u64 *)((char *)c->pinned + (192u << 10));
+    const bool staged = (size_t)nsl * ntasks * 24 <= (64u << 10);
+    HIPCHK(c, hipMemcpyAsync(h_flags, d_overflow, 4, hipMemcpyDeviceToHost, sB));
+    HIPCHK(c, hipMemcpyAsync(h_flags + 1, c->d_err, 4, hipMemcpyDeviceToHost, sB));
+    HIPCHK(c, hipMemcpyAsync(staged ? h_tot : tot.data(), d_tot, (size_t)nsl * ntasks * 24, hipMemcpyDeviceToHost, sB));
+    hipEvent_t placed = ev_get(c);
+    HIPCHK(c, hipEventRecord(placed, sB));
+    HIPCHK(c, hipStreamWaitEvent(sA, placed, 0));                          // the extraction (main stream) reads the store
+    HIPCHK(c, hsk_sync(c, sB));
+    ev_put(c, placed);
+    for (auto e : landed) ev_put(c, e);
+    for (auto e : scanned) ev_put(c, e);
+    if (profile) { pp.keys = 0; c->ev_pending.push_back(pp); }
+    if (staged) memcpy(tot.data(), h_tot, (size_t)nsl * ntasks * 24);
+    bool fallback = *h_flags != 0;                                          // a tile with more supermers than the record capacity
+    if (c->roff_check.valid() && !c->roff_check.get()) { fallback = true; c->roff_bad = true; }     // the reads do not lie back to back: the caller's offsets are needed
+    if (c->index_unchecked && (h_flags[1] & 32u)) fallback = true;          // (parse_count reports it)
+    if (fallback) { HIPCHK(c, hsk_sync(c, sA)); release_all(); free_store(c, st); return PARSE_FALLBACK; }
+    c->index_unchecked = false;
+    // segments: slab by slab, tasks in storage order inside a slab (what parse_scan_kernel laid out on the device)
+    st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0);
+    segs.assign(ntasks, TaskSegs());
+    u64 run_s = 0, run_b = 0;
+    for (u32 sl = 0; sl < nsl; ++sl)
+        for (u32 i = 0; i < ntasks; ++i) {
+            const u32 t = order[i];
+            const u64 *m = &tot[((size_t)sl * ntasks + t) * 3];
+            if (m[0]) {
+                ExpSeg sg; sg.sup_off = run_s; sg.n_sup = m[0]; sg.byte_off = run_b; sg.kmer_off = segs[t].nkmers; sg.tile_start = 0;
+                segs[t].segs.push_back(sg);
+            }
+            segs[t].nkmers += m[2];
+            st.task_tot[3 * t] += m[0]; st.task_tot[3 * t + 1] += m[1]; st.task_tot[3 * t + 2] += m[2];
+            run_s += m[0]; run_b += m[1];
+        }
+    st.tot_sup = run_s; st.tot_bytes = run_b; st.tot_kmers = 0;
+    for (u32 t = 0; t < ntasks; ++t) st.tot_kmers += st.task_tot[3 * t + 2];
+    if (run_s > cap_sup) { release_all(); free_store(c, st); return fail(c, HSK_ERR_INTERNAL, "supermer store overrun (%llu > %llu)", (unsigned long long)run_s, (unsigned long long)cap_sup); }
+    if (profile && !c->ev_pending.empty()) c->ev_pending.back().keys = run_s;
+    release_all();                                                          // (stream-ordered reuse: later users are enqueued behind the kernels above)
     return HSK_OK;
 }
 

@@ -747,8 +747,19 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     std::vector<HeavyIn> hin;                            // heavy tasks this rank owns: the lists of all ranks
     bool any_heavy = false;
     int place_rc = HSK_OK;
+    std::vector<TaskSegs> segs(ntasks);
+    bool pipelined = false;
     pt.begin(PH_PARSE);
-    {
+    // one GPU, reads arriving from pinned host memory, no payload: ingest, scan and placement as one pipeline over slabs
+    static const bool pipe_enabled = !(getenv("HSK_INGEST_PIPELINE") && atoi(getenv("HSK_INGEST_PIPELINE")) == 0);
+    if (nranks == 1 && !ext && c->h2d_src && pipe_enabled && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M) {
+        const u8 *src = c->h2d_src; c->h2d_src = nullptr;
+        const int prc = parse_ingest_pipelined(c, src, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, st, segs);
+        if (prc == HSK_OK) pipelined = true;
+        else if (prc != PARSE_FALLBACK) return prc;
+        else c->stats.parse_fallbacks++;                        // (the packed reads are in HBM now: the two-step parse below takes it from there)
+    }
+    if (!pipelined) {
         // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
         // before the storage order (tasks grouped by owner rank) is known, then parse_place lays the supermers out
         ParseJob job;
@@ -808,7 +819,6 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
 
     // ---- exchange (multi-GPU) ---------------------------------------------------------------------
     // After this block `segs[t]` lists where the supermers of owned task t live.
-    std::vector<TaskSegs> segs(ntasks);
     const u8 *x_len = st.sm_len; const u32 *x_pos = st.sm_pos; const int32_t *x_rid = st.sm_rid;
     BaseSource x_src = source_from_store(st, d_packed, packed_bytes);
     ExchangeBuffers xb;
@@ -836,7 +846,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             x_src = source_from_bytes(xb.bytes, xb.nbytes);
             free_store(c, st);
         }
-    } else {
+    } else if (!pipelined) {
         for (u32 t = 0; t < ntasks; ++t) {
             if (st.task_tot[3 * t] == 0) continue;
             ExpSeg s; s.sup_off = st.task_base[3 * t]; s.n_sup = st.task_tot[3 * t]; s.byte_off = st.task_base[3 * t + 1]; s.kmer_off = 0; s.tile_start = 0;

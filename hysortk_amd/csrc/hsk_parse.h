@@ -56,6 +56,7 @@ struct ParseArgs {
     // (slab > 0); the placement kernels walk all slabs of the workgroup in the same order.
     u32 nslabs, slab;
     u64 slab_tiles;
+    u32 place_one;             // placement kernels: only slab `slab` (its own blk_base: the slabs are placed one by one while the next ones are hashed)
     int64_t rid_base;
     // COUNT: blk_cnt[block][task][3] = {supermers, bytes, kmers}
     u64 *blk_cnt;
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
         u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
         const u64 pk = s_cur[2 * t];
-        if (a.slab == 0) { o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1); }
+        if (a.slab == 0 || a.place_one) { o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1); }      // (place_one: every slab has its own matrix)
         else { o[0] += pk >> 40; o[1] += s_cur[2 * t + 1]; o[2] += pk & ((1ULL << 40) - 1); }      // (same workgroup, launches in stream order)
     }
 }
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] = a.blk_base[((u64)blockIdx.x * a.ntasks + t) * 2];
     const u32 G = a.place_group;
     const u32 nsl = a.nslabs > 1 ? a.nslabs : 1;
-    for (u32 sl = 0; sl < nsl; ++sl) {
+    for (u32 sl = a.place_one ? a.slab : 0; sl < (a.place_one ? a.slab + 1 : nsl); ++sl) {
     const u64 tile0 = (u64)sl * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
     const u64 tile_end = (nsl > 1 && ((u64)sl + 1) * a.slab_tiles < a.ntiles) ? ((u64)sl + 1) * a.slab_tiles : a.ntiles;
     for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
@@ -1067,8 +1068,10 @@ __global__ void task_totals_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, 
 // Exclusive scan of the COUNT matrix: per task totals, task bases (tasks laid out in `order`),
 // and per (block, task) cursors for EMIT.  One thread per task; the matrix is tiny.
 //   task_tot[t][3], task_base[t][3] (supermer slot, byte, kmer), blk_base[b][t][2]
+// run (optional, [3]): the slot / byte / k-mer totals of everything laid out before this call (slabs placed one by one): the bases
+// start there and the totals of this call are added to it.
 __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, const u32 *order, const u8 *skip,
-                                  u64 *task_tot, u64 *task_base, u64 *blk_base)
+                                  u64 *task_tot, u64 *task_base, u64 *blk_base, u64 *run = nullptr)
 {
     __shared__ u64 s_tot[HSK_MAX_TASKS * 3];
     const u32 t = threadIdx.x;
@@ -1081,12 +1084,13 @@ __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, c
     }
     __syncthreads();
     if (t == 0) {
-        u64 s = 0, b = 0, k = 0;
+        u64 s = run ? run[0] : 0, b = run ? run[1] : 0, k = run ? run[2] : 0;
         for (u32 i = 0; i < ntasks; ++i) {
             const u32 task = order[i];
             task_base[3 * task] = s; task_base[3 * task + 1] = b; task_base[3 * task + 2] = k;
             s += s_tot[3 * task]; b += s_tot[3 * task + 1]; k += s_tot[3 * task + 2];
         }
+        if (run) { run[0] = s; run[1] = b; run[2] = k; }
     }
     __syncthreads();
     if (t < ntasks) {
