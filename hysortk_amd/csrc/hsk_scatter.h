@@ -176,6 +176,9 @@ __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
     // lengths and positions of the tile's supermers (byte streams: the tile's input offset instead of the positions)
 #pragma unroll
     for (int x = 0; x < NW + 2; ++x) p_raw[x] = 0;
+    // a workgroup's tiles come in ascending order: the segment of a tile is found by moving a cursor forward (two cursors: the tile
+    // being worked on and the one whose inputs are prefetched), not by searching the table from the start for every tile
+    int sg_meta = 0, sg_tile = 0;
     auto prefetch_meta = [&](u64 tl) {
         p_have = segs_lds && tl < t.ntiles; p_len = 0; p_gpos = 0; p_vb = 0;
         if (p_have) {
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
                     if (EXT) p_vb = (u64)t.sm_pos[s0_sup + sidx] | ((u64)(u32)t.sm_rid[s0_sup + sidx] << 32);
                 }
             } else {
-                int sg = 0;
-                while (sg + 1 < nseg && s_seg[2][sg + 1] <= tl) ++sg;
+                while (sg_meta + 1 < nseg && s_seg[2][sg_meta + 1] <= tl) ++sg_meta;
+                const int sg = sg_meta;
                 const u64 sidx = (tl - s_seg[2][sg]) * XS_TL + tid;
                 if (sidx < s_seg[1][sg]) {
                     p_len = t.sm_len[s_seg[0][sg] + sidx]; if (inplace) p_gpos = sup_pos(s_seg[0][sg] + sidx, s_seg[3][sg]);
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
         u64 sg_sup = s0_sup, sg_n = s0_n, sg_t0 = 0, sg_byte = s0_byte;
         if (single) { }
         else if (segs_lds) {
-            int sg = 0;
-            while (sg + 1 < nseg && s_seg[2][sg + 1] <= tile) ++sg;
+            while (sg_tile + 1 < nseg && s_seg[2][sg_tile + 1] <= tile) ++sg_tile;
+            const int sg = sg_tile;
             sg_sup = s_seg[0][sg]; sg_n = s_seg[1][sg]; sg_t0 = s_seg[2][sg]; sg_byte = s_seg[3][sg];
         } else { const ExpSeg *sp = t.segs + seg_of_tile(t.segs, nseg, tile); sg_sup = sp->sup_off; sg_n = sp->n_sup; sg_t0 = sp->tile_start; sg_byte = sp->byte_off; }
         const u64 first = (tile - sg_t0) * XS_TL;
