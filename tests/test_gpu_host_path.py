@@ -124,9 +124,12 @@ def test_slab_ingest_equals_reads_in_place():
             "    r = c.count(src)\n"
             "    print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
     outs = []
-    for env in ({}, {"HSK_H2D_SLABS": "3"}, {"HSK_H2D_SLABS": "0"}, {"HSK_H2D_SLABS": "8", "HSK_PARSE_REC_CAP": "300"}):
+    # ({}: ingest, scan and placement as one pipeline, the store laid out [slab][task]; HSK_INGEST_PIPELINE=0: slab ingest, one placement;
+    #  a record capacity of 300 makes some tile overflow: both fall back to the general parse kernels with the reads already in HBM)
+    for env in ({}, {"HSK_H2D_SLABS": "3"}, {"HSK_H2D_SLABS": "0"}, {"HSK_H2D_SLABS": "8", "HSK_PARSE_REC_CAP": "300"}, {"HSK_INGEST_PIPELINE": "0"},
+                {"HSK_INGEST_PIPELINE": "0", "HSK_PARSE_REC_CAP": "300"}):
         outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
-    assert len(outs) == 12 and len({o[0] for o in outs}) == 1, outs
+    assert len(outs) == 18 and len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
 
 
