@@ -62,8 +62,24 @@ inline hsk_ctx *context(MPI_Comm comm)
     hsk_config_default(&cfg);
     cfg.kmer_size = KMER_SIZE; cfg.minimizer_size = MINIMIZER_SIZE;
     cfg.lower_freq = LOWER_KMER_FREQ; cfg.upper_freq = UPPER_KMER_FREQ; cfg.extension = EXTENSION;
+    // the reference's other -D macros (Makefile:1-46), where a client's build line carries them
 #ifdef PLAIN_DISPATCHER
     cfg.plain_dispatcher = PLAIN_DISPATCHER;
+#endif
+#ifdef DISPATCH_UPPER_COE
+    cfg.dispatch_upper_coe = DISPATCH_UPPER_COE;
+#endif
+#ifdef DISPATCH_STEP
+    cfg.dispatch_step = DISPATCH_STEP;
+#endif
+#ifdef UNBALANCED_RATIO
+    cfg.unbalanced_ratio = UNBALANCED_RATIO;
+#endif
+#if defined(PLAIN_CLASSIFIER) && PLAIN_CLASSIFIER
+    cfg.flags |= HSK_FLAG_PLAIN_CLASSIFIER;
+#endif
+#if defined(SORT) && SORT == 3                                   // (not a reference value: 1 = PARADIS, 2 = RADULS there) the reference's own algorithm
+    cfg.flags |= HSK_FLAG_FULL_SORT;                             // on the GPU: LSD over all key bytes + merge-count, see include/hsk.h
 #endif
     int ndev = hsk_device_count();                               // GPUs this process can see (0: hsk_init reports HSK_ERR_NO_DEVICE)
     if (const char *e = std::getenv("HSK_GPUS_PER_NODE")) ndev = std::max(1, atoi(e));
