@@ -83,7 +83,24 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     static const int xs_tpb = getenv("HSK_XS_TPB") ? atoi(getenv("HSK_XS_TPB")) : XS_THREADS;
     bool small_wg = xs_tpb == 256 && NW == 1 && !ext;
     for (int i = 0; i < XCD_BATCH && small_wg; ++i) if (xi[i] >= 0 && !(jobs[i].ts->segs.size() == 1 && jobs[i].src.gpos != nullptr)) small_wg = false;
+    // HSK_XS2=1 (experiment, see expand_scatter2_kernel): two sweeps per flush, three workgroups per CU -- one-word keys without
+    // payload, bases read in place, at most XS_MAXSEG segments per task
+    static const bool xs2_env = getenv("HSK_XS2") && atoi(getenv("HSK_XS2")) != 0;
+    bool xs2 = xs2_env && NW == 1 && !ext;
+    for (int i = 0; i < XCD_BATCH && xs2; ++i) if (xi[i] >= 0 && !(jobs[i].src.gpos != nullptr && jobs[i].src.boff == nullptr && jobs[i].ts->segs.size() <= (size_t)XS_MAXSEG)) xs2 = false;
     if constexpr (NW == 1) {
+        if (xs2) {
+            static int occ2 = 0;
+            if (!occ2) { int nb = 0; occ2 = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter2_kernel<31>, XS_THREADS, 0) == hipSuccess && nb > 0) ? nb : 2; }
+            EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
+            const u32 grid = (u32)occ2 * 256u;
+            if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56) hipLaunchKernelGGL((expand_scatter2_kernel<31>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((expand_scatter2_kernel<0>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
+            if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
+            HIPCHK(c, hipGetLastError());
+            sb.active = true;
+            return HSK_OK;
+        }
         if (small_wg) {
             for (int i = 0; i < XCD_BATCH; ++i) if (xi[i] >= 0) a.t[i].ntiles = (jobs[i].ts->segs[0].n_sup + 255) / 256;
             static int occ256 = 0;

@@ -432,6 +432,216 @@ __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Two-sweep variant (one-word keys, no payload, bases read in place; HSK_XS2, hsk_host_scatter.h).  expand_scatter_kernel keeps the
+// 16 keys of a lane's item and their 16 ranks in registers from the roll to the permute: 48 of its 119 VGPRs, four waves per SIMD,
+// two workgroups per CU -- and no unit of the CU more than 55 % busy (VALU 54 %, LDS 34 %: the chain of phases waits for itself).
+// Here a flush rolls its k-mers TWICE: the first sweep only counts digits, the second -- after the digit scan, with the counts
+// turned into running cursors -- rolls them again and drops every key straight into its slot of the stage.  Nothing survives
+// between the sweeps but the item's two window words; the permute phase and its table are gone.  About 12 more VALU instructions
+// per k-mer for 40 fewer registers and 10 KB less LDS: a third workgroup per CU.
+// A flush with more keys than the stage holds (long supermers) is redone as two flushes over the two halves of the items.
+template <class F>
+__device__ __forceinline__ void xs2_roll(u64 win0, u64 win1, u32 cnt, int k, int low, u64 lastmask, F &&emit)
+{
+    Mer<1> fw, rc;
+    fw.w[0] = win0 & lastmask;
+    rc = twin<1>(fw, k);
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        if (r > 0) {
+            fw.w[0] = funnel_left(win0, win1, 2 * r) & lastmask;
+            const u64 nbase = (fw.w[0] >> low) & 3;
+            rc.w[0] = ((rc.w[0] >> 2) | ((3 - nbase) << 62)) & lastmask;
+        }
+        if ((u32)r < cnt) emit(rc.w[0] < fw.w[0] ? rc.w[0] : fw.w[0]);
+    }
+}
+
+template <int KT = 0>
+__global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterArgs a)
+{
+    constexpr int XS_RUN = 16, XS_CHUNK = XsCfg<1>::CHUNK, XS_STG = XS_CHUNK;
+    __shared__ u16 s_ioff[XS_TILE + 1];                                 // first item of every supermer (tiles with supermers of more than 16 k-mers only)
+    __shared__ u8 s_nk[XS_TILE];
+    __shared__ u64 s_gpos[XS_TILE];
+    __shared__ u64 s_stage[XS_STG];
+    __shared__ u32 s_cnt[256], s_hist[256];
+    __shared__ uint4 s_dl[256];
+    __shared__ u32 s_scr[XS_WAVES];
+    __shared__ u32 s_blk[2];
+    __shared__ u32 s_multi;
+    __shared__ u64 s_seg[3][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile} of the task's segments
+    typedef __attribute__((address_space(1))) u32 G32;
+    const int tid = threadIdx.x;
+    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
+    const ScatterTask &t = a.t[xcc];
+    if (t.ntiles == 0) return;
+    const int k = KT ? KT : a.k;
+    const int low = 64 - 2 * k;
+    const u64 lastmask = ~0ULL << low;
+    const u32 sh0 = KT ? 16u : (u32)a.shift0 - 32u, sh1 = KT ? 24u : (u32)a.shift1 - 32u;
+    const int nseg = t.nseg;
+    const bool single = nseg == 1;
+    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup;
+    if (!single && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
+    if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
+    if (tid == 0) {
+        s_multi = 0;
+        s_blk[0] = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s_blk[1] = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    xs_barrier();
+    u64 blk = s_blk[0], nblk = s_blk[1];
+    u32 p_len = 0; u64 p_gpos = 0, p_r0 = 0, p_r1 = 0, p_r2 = 0; bool p_have = false;
+    int sg_meta = 0, sg_tile = 0;
+    auto prefetch_meta = [&](u64 tl) {
+        p_have = tl < t.ntiles; p_len = 0; p_gpos = 0;
+        if (p_have) {
+            u64 base = s0_sup, n = s0_n, t0 = 0;
+            if (!single) {
+                while (sg_meta + 1 < nseg && s_seg[2][sg_meta + 1] <= tl) ++sg_meta;
+                base = s_seg[0][sg_meta]; n = s_seg[1][sg_meta]; t0 = s_seg[2][sg_meta];
+            }
+            const u64 sidx = (tl - t0) * XS_TILE + tid;
+            if (sidx < n) { p_len = t.sm_len[base + sidx]; p_gpos = t.sm_gpos[base + sidx]; }
+        }
+    };
+    auto load_win = [&](u64 gpos, u64 &r0, u64 &r1, u64 &r2) {
+        const u64 wi = (t.src_bit0 + 2 * gpos) >> 6;
+        r0 = (wi < t.src_words) ? t.src8[wi] : 0; r1 = (wi + 1 < t.src_words) ? t.src8[wi + 1] : 0; r2 = (wi + 2 < t.src_words) ? t.src8[wi + 2] : 0;
+    };
+    prefetch_meta(blk);
+    if (p_have) load_win(p_gpos, p_r0, p_r1, p_r2);
+    xs_barrier();
+
+    for (u32 j = 0;;) {
+        const u64 tile = blk + j;
+        if (tile >= t.ntiles) break;
+        const u64 ntile = (j + 1 == (u32)XS_CLAIM) ? nblk : tile + 1;
+        u32 claim = 0;
+        if (j == 0 && tid == 0) claim = __hip_atomic_fetch_add(&t.ctl[0], (u32)XS_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        u64 sg_n = s0_n, sg_t0 = 0;
+        if (!single) { while (sg_tile + 1 < nseg && s_seg[2][sg_tile + 1] <= tile) ++sg_tile; sg_n = s_seg[1][sg_tile]; sg_t0 = s_seg[2][sg_tile]; }
+        const u64 first = (tile - sg_t0) * XS_TILE;
+        const u32 ns = (u32)((sg_n - first) < (u64)XS_TILE ? (sg_n - first) : (u64)XS_TILE);
+
+        // ---- prologue: thread s owns supermer s of the tile (its length, position and first window were asked for a tile ago) ----
+        const u32 len = p_len; const u64 gp = p_gpos;
+        u64 raw0 = p_r0, raw1 = p_r1, raw2 = p_r2;
+        u32 nk = ((u32)tid < ns) ? (len - k + 1) : 0;
+        if (nk > 128u) { atomicOr(a.err, 4u); nk = 0; }
+        const u32 ni = (nk + XS_RUN - 1) / XS_RUN;
+        if (__ballot(ni > 1) != 0 && lane_id() == 0) s_multi = 1;       // a supermer of more than 16 k-mers: items and supermers part ways
+        prefetch_meta(ntile);
+        xs_barrier();
+        const bool multi = s_multi != 0;
+        u32 toti = ns, ei = (u32)tid;
+        if (multi) {                                                   // (rare: repeats, homopolymers)
+            ei = block_excl_scan_xs<XS_WAVES>(ni, s_scr, &toti);
+            s_ioff[tid] = (u16)ei; s_nk[tid] = (u8)nk; s_gpos[tid] = gp;
+            if (tid == XS_THREADS - 1) s_ioff[XS_TILE] = (u16)(ei + ni);
+            if (tid == 0) s_multi = 0;
+            xs_barrier();
+        }
+        bool win_sent = false;
+        for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
+            // ---- this lane's item: up to 16 k-mers of one supermer ----
+            u32 cnt = 0; u64 ipos = gp;
+            if (!multi) cnt = nk < (u32)XS_RUN ? nk : (u32)XS_RUN;       // item = supermer, window already here
+            else {
+                const u32 item = it0 + (u32)tid;
+                if (item < toti) {
+                    u32 lo = 0, hi = XS_TILE;                          // last supermer whose first item is <= item
+                    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u32)s_ioff[mid] <= item) lo = mid; else hi = mid; }
+                    // (a supermer without k-mers shares its offset with its successor and is never the last one at or below `item`)
+                    const u32 i0 = (item - (u32)s_ioff[lo]) * XS_RUN, nks = s_nk[lo];
+                    cnt = nks > i0 ? (nks - i0 < (u32)XS_RUN ? nks - i0 : (u32)XS_RUN) : 0;
+                    ipos = s_gpos[lo] + i0;
+                    load_win(ipos, raw0, raw1, raw2);
+                }
+            }
+            const u32 n_sh = (u32)((t.src_bit0 + 2 * ipos) & 63);
+            u64 win0, win1;
+            {
+                const u64 a0 = __builtin_bswap64(raw0), a1 = __builtin_bswap64(raw1), a2 = __builtin_bswap64(raw2);
+                win0 = n_sh ? ((a0 << n_sh) | (a1 >> (64 - n_sh))) : a0;
+                win1 = n_sh ? ((a1 << n_sh) | (a2 >> (64 - n_sh))) : a1;
+            }
+            int npass = 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                const u32 mycnt = (npass == 1 || (u32)(tid >> 8) == (u32)pass) ? cnt : 0u;
+                // ---- sweep 1: digit counts ----
+                xs2_roll(win0, win1, mycnt, k, low, lastmask, [&](u64 key) { atomicAdd(&s_cnt[((u32)(key >> 32) >> sh0) & 255u], 1u); });
+                if (!win_sent) { if (p_have) load_win(p_gpos, p_r0, p_r1, p_r2); win_sent = true; }     // the next tile's positions have arrived by now
+                xs_barrier();
+                const u32 c = tid < 256 ? s_cnt[tid] : 0;
+                u32 tot;
+                const u32 st = block_excl_scan_xs<XS_WAVES>(c, s_scr, &tot);
+                if (npass == 1 && tot > (u32)XS_STG) {                 // more keys than the stage holds: the two halves of the items one after the other
+                    if (tid < 256) s_cnt[tid] = 0;
+                    xs_barrier();
+                    npass = 2; pass = -1;
+                    continue;
+                }
+                u64 p = 0;
+                if (tid < 256) {
+                    s_cnt[tid] = st;                                   // from a count to the running cursor of the digit's range in the stage
+                    if (c) p = __hip_atomic_fetch_add(&t.cursor[tid], (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                xs_barrier();
+                // ---- sweep 2: the k-mers again, each straight into its slot ----
+                xs2_roll(win0, win1, mycnt, k, low, lastmask, [&](u64 key) {
+                    const u32 hi = (u32)(key >> 32);
+                    const u32 pos = atomicAdd(&s_cnt[(hi >> sh0) & 255u], 1u);
+                    s_stage[pos] = key;
+                    atomicAdd(&s_hist[(hi >> sh1) & 255u], 1u);
+                });
+                if (tid < 256 && c) {
+                    const u64 v0 = p / XS_CHUNK;
+                    const u32 off0 = (u32)(p % XS_CHUNK);
+                    const u32 nv = (off0 + c - 1) / XS_CHUNK + 1;
+                    G32 *mp = (G32 *)(t.map + (u64)tid * t.vmax);
+                    u32 ph[XS_SPAN] = {0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < XS_SPAN; ++q) {
+                        if ((u32)q >= nv || (q == 0 && off0 != 0)) continue;
+                        ph[q] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                        __hip_atomic_store(mp + v0 + q, ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (off0 != 0) {
+                        u32 spins = 0;
+                        while ((ph[0] = __hip_atomic_load(mp + v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                            if (++spins > XS_SPIN_LIMIT) { atomicOr(a.err, 2u); ph[0] = 1; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    const u32 split = st + ((u32)XS_CHUNK - off0);
+                    s_dl[tid] = make_uint4(split, (ph[0] - 1) * (u32)XS_CHUNK + off0 - st, ((ph[1] ? ph[1] : 1u) - 1) * (u32)XS_CHUNK - split,
+                                           ((ph[2] ? ph[2] : 1u) - 1) * (u32)XS_CHUNK - (split + (u32)XS_CHUNK));
+                }
+                xs_barrier();                                          // stage and digit table complete
+                for (u32 i = tid; i < tot; i += XS_THREADS) {
+                    const u64 kw = s_stage[i];
+                    const u32 d = ((u32)(kw >> 32) >> sh0) & 255u;
+                    const uint4 dl = s_dl[d];
+                    const u32 o = i + (i < dl.x ? dl.y : (i < dl.x + (u32)XS_CHUNK ? dl.z : dl.w));   // (mod 2^32)
+                    t.chunks[o] = kw;
+                }
+                if (tid < 256) s_cnt[tid] = 0;
+                xs_barrier();                                          // the stage is rewritten by the next flush
+            }
+        }
+        if (!win_sent && p_have) load_win(p_gpos, p_r0, p_r1, p_r2);
+        if (j == 0 && tid == 0) s_blk[1] = claim;
+        if (++j == (u32)XS_CLAIM) { xs_barrier(); blk = nblk; nblk = s_blk[1]; j = 0; xs_barrier(); }
+    }
+    if (tid < 256) {
+        const u32 cv = s_hist[tid];
+        if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
+    }
+}
+
 // tile_src[i] = (physical chunk << 32) | keys, chunks in (digit, virtual chunk) order; one workgroup per task.  The kernel
 // also prepares everything else the second pass needs, so that the host does not have to read anything back between the
 // two passes: the digit bases of the second pass (exclusive scan of the histogram the expand counted), the tile count, and
