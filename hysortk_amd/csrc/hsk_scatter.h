@@ -433,7 +433,8 @@ __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Two-sweep variant (one-word keys, no payload, bases read in place; HSK_XS2, hsk_host_scatter.h).  expand_scatter_kernel keeps the
+// Two-sweep variant (one-word keys, no payload, bases read in place -- positions in the packed reads on one GPU, offsets into the
+// received byte streams on several; HSK_XS2=0 takes expand_scatter_kernel instead, hsk_host_scatter.h).  expand_scatter_kernel keeps the
 // 16 keys of a lane's item and their 16 ranks in registers from the roll to the permute: 48 of its 119 VGPRs, four waves per SIMD,
 // two workgroups per CU -- and no unit of the CU more than 55 % busy (VALU 54 %, LDS 34 %: the chain of phases waits for itself).
 // Here a flush rolls its k-mers TWICE: the first sweep only counts digits, the second -- after the digit scan, with the counts
@@ -447,7 +448,10 @@ __device__ __forceinline__ void xs2_roll(u64 win0, u64 win1, u32 cnt, int k, int
     Mer<1> fw, rc;
     fw.w[0] = win0 & lastmask;
     rc = twin<1>(fw, k);
-#pragma unroll 4
+#ifndef XS2_UNROLL
+#define XS2_UNROLL 4
+#endif
+#pragma unroll XS2_UNROLL
     for (int r = 0; r < 16; ++r) {
         if (r > 0) {
             fw.w[0] = funnel_left(win0, win1, 2 * r) & lastmask;
@@ -458,20 +462,26 @@ __device__ __forceinline__ void xs2_roll(u64 win0, u64 win1, u32 cnt, int k, int
     }
 }
 
+#ifndef XS2_WAVES
+#define XS2_WAVES 6                                                      // waves per SIMD the kernel is built for: 6 = three workgroups per CU
+#endif
 template <int KT = 0>
-__global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterArgs a)
+__global__ __launch_bounds__(XS_THREADS, XS2_WAVES) void expand_scatter2_kernel(ScatterArgs a)
 {
     constexpr int XS_RUN = 16, XS_CHUNK = XsCfg<1>::CHUNK, XS_STG = XS_CHUNK;
-    __shared__ u16 s_ioff[XS_TILE + 1];                                 // first item of every supermer (tiles with supermers of more than 16 k-mers only)
-    __shared__ u8 s_nk[XS_TILE];
-    __shared__ u64 s_gpos[XS_TILE];
     __shared__ u64 s_stage[XS_STG];
+    // tiles with supermers of more than 16 k-mers (rare) look their items up in tables that live in the stage between two flushes:
+    // first item, k-mers and position of every supermer
+    u16 *const s_ioff = reinterpret_cast<u16 *>(s_stage);               // [XS_TILE + 1]: bytes 0 .. 1026
+    u8 *const s_nk = reinterpret_cast<u8 *>(s_stage) + 1536;            // [XS_TILE]:     bytes 1536 .. 2048
+    u64 *const s_gpos = s_stage + 256;                                  // [XS_TILE]:     bytes 2048 .. 6144
+    static_assert(XS_STG * 8 >= 2048 + XS_TILE * 8, "the item tables fit the stage");
     __shared__ u32 s_cnt[256], s_hist[256];
     __shared__ uint4 s_dl[256];
     __shared__ u32 s_scr[XS_WAVES];
     __shared__ u32 s_blk[2];
     __shared__ u32 s_multi;
-    __shared__ u64 s_seg[3][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile} of the task's segments
+    __shared__ u64 s_seg[4][XS_MAXSEG];                                 // {first supermer slot, supermers, first tile, first byte} of the task's segments
     typedef __attribute__((address_space(1))) u32 G32;
     const int tid = threadIdx.x;
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
@@ -483,8 +493,9 @@ __global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterA
     const u32 sh0 = KT ? 16u : (u32)a.shift0 - 32u, sh1 = KT ? 24u : (u32)a.shift1 - 32u;
     const int nseg = t.nseg;
     const bool single = nseg == 1;
-    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup;
-    if (!single && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; }
+    const bool byboff = t.sm_boff != nullptr;              // byte-store mode: supermer s starts at byte seg.byte_off + sm_boff[s] of the stream
+    const u64 s0_sup = t.segs[0].sup_off, s0_n = t.segs[0].n_sup, s0_byte = t.segs[0].byte_off;
+    if (!single && tid < nseg) { const ExpSeg sg = t.segs[tid]; s_seg[0][tid] = sg.sup_off; s_seg[1][tid] = sg.n_sup; s_seg[2][tid] = sg.tile_start; s_seg[3][tid] = sg.byte_off; }
     if (tid < 256) { s_cnt[tid] = 0; s_hist[tid] = 0; }
     if (tid == 0) {
         s_multi = 0;
@@ -498,13 +509,13 @@ __global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterA
     auto prefetch_meta = [&](u64 tl) {
         p_have = tl < t.ntiles; p_len = 0; p_gpos = 0;
         if (p_have) {
-            u64 base = s0_sup, n = s0_n, t0 = 0;
+            u64 base = s0_sup, n = s0_n, t0 = 0, byte0 = s0_byte;
             if (!single) {
                 while (sg_meta + 1 < nseg && s_seg[2][sg_meta + 1] <= tl) ++sg_meta;
-                base = s_seg[0][sg_meta]; n = s_seg[1][sg_meta]; t0 = s_seg[2][sg_meta];
+                base = s_seg[0][sg_meta]; n = s_seg[1][sg_meta]; t0 = s_seg[2][sg_meta]; byte0 = s_seg[3][sg_meta];
             }
             const u64 sidx = (tl - t0) * XS_TILE + tid;
-            if (sidx < n) { p_len = t.sm_len[base + sidx]; p_gpos = t.sm_gpos[base + sidx]; }
+            if (sidx < n) { p_len = t.sm_len[base + sidx]; p_gpos = byboff ? 4 * (byte0 + (u64)t.sm_boff[base + sidx]) : t.sm_gpos[base + sidx]; }
         }
     };
     auto load_win = [&](u64 gpos, u64 &r0, u64 &r1, u64 &r2) {
@@ -539,10 +550,7 @@ __global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterA
         u32 toti = ns, ei = (u32)tid;
         if (multi) {                                                   // (rare: repeats, homopolymers)
             ei = block_excl_scan_xs<XS_WAVES>(ni, s_scr, &toti);
-            s_ioff[tid] = (u16)ei; s_nk[tid] = (u8)nk; s_gpos[tid] = gp;
-            if (tid == XS_THREADS - 1) s_ioff[XS_TILE] = (u16)(ei + ni);
             if (tid == 0) s_multi = 0;
-            xs_barrier();
         }
         bool win_sent = false;
         for (u32 it0 = 0; it0 < toti; it0 += XS_THREADS) {
@@ -550,6 +558,11 @@ __global__ __launch_bounds__(XS_THREADS, 6) void expand_scatter2_kernel(ScatterA
             u32 cnt = 0; u64 ipos = gp;
             if (!multi) cnt = nk < (u32)XS_RUN ? nk : (u32)XS_RUN;       // item = supermer, window already here
             else {
+                // the tables, written into the stage (the previous flush is behind its last barrier; the next write to the stage
+                // is this flush's second sweep, two barriers from here)
+                s_ioff[tid] = (u16)ei; s_nk[tid] = (u8)nk; s_gpos[tid] = gp;
+                if (tid == XS_THREADS - 1) s_ioff[XS_TILE] = (u16)(ei + ni);
+                xs_barrier();
                 const u32 item = it0 + (u32)tid;
                 if (item < toti) {
                     u32 lo = 0, hi = XS_TILE;                          // last supermer whose first item is <= item
