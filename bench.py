@@ -377,7 +377,7 @@ def main():
                     return (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
             return None
 
-        def kern(name, ms, n, alg_bytes, bound, note):
+        def kern(name, ms, n, alg_bytes, bound, note, pmc_prefix=None):
             d = {"kernel": name, "ms_per_step": ms / S, "launches_per_step": n / S, "avg_launch_ms": (ms / n) if n else None, "bound": bound, "note": note}
             if alg_bytes and ms > 0:
                 d["algorithmic_bytes_per_launch"] = alg_bytes / max(n, 1)
@@ -385,13 +385,14 @@ def main():
                 d["frac_of_hbm_peak"] = d["algorithmic_GBs"] / HBM_PEAK_GBS
                 if copy_peak:
                     d["frac_of_copy_peak"] = d["algorithmic_GBs"] / copy_peak
-            d["pmc_traffic_bytes_per_launch"] = pmc_bytes(name)
+            d["pmc_traffic_bytes_per_launch"] = pmc_bytes(pmc_prefix or name)
             return d
         kernels = [
             kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
                  "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: ~97 VALU instructions per base position, 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records, so its HBM fraction says nothing about it"),
-            kern("expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
-                 "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins"),
+            kern("expand_scatter2_kernel" if KK <= 32 and not a.ext else "expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
+                 "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins; "
+                 "a chain of short phases per 3700-key flush, no unit of the CU saturated: bound by how many workgroups a CU holds (three since round 3: the two-sweep kernel)", pmc_prefix="expand_scatter"),
             kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
             kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"], "lds-issue", "per-prefix-bin LDS hash aggregation: reads every record once; bound by instruction issue around the LDS probes (scalar unit + LDS queue; the probe loop is hand-written assembly for that reason), not by HBM"),
             kern("place_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 13.0, "hbm-scattered",
