@@ -399,7 +399,21 @@ def main():
                  "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
         ]
         kernels.sort(key=lambda d: -d["ms_per_step"])
-        dom = kernels[0]                                   # the time-dominant kernel of THIS run
+        # The roofline block declares an HBM bound, so it names the time-dominant kernel AMONG THE HBM-BOUND ones; when a kernel with
+        # another bound leads the list (the VALU-bound minimizer scan, since the extraction got faster in round 3) it is named beside
+        # it with the fraction of ITS ceiling: VALU issue = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second.
+        dom = next(d for d in kernels if d["bound"].startswith("hbm"))
+        lead = kernels[0]
+        VALU_PEAK = 256 * 4 * 16 * 2.4e9
+        scan_instr_per_pos = 97.0                          # rocprofv3 SQ_INSTS_VALU x 64 / base positions (profiles/r02_pmc_summary_scale0.2.txt)
+        lead_note = None
+        if lead is not dom:
+            lead_note = {"kernel": lead["kernel"], "ms_per_step": lead["ms_per_step"], "bound": lead["bound"]}
+            if lead["kernel"] == "scan_kernel" and st["scan_ms"] > 0:
+                rate = scan_instr_per_pos * (st["scan_bytes"] * 4.0) / (st["scan_ms"] * 1e-3)
+                lead_note.update({"valu_lane_instr_per_s": rate, "valu_issue_peak": VALU_PEAK, "frac_of_valu_issue_peak": rate / VALU_PEAK,
+                                  "note": "97 VALU instructions per base position (SQ_INSTS_VALU, round-2 PMC pass) x positions / kernel time against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; "
+                                          "its HBM fraction (kernels[]) says nothing about it"})
         ms_total = phase.get("ms_total", 0) / S
         ref_b = 152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)
         dev = {"value": value, "unit": "k-mers/s", "ms_per_step": ms_step, "input": "resident in HBM", "output": "left in HBM"}
@@ -415,7 +429,8 @@ def main():
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
             "device_resident": dev,
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"] + " (the time-dominant kernel of this run: %.1f of %.1f ms per step; its bound: %s)" % (dom["ms_per_step"], ms_total, dom["bound"]),
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"] + " (the time-dominant HBM-bound kernel of this run: %.1f of %.1f ms per step)" % (dom["ms_per_step"], ms_total),
+                         "time_dominant_overall": lead_note,
                          "achieved": dom.get("algorithmic_GBs", 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom.get("frac_of_hbm_peak", 0.0), "traffic": dom["pmc_traffic_bytes_per_launch"],
                          "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this build (tools/gpu_round_artifacts.sh), NOT measured in this run",
