@@ -307,7 +307,8 @@ static int check_host_index(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *o
 // Four threads: segment sums, then every segment is checked against its base.  Runs beside the GPU's scan.
 // ... and do they end inside the packed buffer?  (A back-to-back index whose summed length runs past packed_bytes is "not fine"
 // here too: the caller's offsets are then checked on the device like any other index, and index_check_kernel rejects them.)
-static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint64_t nreads, uint64_t packed_bytes)
+// uniform_len != 0: ... and are all reads that long?  (the device generated the lengths from a sample instead of copying 4 bytes per read)
+static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint64_t nreads, uint64_t packed_bytes, uint32_t uniform_len)
 {
     constexpr int NT = 4;
     uint64_t seg[NT + 1], sum[NT];
@@ -323,7 +324,7 @@ static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint6
         std::thread th[NT];
         for (int t = 0; t < NT; ++t) th[t] = std::thread([&, t]() {
             uint64_t b = base[t]; bool good = true;
-            for (uint64_t r = seg[t]; r < seg[t + 1]; ++r) { good &= off[r] == b; b += ((uint64_t)len[r] + 3) >> 2; }
+            for (uint64_t r = seg[t]; r < seg[t + 1]; ++r) { good &= off[r] == b; good &= uniform_len == 0 || len[r] == uniform_len; b += ((uint64_t)len[r] + 3) >> 2; }
             ok[t] = good; });
         for (auto &x : th) x.join();
     }
@@ -354,14 +355,20 @@ static int derive_input(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *off, 
     DALLOC(c, d_tsum, u64 *, ntl * 8 + 64);
     u64 *stage = (u64 *)((char *)c->pinned + c->pinned_bytes - 256);
     *stage = packed_bytes;
-    HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
+    // Fixed-length reads (sequencer output): three samples say so, the device fills in the lengths, and the host threads that
+    // compare the offsets anyway verify EVERY length while the GPU scans -- 4 bytes per read less on the link (267 MB of 2.8 GB at
+    // 10 Gbp of 150-bp reads).  A single read of another length sends the call down the same road as a buffer with gaps.
+    static const bool uniform_enabled = !(getenv("HSK_UNIFORM_LEN") && atoi(getenv("HSK_UNIFORM_LEN")) == 0);
+    const uint32_t ulen = (uniform_enabled && len[0] != 0 && len[0] == len[nreads / 2] && len[0] == len[nreads - 1]) ? len[0] : 0;
+    if (ulen) { hipLaunchKernelGGL(rlen_fill_kernel, dim3(2048), dim3(256), 0, c->stream, d.rlen, nreads, ulen); c->rlen_host = len; c->stats.h2d_bytes -= nreads * 4; }
+    else HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(roff_tilesum_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum);
     hipLaunchKernelGGL(roff_tilescan_kernel, dim3(1), dim3(PARSE_THREADS), 0, c->stream, d_tsum, ntl);
     hipLaunchKernelGGL(roff_write_kernel, dim3((u32)ntl), dim3(PARSE_THREADS), 0, c->stream, d.rlen, nreads, d_tsum, d.roff);
     HIPCHK(c, hipMemcpyAsync(d.roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
     // the caller's offsets stay on the host: four threads check them against the back-to-back layout while the GPU scans
     c->roff_given = d_given; c->roff_host = off;
-    c->roff_check = std::async(std::launch::async, offsets_back_to_back, off, len, nreads, packed_bytes);
+    c->roff_check = std::async(std::launch::async, offsets_back_to_back, off, len, nreads, packed_bytes, ulen);
     return HSK_OK;
 }
 
@@ -393,7 +400,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     if (!derive) rc = upload_input(c, zc ? nullptr : packed, packed_bytes, off, len, nreads, d, false);
     else rc = derive_input(c, packed_bytes, off, len, nreads, d, d_given, d_tsum);
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
-    c->stats.h2d_bytes += packed_bytes + nreads * 12;
+    c->stats.h2d_bytes += packed_bytes + nreads * (derive ? 4 : 12);      // (derive: the offsets stay on the host; fixed-length reads: the lengths too, see derive_input)
     if (rc == HSK_OK && device_check && !derive) {
         hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, d.roff, d.rlen, nreads, packed_bytes, c->d_err);
         c->index_unchecked = true;
@@ -403,7 +410,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     tmark(zc ? (derive ? "input enqueued (zero-copy packed, offsets derived from the lengths)" : "input enqueued (zero-copy packed)") : "input enqueued (copies)");
     if (rc == HSK_OK) rc = dispatch_pipeline(c, d.packed, packed_bytes, d.roff, d.rlen, nreads, rid_base, out);
     tmark("pipeline returned");
-    c->zc_src = nullptr; c->h2d_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr; c->roff_bad = false;
+    c->zc_src = nullptr; c->h2d_src = nullptr; c->index_unchecked = false; c->roff_given = nullptr; c->roff_host = nullptr; c->roff_bad = false; c->rlen_host = nullptr;
     if (c->roff_check.valid()) (void)c->roff_check.get();          // (the pipeline failed before it collected the verdict)
     c->pool.release(d_given); c->pool.release(d_tsum);
     free_input(c, d);

@@ -127,7 +127,9 @@ struct hsk_ctx {
     // scans (result collected with the task totals); roff_host / roff_given: the caller's array and a device buffer for it, used
     // only when the comparison fails (a buffer with gaps)
     std::future<bool> roff_check;
-    bool roff_bad = false;             // ... its verdict, when somebody other than parse_count collected it (parse_ingest_pipelined)
+    bool roff_bad = false;
+    const uint32_t *rlen_host = nullptr;   // the read lengths were generated on the device from a sample (all reads equally long): the caller's array,
+                                           // copied after all if the host threads find a read of another length (same fallback as a buffer with gaps)             // ... its verdict, when somebody other than parse_count collected it (parse_ingest_pipelined)
     const uint64_t *roff_host = nullptr;
     u64 *roff_given = nullptr;
     bool index_unchecked = false;      // hsk_count(): the read index is validated on the device (index_check_kernel), the verdict is read with the task totals

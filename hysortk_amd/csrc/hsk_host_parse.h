@@ -202,6 +202,10 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             u64 *given = c->roff_given;
             c->pool.release(d_task_tot);
             parse_release(c, j);
+            if (c->rlen_host) {                                    // (the lengths were a guess from a sample: the real ones now)
+                HIPCHK(c, hipMemcpyAsync(const_cast<u32 *>(d_rlen), c->rlen_host, nreads * 4, hipMemcpyHostToDevice, c->stream));
+                c->stats.h2d_bytes += nreads * 4; c->rlen_host = nullptr;
+            }
             HIPCHK(c, hipMemcpyAsync(given, c->roff_host, nreads * 8, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(given + nreads, d_roff + nreads, 8, hipMemcpyDeviceToDevice, c->stream));
             hipLaunchKernelGGL(index_check_kernel, dim3(1024), dim3(256), 0, c->stream, given, d_rlen, nreads, packed_bytes, c->d_err);

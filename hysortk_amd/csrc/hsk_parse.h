@@ -995,6 +995,13 @@ __global__ void index_check_kernel(const u64 *roff, const u32 *rlen, u64 nreads,
 // read_byte_off[r] = sum of (len + 3) / 4 over the reads before r.  Only the lengths (4 B per read) are copied ahead of the
 // scan; the caller's offsets (8 B per read) do not travel at all: host threads compare them with the same prefix sums while
 // the GPU scans (hsk_api.hip: offsets_back_to_back).  A buffer with gaps between its reads is counted again with the caller's offsets.
+// read lengths that are all the same (fixed-length short reads): generated on the device instead of copied (hsk_count(), derive_input)
+__global__ void rlen_fill_kernel(u32 *rlen, u64 nreads, u32 len)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) rlen[r] = len;
+}
+
 constexpr int ROFF_TILE = PARSE_THREADS * 8;
 __global__ __launch_bounds__(PARSE_THREADS) void roff_tilesum_kernel(const u32 *rlen, u64 nreads, u64 *tile_sum)
 {

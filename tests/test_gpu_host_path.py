@@ -153,3 +153,35 @@ def test_result_outlives_its_context():
     L.hsk_result_free(None, C.byref(res))
     assert not res.entries and int(res.n) == 0
     assert np.array_equal(e[:, 0], want.kmers[:, 0]) and np.array_equal(e[:, 1], want.cnt) and np.array_equal(histo, want.histo)
+
+
+def test_pinned_reads_of_almost_uniform_length():
+    """Pinned input whose first, middle and last read are equally long: the device generates the read lengths from that sample instead of
+    copying them, host threads verify every length while the GPU scans.  Here 1 % of the reads are shorter (none of the sampled ones):
+    the guess is wrong, the call must notice and count with the real lengths -- same list as from pageable memory.  With truly uniform
+    lengths (second half) the guess holds."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 4321
+    seqs_packed, off0, lens0 = synth.packed_reads(2000000, 150, n, 33)
+    rng = np.random.default_rng(3)
+    lens = lens0.copy()
+    short = rng.choice(np.arange(1, n - 1), n // 100, replace=False)
+    short = short[short != n // 2]
+    lens[short] = 120                                            # the packed bytes stay where they are: a read simply ends earlier ...
+    packed = seqs_packed
+    off = off0                                                   # ... so the buffer has gaps too (38 bytes per slot, 30 used)
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
+    with H.Context(K=31, M=17, L=2, U=200, ntasks=16) as c:
+        a = c.count((pp, po, pl))
+        ref = c.count((packed, off, lens))
+        pl[:] = lens0
+        b = c.count((pp, po, pl))
+        ref_b = c.count((packed, off0, lens0))
+        st = c.stats()
+    for y in (pp, po, pl):
+        H.pinned_free(y)
+    assert len(ref) > 100000 and len(ref) != len(ref_b)
+    assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off)
+    assert np.array_equal(ref_b.kmers, b.kmers) and np.array_equal(ref_b.cnt, b.cnt)
