@@ -182,6 +182,6 @@ def test_pinned_reads_of_almost_uniform_length():
         st = c.stats()
     for y in (pp, po, pl):
         H.pinned_free(y)
-    assert len(ref) > 100000 and len(ref) != len(ref_b)
+    assert len(ref) > 100000 and int(ref.cnt.sum()) < int(ref_b.cnt.sum())             # (the shorter reads really count for less)
     assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off)
     assert np.array_equal(ref_b.kmers, b.kmers) and np.array_equal(ref_b.cnt, b.cnt)
