@@ -106,7 +106,8 @@ def test_pinned_input_with_gaps_between_reads():
         assert np.array_equal(ref.kmers, x.kmers) and np.array_equal(ref.cnt, x.cnt) and np.array_equal(ref.task_off, x.task_off)
 
 
-def test_slab_ingest_equals_reads_in_place():
+@pytest.mark.parametrize("K,EXT", [(31, 0), (51, 0), (31, 1)])
+def test_slab_ingest_equals_reads_in_place(K, EXT):
     """Pinned input above 32 MB: the packed reads arrive as DMA copies slab by slab while the scan hashes the slabs before
     (HSK_H2D_SLABS=8 by default, 3 here as well; the last slab is short and a read straddles every slab edge); =0: the scan reads
     the host buffer in place as in round 2.  Same list, same histogram, and equal to the pageable path.  Subprocesses: the
@@ -119,10 +120,11 @@ def test_slab_ingest_equals_reads_in_place():
             "packed, off, lens = synth.packed_reads(2000000, 150, n, 21)\n"
             "pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)\n"
             "pp[:] = packed; po[:] = off; pl[:] = lens\n"
-            "c = H.Context(K=31, M=17, L=2, U=200, ntasks=16)\n"
+            "c = H.Context(K=%d, M=17, L=2, U=200, EXT=%d, ntasks=16)\n"
             "for src in ((pp, po, pl), (packed, off, lens), (pp, po, pl)):\n"
             "    r = c.count(src)\n"
-            "    print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
+            "    pay = b'' if r.pos is None else np.sort(r.pos.astype(np.uint64) | (r.rid.astype(np.uint64) << np.uint64(32))).tobytes()\n"
+            "    print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes() + pay).hexdigest(), len(r))\n") % (util.ROOT, K, EXT)
     outs = []
     # ({}: ingest, scan and placement as one pipeline, the store laid out [slab][task]; HSK_INGEST_PIPELINE=0: slab ingest, one placement;
     #  a record capacity of 300 makes some tile overflow: both fall back to the general parse kernels with the reads already in HBM)
