@@ -104,8 +104,7 @@ static u32 auto_ntasks(hsk_ctx *c, u64 packed_bytes, int nranks)
 // long bin with several keys, see hsk_finish.h) are redone with the full-width passes and the two-pass counter.
 static bool finish_enabled()
 {
-    static const bool on = !(getenv("HSK_FUSED_FINISH") && atoi(getenv("HSK_FUSED_FINISH")) == 0);
-    return on && !(g_plan_flags & HSK_FLAG_FULL_SORT);
+    return !(g_plan_flags & HSK_FLAG_FULL_SORT);
 }
 
 template <int NW>
@@ -179,8 +178,7 @@ static int finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, u64 max_task, u
 // ---- two passes + aggregation (hsk_agg.h): the batch's keys are sorted on their top 16 bits ---------------
 static bool agg_enabled()
 {
-    static const bool on = !(getenv("HSK_AGG") && atoi(getenv("HSK_AGG")) == 0);
-    return on && !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
+    return !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
 }
 
 // The aggregating finish of a batch in two stages, so that the host never has to wait for the GPU with nothing queued

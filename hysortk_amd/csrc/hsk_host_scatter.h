@@ -78,15 +78,10 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     }
     a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.chunk = XS_CHUNK; a.err = c->d_err;
     const bool ext = c->cfg.extension != 0;
-    // HSK_XS_TPB=256 (experiment, see hsk_scatter.h): 256-thread workgroups, four per CU, for one-word keys without payload whose
-    // supermers are one in-place segment per task (one GPU); tiles are then counted in units of 256 supermers
-    static const int xs_tpb = getenv("HSK_XS_TPB") ? atoi(getenv("HSK_XS_TPB")) : XS_THREADS;
-    bool small_wg = xs_tpb == 256 && NW == 1 && !ext;
-    for (int i = 0; i < XCD_BATCH && small_wg; ++i) if (xi[i] >= 0 && !(jobs[i].ts->segs.size() == 1 && jobs[i].src.gpos != nullptr)) small_wg = false;
     // expand_scatter2_kernel (two sweeps per flush, three workgroups per CU: 33.0 against 36.2 ms per step on the benchmark) takes
     // one-word keys without payload whose bases are read in place, at most XS_MAXSEG segments per task; HSK_XS2=0: the one-sweep kernel
     static const bool xs2_env = !(getenv("HSK_XS2") && atoi(getenv("HSK_XS2")) == 0);
-    bool xs2 = xs2_env && NW == 1 && !ext && small_wg == false;
+    bool xs2 = xs2_env && NW == 1 && !ext;
     for (int i = 0; i < XCD_BATCH && xs2; ++i) if (xi[i] >= 0 && !(reads_in_place(jobs[i].src) && jobs[i].ts->segs.size() <= (size_t)XS_MAXSEG)) xs2 = false;
     if constexpr (NW == 1) {
         if (xs2) {
@@ -96,19 +91,6 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
             const u32 grid = (u32)occ2 * 256u;
             if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56) hipLaunchKernelGGL((expand_scatter2_kernel<31>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((expand_scatter2_kernel<0>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
-            if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
-            HIPCHK(c, hipGetLastError());
-            sb.active = true;
-            return HSK_OK;
-        }
-        if (small_wg) {
-            for (int i = 0; i < XCD_BATCH; ++i) if (xi[i] >= 0) a.t[i].ntiles = (jobs[i].ts->segs[0].n_sup + 255) / 256;
-            static int occ256 = 0;
-            if (!occ256) { int nb = 0; occ256 = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, expand_scatter_kernel<1, false, 31, 256>, 256, 0) == hipSuccess && nb > 0) ? nb : 4; }
-            EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * 8; (void)hipEventRecord(ep.a, stream); }
-            const u32 grid = (u32)occ256 * 256u;
-            if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56) hipLaunchKernelGGL((expand_scatter_kernel<1, false, 31, 256>), dim3(grid), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((expand_scatter_kernel<1, false, 0, 256>), dim3(grid), dim3(256), 0, stream, a);
             if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
             HIPCHK(c, hipGetLastError());
             sb.active = true;

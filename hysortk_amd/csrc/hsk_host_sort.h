@@ -32,8 +32,7 @@ static int make_hybrid_plan(PassDesc *out, int prefix_bits = 64 - HYBRID_SHIFT, 
 }
 static bool hybrid_enabled()
 {
-    static const bool on = !(getenv("HSK_HYBRID") && atoi(getenv("HSK_HYBRID")) == 0);
-    return on && !(g_plan_flags & HSK_FLAG_FULL_SORT);
+    return !(g_plan_flags & HSK_FLAG_FULL_SORT);
 }
 // Two- and three-word keys take the prefix plan when the aggregating finish follows.  Where the most significant word carries
 // fewer than the 16 prefix bits (K - 32 (NW - 1) < 8 bases), the prefix continues in the top bits of the word below it

@@ -114,10 +114,8 @@ __device__ unsigned long long g_xs_diag[16];
 // keeps (lane, round) per slot and the lanes' base values sit in LDS, so the payload is rebuilt when the run is written.
 // KT: k as a compile-time constant with the two digits in the top 16 key bits (0: k and the digit shifts come from the
 // arguments).  The reference fixes k at compile time (KMER_SIZE); here the default k gets its own instance.
-// TPB: threads per workgroup = supermers per tile.  512 (two workgroups per CU) everywhere; the 256-thread instance -- four
-// workgroups per CU at the same wave count: twice as many independent barrier domains to fill the gaps of the phase chain,
-// half the flush, a stage of half a chunk -- exists for one-word keys without payload whose bases are read in place from ONE
-// segment (one GPU), where the host counts tiles in units of TPB supermers (HSK_XS_TPB, hsk_host_scatter.h).
+// TPB: threads per workgroup = supermers per tile (512 everywhere; a 256-thread instance -- four workgroups per CU, half the flush --
+// was measured in round 3 and is slower: DESIGN.md 6.3).
 template <int NW, bool EXT, int KT = 0, int TPB = XS_THREADS>
 __global__ __launch_bounds__(TPB, 4) void expand_scatter_kernel(ScatterArgs a)
 {

@@ -657,19 +657,20 @@ def test_aggregating_finish_table_ladder(H, O, L, U):
 
 
 def test_fused_finish_equals_two_pass_path(H):
-    """Same input through the aggregating finish (default), HSK_AGG=0 (tile finish), HSK_FUSED_FINISH=0, HSK_HYBRID=0 and
-    the single-task path (subprocesses: the switches are read once)."""
+    """Same input through the aggregating finish (default), the other two plans of the C ABI (HSK_FLAG_NO_AGGREGATION: tile finish,
+    HSK_FLAG_FULL_SORT: the reference's algorithm), the single-task path and every test switch of the library (subprocesses: the
+    switches are read once)."""
     import subprocess, sys, os, json
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
-            "c = H.Context(K=31, M=17, L=2, U=60, ntasks=24)\n"
+    code = ("import os, sys, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
+            "c = H.Context(K=31, M=17, L=2, U=60, ntasks=24, plan=os.environ.get('HSK_TEST_PLAN') or None)\n"
             "dp, nb, do, dl = c.synth_reads(3000000, 150, 400000, 5)\n"
             "r = c.count_device(dp, nb, do, dl, 400000)\n"
             "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r))\n") % util.ROOT
     outs = []
     # ... and the parse: fast path (scan/place kernels), the general kernels, and the fast path overflowing its record
     # capacity (falls back to the general kernels; a capacity of 300 is hit by some tiles only)
-    for env in ({"HSK_FUSED_FINISH": "1"}, {"HSK_AGG": "0"}, {"HSK_FUSED_FINISH": "0"}, {"HSK_HYBRID": "0"}, {"HSK_XCD_BATCH": "0"},
-                {"HSK_PARSE_FAST": "0"}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}, {"HSK_SCAN_GENERIC": "1"}, {"HSK_SCATTER_GENERIC": "1"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}, {"HSK_LAG": "0"}, {"HSK_LAG": "1"}, {"HSK_EARLY_D2H": "0"}, {"HSK_COMPACT_D2H": "0"}, {"HSK_WIDEN_THREADS": "3"}, {"HSK_ZERO_COPY": "0"}, {"HSK_XS_TPB": "256"}, {"HSK_XS2": "0"}, {"HSK_PLACE_BYTES": "1"}, {"HSK_DERIVE_OFFSETS": "0"}):
+    for env in ({}, {"HSK_TEST_PLAN": "no_aggregation"}, {"HSK_TEST_PLAN": "full_sort"}, {"HSK_TEST_PLAN": "full_sort", "HSK_XCD_BATCH": "0"}, {"HSK_XCD_BATCH": "0"},
+                {"HSK_PARSE_FAST": "0"}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}, {"HSK_SCAN_GENERIC": "1"}, {"HSK_SCATTER_GENERIC": "1"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}, {"HSK_LAG": "0"}, {"HSK_LAG": "1"}, {"HSK_EARLY_D2H": "0"}, {"HSK_COMPACT_D2H": "0"}, {"HSK_WIDEN_THREADS": "3"}, {"HSK_ZERO_COPY": "0"}, {"HSK_XS2": "0"}, {"HSK_PLACE_BYTES": "1"}, {"HSK_DERIVE_OFFSETS": "0"}):
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
