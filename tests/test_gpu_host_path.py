@@ -190,3 +190,22 @@ def test_pinned_reads_of_almost_uniform_length():
     assert len(ref) > 100000 and int(ref.cnt.sum()) < int(ref_b.cnt.sum())             # (the shorter reads really count for less)
     assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off)
     assert np.array_equal(ref_b.kmers, b.kmers) and np.array_equal(ref_b.cnt, b.cnt)
+
+
+@pytest.mark.parametrize("ntasks", [1, 5, 7])
+def test_pipelined_ingest_with_few_tasks(ntasks):
+    """Pinned input above 32 MB with the reference's small task counts: the store is laid out [slab][task], every task has one segment
+    per slab, and one to seven tasks take the single-task extraction / the padded batch -- same list as from pageable memory."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 99
+    packed, off, lens = synth.packed_reads(1500000, 150, n, 8)
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
+    with H.Context(K=31, M=17, L=2, U=300, ntasks=ntasks) as c:
+        a = c.count((pp, po, pl))
+        ref = c.count((packed, off, lens))
+    for y in (pp, po, pl):
+        H.pinned_free(y)
+    assert len(ref) > 100000
+    assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off) and np.array_equal(ref.histo, a.histo)
