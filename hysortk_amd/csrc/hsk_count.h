@@ -208,4 +208,42 @@ __global__ __launch_bounds__(256) void pack_entries_kernel(const u64 *entries, u
     }
 }
 
+// One-word keys, the smaller form: a task's list is ascending, so the top 16 key bits -- the prefix the sort grouped by -- need
+// not travel with every entry: an entry is the low 48 key bits (u32 + u16) and its count (u8 when UPPER_KMER_FREQ <= 255, else
+// u16), 7 bytes for 16, and a directory per task says where each prefix starts: dir[p] = first entry whose key >> 48 is >= p,
+// dir[65536] = n (first written where a prefix begins, then closed over the empty prefixes by pack_dir_close_kernel).
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_entries_prefix_kernel(const u64 *entries, u64 n, u32 *lo32, unsigned short *mid16, CT *cnt, u32 *dir)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 key = entries[2 * i];
+        lo32[i] = (u32)key; mid16[i] = (unsigned short)(key >> 32); cnt[i] = (CT)entries[2 * i + 1];
+        const u32 p = (u32)(key >> 48);
+        if (i == 0 || (u32)(entries[2 * i - 2] >> 48) != p) dir[p] = (u32)i;
+    }
+}
+// dir[p] = 0xFFFFFFFF for prefixes without entries -> the start of the next prefix that has some (suffix minimum); one workgroup
+// of 1024 threads per task, 64 prefixes per thread; dir[65536] = n.
+__global__ __launch_bounds__(1024) void pack_dir_close_kernel(u32 *dir, u32 n)
+{
+    __shared__ u32 s_min[1024];
+    const int tid = threadIdx.x;
+    u32 m = 0xFFFFFFFFu;
+    for (int q = 63; q >= 0; --q) { const u32 v = dir[tid * 64 + q]; if (v < m) m = v; }
+    s_min[tid] = m;
+    __syncthreads();
+    // suffix minimum over the threads behind this one (1024 values: a plain loop per thread would do; halving steps are shorter)
+    for (int d = 1; d < 1024; d <<= 1) {
+        const u32 o = (tid + d < 1024) ? s_min[tid + d] : 0xFFFFFFFFu;
+        __syncthreads();
+        if (o < s_min[tid]) s_min[tid] = o;
+        __syncthreads();
+    }
+    u32 run = (tid + 1 < 1024) ? s_min[tid + 1] : 0xFFFFFFFFu;
+    if (run > n) run = n;
+    for (int q = 63; q >= 0; --q) { const u32 v = dir[tid * 64 + q]; if (v < run) run = v; dir[tid * 64 + q] = run; }
+    if (tid == 0) dir[65536] = n;
+}
+
 } // namespace hsk

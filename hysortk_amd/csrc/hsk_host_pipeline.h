@@ -207,7 +207,11 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
 // Host threads that widen compact result batches (pack_entries_kernel's k-mer words + 16-bit counts, copied into pinned staging)
 // into the caller-visible entries while the GPU counts the next batches.  Every thread of a batch waits for the batch's copy
 // event, then takes its slice.  The destructor joins: no thread outlives the call that started it.
-struct WidenPiece { hipEvent_t copied; const u64 *keys; const unsigned short *cnts; u64 *dst; u64 n; };      // one task's share of a batch
+struct WidenPiece {                                                 // one task's share of a batch
+    hipEvent_t copied; const u64 *keys; const unsigned short *cnts; u64 *dst; u64 n;
+    // prefix form (one-word keys): low 48 key bits as u32 + u16, counts of cw bytes, dir[p] = first entry of prefix p (dir[65536] = n)
+    const u32 *lo32 = nullptr; const unsigned short *mid16 = nullptr; const u8 *cnt8 = nullptr; const u32 *dir = nullptr; int cw = 0;
+};
 struct WidenPool {
     hsk_ctx *c;
     std::vector<std::thread> th;
@@ -235,6 +239,22 @@ struct WidenPool {
                     (void)hipEventSynchronize(p.copied);
                     const u64 lo = p.n * (u64)t / nt, hi = p.n * (u64)(t + 1) / nt;
                     const u64 *keys = p.keys; const unsigned short *cnts = p.cnts; u64 *dst = p.dst;
+                    if (p.dir) {                                       // prefix form: the top 16 key bits come from the directory
+                        if (lo >= hi) continue;
+                        typedef unsigned long long v2u64p __attribute__((vector_size(16)));
+                        u32 pl = 0, ph = 65536;                        // last prefix that starts at or before entry lo
+                        while (ph - pl > 1) { const u32 mid = (pl + ph) >> 1; if ((u64)p.dir[mid] <= lo) pl = mid; else ph = mid; }
+                        u32 pre = pl; u64 next = p.dir[pre + 1];
+                        const bool nt = ((uintptr_t)dst & 15) == 0;
+                        for (u64 i = lo; i < hi; ++i) {
+                            while (i >= next) { ++pre; next = p.dir[pre + 1]; }
+                            const unsigned long long key = ((unsigned long long)pre << 48) | ((unsigned long long)p.mid16[i] << 32) | p.lo32[i];
+                            const unsigned long long cv = p.cw == 1 ? (unsigned long long)p.cnt8[i] : (unsigned long long)reinterpret_cast<const unsigned short *>(p.cnt8)[i];
+                            if (nt) { const v2u64p e = {key, cv}; __builtin_nontemporal_store(e, (v2u64p *)dst + i); }
+                            else { dst[2 * i] = key; dst[2 * i + 1] = cv; }
+                        }
+                        continue;
+                    }
                     // one-word keys: an entry is one aligned 16-byte store that nobody reads back soon -- non-temporal (no read for
                     // ownership: a plain store loop is bound by the cache lines it first has to fetch)
                     typedef unsigned long long v2u64 __attribute__((vector_size(16)));
@@ -363,8 +383,10 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty());
     u64 *early_buf = nullptr; u64 early_cap = 0, early_used = 0, early_kmers = 0;
     // compact copies (HSK_COMPACT_D2H=0: entries travel as they are): counts fit 16 bits whenever the filter's upper bound does
-    static const bool compact_enabled = !(getenv("HSK_COMPACT_D2H") && atoi(getenv("HSK_COMPACT_D2H")) == 0);
-    const bool compact = compact_enabled && c->cfg.upper_freq <= 65535;
+    // HSK_COMPACT_D2H: 0 entries as they are (16 bytes), 1 k-mer words + 16-bit counts (10 bytes), 2 (default) the prefix form for
+    // one-word keys (7 bytes with U <= 255, else 8; + 256 KB of directory per task)
+    static const int compact_mode = getenv("HSK_COMPACT_D2H") ? atoi(getenv("HSK_COMPACT_D2H")) : 2;
+    const bool compact = compact_mode > 0 && c->cfg.upper_freq <= 65535;
     WidenPool widen(c);
     u64 compact_bytes = 0, compact_entries = 0;
     std::vector<void *> pk_dev, pk_host;                  // device / pinned staging of the compact batches (handed back when the call ends)
@@ -386,22 +408,42 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         // compact: every task's entries are packed on the main stream ([k-mer words][16-bit counts], 16-byte aligned per task), copied
         // task by task into pinned staging and widened into early_buf by host threads while the next batch is counted
         u8 *d_pk = nullptr, *h_pk = nullptr;
-        size_t pk_off[XCD_BATCH + 1] = {0};
+        size_t pk_off[XCD_BATCH + 1] = {0}, pk_len[XCD_BATCH] = {0};
+        // one-word keys: the prefix form (7 or 8 bytes per entry + a 256 KB directory per task); otherwise k-mer words + 16-bit counts
+        const bool prefix_form = NW == 1 && compact_mode >= 2;
+        const int cw = c->cfg.upper_freq <= 255 ? 1 : 2;
+        constexpr size_t DIR_BYTES = (size_t)65537 * 4 + 12;            // (padded to 16 bytes)
         if (compact && nb) {
+            bool fits = true;
             for (int i = 0; i < ntk; ++i) {
                 const u64 n_i = (tasks[i] == EMPTY_TASK) ? 0 : touts[tasks[i]].n;
-                pk_off[i + 1] = pk_off[i] + (((size_t)n_i * (NW * 8 + 2) + 15) & ~(size_t)15);
+                if (n_i >= 0xFFFFFFF0ULL) fits = false;
+                pk_len[i] = prefix_form ? (n_i ? (((size_t)n_i * 4 + 15) & ~(size_t)15) + (((size_t)n_i * 2 + 15) & ~(size_t)15) + (((size_t)n_i * cw + 15) & ~(size_t)15) + DIR_BYTES : 0)
+                                        : (size_t)n_i * (NW * 8 + 2);
+                pk_off[i + 1] = pk_off[i] + ((pk_len[i] + 15) & ~(size_t)15);
             }
             const size_t pk_bytes = pk_off[ntk] + 64;
-            d_pk = (u8 *)c->pool.alloc(pk_bytes); h_pk = (u8 *)host_alloc(c, rp, pk_bytes);
+            if (fits) { d_pk = (u8 *)c->pool.alloc(pk_bytes); h_pk = (u8 *)host_alloc(c, rp, pk_bytes); }
             if (!d_pk || !h_pk) { c->pool.release(d_pk); if (h_pk) host_release(c, rp, h_pk); d_pk = nullptr; h_pk = nullptr; }      // (no room: this batch travels as it is)
             else {
                 pk_dev.push_back(d_pk); pk_host.push_back(h_pk);
                 for (int i = 0; i < ntk; ++i) {
                     if (tasks[i] == EMPTY_TASK || !touts[tasks[i]].n) continue;
                     const TaskOut &to = touts[tasks[i]];
-                    hipLaunchKernelGGL(pack_entries_kernel, dim3((u32)std::min<u64>((to.n + 255) / 256, 2048)), dim3(256), 0, c->stream, to.entries, to.n, NW,
-                                       (u64 *)(d_pk + pk_off[i]), (unsigned short *)(d_pk + pk_off[i] + (size_t)to.n * NW * 8));
+                    const u32 grid = (u32)std::min<u64>((to.n + 255) / 256, 2048);
+                    if (prefix_form) {
+                        if constexpr (NW == 1) {
+                            u8 *b = d_pk + pk_off[i];
+                            u32 *lo32 = (u32 *)b; unsigned short *mid16 = (unsigned short *)(b + (((size_t)to.n * 4 + 15) & ~(size_t)15));
+                            u8 *cnt = (u8 *)mid16 + (((size_t)to.n * 2 + 15) & ~(size_t)15);
+                            u32 *dir = (u32 *)(cnt + (((size_t)to.n * cw + 15) & ~(size_t)15));
+                            HIPCHK(c, hipMemsetAsync(dir, 0xFF, (size_t)65537 * 4, c->stream));
+                            if (cw == 1) hipLaunchKernelGGL((pack_entries_prefix_kernel<u8>), dim3(grid), dim3(256), 0, c->stream, to.entries, to.n, lo32, mid16, cnt, dir);
+                            else hipLaunchKernelGGL((pack_entries_prefix_kernel<unsigned short>), dim3(grid), dim3(256), 0, c->stream, to.entries, to.n, lo32, mid16, (unsigned short *)cnt, dir);
+                            hipLaunchKernelGGL(pack_dir_close_kernel, dim3(1), dim3(1024), 0, c->stream, dir, (u32)to.n);
+                        }
+                    } else hipLaunchKernelGGL(pack_entries_kernel, dim3(grid), dim3(256), 0, c->stream, to.entries, to.n, NW,
+                                              (u64 *)(d_pk + pk_off[i]), (unsigned short *)(d_pk + pk_off[i] + (size_t)to.n * NW * 8));
                 }
             }
         }
@@ -416,16 +458,23 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             for (int i = 0; i < ntk; ++i) {
                 if (tasks[i] == EMPTY_TASK || !touts[tasks[i]].n) continue;
                 const u64 n_i = touts[tasks[i]].n;
-                HIPCHK(c, hipMemcpyAsync(h_pk + pk_off[i], d_pk + pk_off[i], (size_t)n_i * (NW * 8 + 2), hipMemcpyDeviceToHost, c->d2h_stream));
+                HIPCHK(c, hipMemcpyAsync(h_pk + pk_off[i], d_pk + pk_off[i], pk_len[i], hipMemcpyDeviceToHost, c->d2h_stream));
                 WidenPiece wp; wp.copied = ev_get(c);
                 HIPCHK(c, hipEventRecord(wp.copied, c->d2h_stream));
-                wp.keys = (const u64 *)(h_pk + pk_off[i]); wp.cnts = (const unsigned short *)(h_pk + pk_off[i] + (size_t)n_i * NW * 8);
+                wp.keys = nullptr; wp.cnts = nullptr;
+                if (prefix_form) {
+                    const u8 *b = h_pk + pk_off[i];
+                    wp.lo32 = (const u32 *)b; wp.mid16 = (const unsigned short *)(b + (((size_t)n_i * 4 + 15) & ~(size_t)15));
+                    wp.cnt8 = (const u8 *)wp.mid16 + (((size_t)n_i * 2 + 15) & ~(size_t)15);
+                    wp.dir = (const u32 *)(wp.cnt8 + (((size_t)n_i * cw + 15) & ~(size_t)15)); wp.cw = cw;
+                } else { wp.keys = (const u64 *)(h_pk + pk_off[i]); wp.cnts = (const unsigned short *)(h_pk + pk_off[i] + (size_t)n_i * NW * 8); }
                 wp.dst = early_buf + (early_used + o) * (NW + 1); wp.n = n_i;
                 pieces.push_back(wp);
                 o += n_i;
+                compact_bytes += pk_len[i];
             }
             widen.add(pieces, NW);
-            compact_bytes += (u64)nb * (NW * 8 + 2); compact_entries += nb;
+            compact_entries += nb;
         }
         for (int i = 0; i < ntk; ++i) {
             const u32 t = tasks[i];

@@ -670,7 +670,7 @@ def test_fused_finish_equals_two_pass_path(H):
     # ... and the parse: fast path (scan/place kernels), the general kernels, and the fast path overflowing its record
     # capacity (falls back to the general kernels; a capacity of 300 is hit by some tiles only)
     for env in ({}, {"HSK_TEST_PLAN": "no_aggregation"}, {"HSK_TEST_PLAN": "full_sort"}, {"HSK_TEST_PLAN": "full_sort", "HSK_XCD_BATCH": "0"}, {"HSK_XCD_BATCH": "0"},
-                {"HSK_PARSE_FAST": "0"}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}, {"HSK_SCAN_GENERIC": "1"}, {"HSK_SCATTER_GENERIC": "1"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}, {"HSK_LAG": "0"}, {"HSK_LAG": "1"}, {"HSK_EARLY_D2H": "0"}, {"HSK_COMPACT_D2H": "0"}, {"HSK_WIDEN_THREADS": "3"}, {"HSK_ZERO_COPY": "0"}, {"HSK_XS2": "0"}, {"HSK_PLACE_BYTES": "1"}, {"HSK_DERIVE_OFFSETS": "0"}):
+                {"HSK_PARSE_FAST": "0"}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}, {"HSK_SCAN_GENERIC": "1"}, {"HSK_SCATTER_GENERIC": "1"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}, {"HSK_LAG": "0"}, {"HSK_LAG": "1"}, {"HSK_EARLY_D2H": "0"}, {"HSK_COMPACT_D2H": "0"}, {"HSK_COMPACT_D2H": "1"}, {"HSK_WIDEN_THREADS": "3"}, {"HSK_ZERO_COPY": "0"}, {"HSK_XS2": "0"}, {"HSK_PLACE_BYTES": "1"}, {"HSK_DERIVE_OFFSETS": "0"}):
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
