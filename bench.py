@@ -279,9 +279,11 @@ def e2e_host_leg(H, KK, ext, ntasks, local, genome_len, nreads, seed, steps):
     nk = nreads * (READ_LEN - KK + 1)
     mean = sum(secs) / len(secs)
     return {"value": nk / mean, "unit": "k-mers/s", "ms_per_step": mean * 1e3, "steps": steps, "L": L, "U": U, "entries": n_entries,
-            "input": "DnaBuffer in pinned host memory (hsk_host_alloc): packed reads read in place over PCIe by the minimizer scan; of the read index only the lengths travel "
-                     "(offsets derived on the device, the caller's offsets checked against them by host threads while the GPU scans)",
-            "output": "KmerListS entries + histogram in pinned host memory; batches copied while later batches are counted",
+            "input": "DnaBuffer in pinned host memory (hsk_host_alloc): the packed reads cross PCIe as 16 DMA slabs pipelined with the minimizer scan and the placement; "
+                     "of the read index nothing travels for fixed-length reads (lengths generated on the device from a sample, offsets derived from them; host threads verify "
+                     "every length and offset while the GPU scans)",
+            "output": "KmerListS entries + histogram in pinned host memory; a batch's entries cross PCIe as 7 bytes each (low 48 key bits + 8-bit count below a per-task prefix "
+                      "directory) while later batches are counted, and are widened to the 16-byte KmerListEntryS layout by host threads",
             "h2d_bytes_per_step": st["h2d_bytes"] / steps, "d2h_bytes_per_step": st["d2h_bytes"] / steps,
             "h2d_ms": st["h2d_ms"] / steps, "d2h_ms": st["d2h_ms"] / steps,
             "device_ms_total": info["ms_total"], "host_syncs_per_step": st["host_syncs"] / steps, "host_waits_covered_per_step": st["host_waits_covered"] / steps}
