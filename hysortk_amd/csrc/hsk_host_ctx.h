@@ -195,6 +195,14 @@ static hipEvent_t ev_get(hsk_ctx *c)
 }
 static void ev_put(hsk_ctx *c, hipEvent_t e) { c->ev_free.push_back(e); }
 
+// events of one scope: handed back to the pool on every way out (the early returns of HIPCHK included)
+struct EvList {
+    hsk_ctx *c; std::vector<hipEvent_t> v;
+    explicit EvList(hsk_ctx *c_) : c(c_) {}
+    hipEvent_t get() { v.push_back(ev_get(c)); return v.back(); }
+    ~EvList() { for (auto e : v) ev_put(c, e); }
+};
+
 // phase timer: records an event pair on the stream, elapsed time is summed after the final sync
 struct PhaseTimer {
     hsk_ctx *c; std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[8];

@@ -170,12 +170,13 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             // copy of slab s + 1 (a tile's windows reach a few words into the next tile), so the link and the VALUs work side by side:
             // the parse takes about as long as the transfer (a kernel reading the host buffer in place gets ~40 GB/s out of the link,
             // the DMA engine ~55).
+            EvList evs(c);
             std::vector<hipEvent_t> landed(a.nslabs);
             EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, c->d2h_stream); }
             for (u32 sl = 0; sl < a.nslabs; ++sl) {
                 const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
                 if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, c->d2h_stream));
-                landed[sl] = ev_get(c);
+                landed[sl] = evs.get();
                 HIPCHK(c, hipEventRecord(landed[sl], c->d2h_stream));
             }
             if (profile) { (void)hipEventRecord(hp.b, c->d2h_stream); c->ev_pending.push_back(hp); }
@@ -185,7 +186,6 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
                 launch_scan();
             }
             a.slab = 0;
-            for (auto e : landed) ev_put(c, e);
         } else launch_scan();
         if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         a.packed = d_packed; a.packed_copy = nullptr; c->zc_src = nullptr;                                  // everything after the scan reads the copy in HBM
@@ -373,16 +373,16 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     HIPCHK(c, hipMemcpyAsync(d_order, h_order, (size_t)ntasks * 4, hipMemcpyHostToDevice, sA));
     a.tile_rec = d_tile_rec; a.tile_nrec = d_tile_nrec; a.overflow = d_overflow;
     a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.blk_base = d_blk_base; a.task_base3 = d_task_base;
-    hipEvent_t ready = ev_get(c);                                          // the small buffers above are set up; the second stream may start
+    EvList evs(c);
+    hipEvent_t ready = evs.get();                                          // the small buffers above are set up; the second stream may start
     HIPCHK(c, hipEventRecord(ready, sA));
     HIPCHK(c, hipStreamWaitEvent(sB, ready, 0));
-    ev_put(c, ready);
     std::vector<hipEvent_t> landed(nsl), scanned(nsl);
     EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, sC); }
     for (u32 sl = 0; sl < nsl; ++sl) {
         const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
         if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, sC));
-        landed[sl] = ev_get(c);
+        landed[sl] = evs.get();
         HIPCHK(c, hipEventRecord(landed[sl], sC));
     }
     if (profile) { (void)hipEventRecord(hp.b, sC); c->ev_pending.push_back(hp); }
@@ -396,7 +396,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
-        scanned[sl] = ev_get(c);
+        scanned[sl] = evs.get();
         HIPCHK(c, hipEventRecord(scanned[sl], sA));
         // the slab's placement on the second stream: totals, bases (behind everything the slabs before laid out), supermers to their slots
         HIPCHK(c, hipStreamWaitEvent(sB, scanned[sl], 0));
@@ -413,13 +413,10 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     HIPCHK(c, hipMemcpyAsync(h_flags, d_overflow, 4, hipMemcpyDeviceToHost, sB));
     HIPCHK(c, hipMemcpyAsync(h_flags + 1, c->d_err, 4, hipMemcpyDeviceToHost, sB));
     HIPCHK(c, hipMemcpyAsync(staged ? h_tot : tot.data(), d_tot, (size_t)nsl * ntasks * 24, hipMemcpyDeviceToHost, sB));
-    hipEvent_t placed = ev_get(c);
+    hipEvent_t placed = evs.get();
     HIPCHK(c, hipEventRecord(placed, sB));
     HIPCHK(c, hipStreamWaitEvent(sA, placed, 0));                          // the extraction (main stream) reads the store
     HIPCHK(c, hsk_sync(c, sB));
-    ev_put(c, placed);
-    for (auto e : landed) ev_put(c, e);
-    for (auto e : scanned) ev_put(c, e);
     if (profile) { pp.keys = 0; c->ev_pending.push_back(pp); }
     if (staged) memcpy(tot.data(), h_tot, (size_t)nsl * ntasks * 24);
     bool fallback = *h_flags != 0;                                          // a tile with more supermers than the record capacity
