@@ -400,6 +400,24 @@ def main():
             kern("place_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 13.0, "hbm-scattered",
                  "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
         ]
+        if st.get("combine_launches"):
+            # the combining extraction ran (hsk_combine.h): no instance extraction, the scatter pass and the finish work on {k-mer, count} pairs.
+            # Per supermer item (16 bytes + 4 of minimizer bits): the placement reads its 4 + 4 bytes of records and ~2.4 bytes of packed bases and
+            # writes 20; the bucket order reads 4 (histogram), then 4 + 16 and writes 16.
+            kernels = [k_ for k_ in kernels if k_["kernel"] not in ("expand_scatter2_kernel", "expand_scatter_kernel", "place_kernel")]
+            items = st["bucket_items"]
+            kernels += [
+                kern("place_items_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 30.4, "hbm-scattered",
+                     "supermers (as 16-byte items: 64 bases + k-mer count, with 4 bytes of minimizer bits) to their virtual-task slots (16 virtual tasks per task: the top "
+                     "minimizer bits); bases read once from the packed reads staged in LDS; 8 bytes of records in, 20 out in runs of ~25 items"),
+                kern("bucket_scatter_kernel", st["bucket_ms"], st["bucket_launches"], items * 40.0, "hbm-scattered",
+                     "bucket order of the items inside a virtual task (histogram launch + scatter launch): 8192 items staged and ordered in LDS, every bucket's run written in one piece (~8 items = 128 bytes)",
+                     pmc_prefix="bucket_scatter_kernel"),
+                kern("combine_kernel", st["combine_ms"], st["combine_launches"], items * 16.0 + st["combine_pairs"] * 16.0, "lds-latency",
+                     "extraction + counting per minimizer bucket: reads the bucket's items (16 B per supermer), rolls the k-mers into a 2048-slot LDS hash table, writes the table's "
+                     "{k-mer, count} pairs into the digit bins of the first radix pass; bound by the LDS round trips of the inserts and the table dumps, not by HBM "
+                     "(%.1f k-mers per pair in this run)" % (st["combine_kmers"] / max(st["combine_pairs"], 1))),
+            ]
         kernels.sort(key=lambda d: -d["ms_per_step"])
         # The roofline block declares an HBM bound, so it names the time-dominant kernel AMONG THE HBM-BOUND ones; when a kernel with
         # another bound leads the list (the VALU-bound minimizer scan, since the extraction got faster in round 3) it is named beside
@@ -449,6 +467,9 @@ def main():
                                                          "algorithm's byte count, not bytes this build moves (2 passes + LDS aggregation, ~49 B per k-mer) and so not a roofline fraction; "
                                                          "variants[full_sort] runs that algorithm for real"}},
             "kernels": kernels,
+            "plan": ("combining extraction: supermers ordered by minimizer bucket, k-mers counted in LDS tables where they are extracted, %.1f k-mers per {k-mer, count} pair into one "
+                     "scatter pass + weighted LDS finish (hsk_combine.h; HSK_FLAG_NO_COMBINE / variants[instance_path]: every instance through two passes)" % (st["combine_kmers"] / max(st["combine_pairs"], 1)))
+                    if st.get("combine_launches") else "instance path: every k-mer instance through two radix passes + LDS aggregation",
             "host_syncs_per_step": st["host_syncs"] / S, "host_waits_covered_per_step": st["host_waits_covered"] / S,
             "path_stats": {k_: int(st[k_]) for k_ in ("fused_tasks", "redone_tasks", "agg_retried_tasks", "parse_fallbacks", "heavy_tasks") if k_ in st},
             "phases_ms_per_step": {k_: v / S for k_, v in sorted(phase.items())},
@@ -465,6 +486,8 @@ def main():
             legs = [
                 ("k51", "BASELINE configs[3]'s record shape (two-word keys) on the same reads", 51, 0, None, L, U, G, nreads, 0.0, 464.4),
                 ("ext", "BASELINE configs[4]'s record shape (EXTENSION=1: pos + rid carried through the sort and grouped per k-mer)", 31, 1, None, L, U, G, nreads, 0.0, 304.3),
+                ("instance_path", "the headline workload with HSK_FLAG_NO_COMBINE: every k-mer instance extracted and moved through two radix passes, then the LDS aggregation "
+                                  "(the default plan of rounds 1-2 and of every record shape the combining extraction does not take)", 31, 0, "no_combine", L, U, G, nreads, 0.0, 152.3),
                 ("no_aggregation", "the headline workload with HSK_FLAG_NO_AGGREGATION: four scatter passes on the top 32 bits + in-LDS tile finish", 31, 0, "no_aggregation", L, U, G, nreads, 0.0, 152.3),
                 ("full_sort", "the headline workload with HSK_FLAG_FULL_SORT = the algorithm north_star names: LSD radix sort over all 8 key bytes "
                               "(reference sort_task, src/kmerops.cpp:1383) + adjacent-equal merge-count (count_sorted_kmers, :1410)", 31, 0, "full_sort", L, U, G, nreads, 0.0, 152.3),

@@ -42,6 +42,8 @@ class Stats(C.Structure):
         ("scan_launches", C.c_uint64), ("scan_bytes", C.c_uint64), ("scan_ms", C.c_double),
         ("place_launches", C.c_uint64), ("place_supermers", C.c_uint64), ("place_ms", C.c_double),
         ("host_syncs", C.c_uint64), ("host_waits_covered", C.c_uint64), ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+        ("bucket_launches", C.c_uint64), ("bucket_items", C.c_uint64), ("bucket_ms", C.c_double),
+        ("combine_launches", C.c_uint64), ("combine_kmers", C.c_uint64), ("combine_pairs", C.c_uint64), ("combine_ms", C.c_double),
     ]
 
 
@@ -50,6 +52,7 @@ FLAG_KEEP_DEVICE = 2
 FLAG_PLAIN_CLASSIFIER = 4
 FLAG_NO_AGGREGATION = 8
 FLAG_FULL_SORT = 16
+FLAG_NO_COMBINE = 32
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/hsk.h declares (tests/test_abi.py checks the library exports all of them)

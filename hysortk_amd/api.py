@@ -245,7 +245,7 @@ class Context:
         cfg.kmer_size, cfg.minimizer_size, cfg.lower_freq, cfg.upper_freq = K, M, L, U
         cfg.extension, cfg.ntasks, cfg.device, cfg.plain_dispatcher, cfg.radix_bits = EXT, ntasks, device, plain_dispatcher, radix_bits
         cfg.flags = (_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_KEEP_DEVICE if keep_device else 0) | \
-            {None: 0, "no_aggregation": _lib.FLAG_NO_AGGREGATION, "full_sort": _lib.FLAG_FULL_SORT}[plan]
+            {None: 0, "no_aggregation": _lib.FLAG_NO_AGGREGATION, "full_sort": _lib.FLAG_FULL_SORT, "no_combine": _lib.FLAG_NO_COMBINE}[plan]
         self.keep_device = bool(keep_device)
         self.cfg = cfg
         self.K, self.EXT = K, EXT

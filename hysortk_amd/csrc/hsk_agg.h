@@ -47,6 +47,7 @@ enum { AG_FLAG_OVERFLOW = 1 };
 
 struct AggTask {
     const u64 *keys; u64 n;        // sorted on the top AG_PREFIX_BITS bits
+    const u64 *vals;               // weighted finish (agg_finish_kernel<cap, true>, hsk_combine.h): record i stands for vals[i] instances of its key (null: one)
     u64 *bounds;                   // [nbins + 1] first record of every prefix bin (bin_bounds_kernel)
     u64 *scratch; u32 slot_shift;  // bin b writes entry e {key, count} to scratch[((bounds[b] >> slot_shift) + e) * 2 ..]
     u32 active;
@@ -116,12 +117,12 @@ __device__ __forceinline__ u32 agg_slot(u64 k)
 // if / break structure, this loop 6 (9 when a slot is claimed, 4 more per further probe).
 //   key_base / cnt_base: LDS byte addresses of the key and count arrays; h: first slot (CAP = MASK + 1 slots)
 template <u32 MASK>
-__device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_base, u32 &h, u64 k)
+__device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_base, u32 &h, u64 k, u32 inc = 1u)      // inc: what the key's counter grows by (1: an instance; a pair's count in the weighted finish)
 {
     u64 save, t, cur;
     u32 ka, ca, p;
     const u64 empty = AG_EMPTY;
-    const u32 one = 1u;
+    const u32 one = inc;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "s_movk_i32 %[p], %[maxp]\n\t"
@@ -279,7 +280,8 @@ __device__ unsigned long long g_agg_diag[16];
 #define AG_STAMP(i) do { } while (0)
 #endif
 
-template <int LOG2CAP>
+// W: the records are {key, count} pairs (AggTask::vals) and a key's counter grows by the pair's count
+template <int LOG2CAP, bool W = false>
 __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
 {
 #ifdef HSK_DIAG
@@ -314,14 +316,17 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     typedef __attribute__((address_space(3))) void *LdsPtr;
     const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_key, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;     // LDS byte addresses of the two arrays
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * AG_UNROLL) {
-        u64 k[AG_UNROLL];
+        u64 k[AG_UNROLL]; u32 wv[W ? AG_UNROLL : 1];
 #pragma unroll
-        for (int u = 0; u < AG_UNROLL; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY; }
+        for (int u = 0; u < AG_UNROLL; ++u) {
+            const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? t.keys[idx] : AG_EMPTY;
+            if (W) wv[u] = idx < e ? (u32)t.vals[idx] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
             const u64 act = __ballot(k[u] != AG_EMPTY);
             u32 h = agg_slot<LOG2CAP>(k[u]);
-            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u]) != 0) s_ovf = 1;      // (uniform)
+            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u], W ? wv[u] : 1u) != 0) s_ovf = 1;      // (uniform)
         }
         // a bin with more distinct keys than the table takes (a probe sequence ran past AG_MAX_PROBE slots: with linear probing
         // that starts at a load of ~0.8) gives up here instead of grinding through the rest of its records

@@ -34,6 +34,7 @@
 #include "hsk_count.h"
 #include "hsk_finish.h"
 #include "hsk_agg.h"
+#include "hsk_combine.h"
 #include "hsk_heavy.h"
 #include "hsk_synth.h"
 #include "hsk_plan.h"
@@ -191,6 +192,8 @@ static void drain_profile_events(hsk_ctx *c)
             else if (p.kind == 4) { c->stats.place_launches++; c->stats.place_supermers += p.keys; c->stats.place_ms += f; }
             else if (p.kind == 5) { c->stats.h2d_ms += f; }
             else if (p.kind == 6) { c->stats.d2h_ms += f; }
+            else if (p.kind == 7) { c->stats.combine_launches++; c->stats.combine_kmers += p.keys; c->stats.combine_ms += f; }
+            else if (p.kind == 8) { c->stats.bucket_launches += 2; c->stats.bucket_items += p.keys; c->stats.bucket_ms += f; }
             else { c->stats.hist_launches++; c->stats.hist_bytes += p.bytes; c->stats.hist_ms += f; }
         }
         ev_put(c, p.a); ev_put(c, p.b);
@@ -212,6 +215,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 #include "hsk_host_expand.h"
 #include "hsk_host_sort.h"
 #include "hsk_host_scatter.h"
+#include "hsk_host_combine.h"
 #include "hsk_host_finish.h"
 #include "hsk_host_pipeline.h"
 
@@ -225,12 +229,18 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
     case 2: rc = run_pipeline<2>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     default: rc = run_pipeline<3>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     }
+    c->vt_shift = 0;
     if (rc != HSK_OK) {
         // the failed call's kernels are drained, its result is dropped, and every device block it still holds goes back to the pool
         (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream);
         hsk_result_free(c, out);
         c->pool.release_all_but(before);
         (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+    }
+    if (rc == HSK_RETRY_PLAN) {
+        // the combining extraction gave up (hsk_ctx::combine_off is set): once more, from the reads in HBM, on the instance path
+        c->stats.redone_tasks++;
+        return dispatch_pipeline(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out);
     }
     return rc;
 }

@@ -1,0 +1,354 @@
+// hsk_combine.h -- the combining extraction: k-mers are counted where they are born, per MINIMIZER BUCKET, and only the distinct
+// {k-mer, count} pairs of a bucket enter the radix passes (one-word keys, no payload, one GPU).
+//
+// The reference extracts every k-mer instance of a task, sorts all of them and counts runs (src/kmerops.cpp:1382-1445); so does the
+// path of hsk_scatter.h + hsk_sort.h + hsk_agg.h, which writes every instance to HBM once and moves it once before the LDS tables of
+// the finish see it (4 x 8 bytes of HBM traffic per instance).  Sequencing data repeats every k-mer ~coverage times, and all instances
+// of a canonical k-mer share its minimizer: the supermers that carry them meet in the same (task, minimizer) bucket long before anything
+// is sorted.  So:
+//   1. scan_kernel hands out 32 mixed bits of every supermer's minimizer hash (ParseArgs::tile_sub), place_kernel carries them to the
+//      supermer's slot (sm_sub);
+//   2. bucket_hist / bucket_scan / bucket_scatter order a task's supermer RECORDS (8 bytes each: position | length << 56, one per
+//      ~8 k-mers) by the top bits of those 32: buckets of ~12 k k-mers;
+//   3. combine_kernel: a workgroup takes a bucket, rolls the k-mers of its supermers straight into an LDS hash table (the probe loop of
+//      the finish, agg_count_keys) and then writes the table's {key, count} pairs into the chunk store of the first radix pass exactly
+//      as expand_scatter2_kernel writes keys (cursor / map / chunk protocol of hsk_scatter.h), the counts into the payload chunks;
+//      a table that fills up in the middle of a bucket is written out and started again, so a key may leave a bucket in several
+//      partial pairs: nothing downstream assumes otherwise;
+//   4. the second radix pass carries the counts as the payload (onesweep_multi_kernel<1, true>), and the finish adds them up instead
+//      of counting records (agg_finish_kernel<cap, true>): same bins, same order, same filter, same list.
+// At ~32 instances per k-mer the passes and the finish then move 1/32 of the records; what remains per instance is the roll and one
+// LDS insert.  With (nearly) unique k-mers the pairs are as many as the instances and 16 instead of 8 bytes each: the host watches the
+// ratio and goes back to the instance path (hsk_ctx::combine_off).
+#pragma once
+#include "hsk_scatter.h"
+#include "hsk_agg.h"
+
+namespace hsk {
+
+// ---- 2. bucket order of the supermer items -------------------------------------------------------------------------------------
+// The parse has already split every task by the top vt_shift minimizer bits ("virtual tasks", ParseArgs::vt_shift: the placement's
+// counting sort takes 16 x as many bins in its stride); what is left is at most 10 bits per virtual task.  A workgroup stages 8192
+// items in LDS, orders them by those bits there and writes every bucket's run (8 items = 128 bytes on average) in one piece.
+constexpr int CS_THREADS = 1024;
+constexpr int CS_IPT = 8;
+constexpr u32 CS_TILE = CS_THREADS * CS_IPT;         // items staged per step
+constexpr int CS_MAX_LOCAL = 10;                     // bucket bits inside a virtual task at most (one lane per bucket)
+constexpr int CS_MAX_LOG2NB = 14;                    // buckets per task at most
+constexpr u32 CS_ITEM = 1u << 17;                    // items per workgroup at most
+
+struct BucketItem { u64 first; u32 n; u16 task; u16 hi; };   // supermer slots [first, first + n): task `task`, top minimizer bits `hi` (virtual task)
+struct BucketSortArgs {
+    const BucketItem *items;
+    const u32 *sm_sub; const ulonglong2 *sm_item;
+    u32 *off;                  // [ntasks][stride]: counts, then (bucket_scan_kernel) exclusive offsets with the total behind the last bucket
+    u32 *cur;                  // [ntasks][stride]: running cursors of the scatter
+    const u32 *log2nb;         // [ntasks] buckets of every task (log2)
+    const u64 *out_base;       // [ntasks] first item of every task in `recs`
+    u32 stride;
+    u32 vt_shift;              // minimizer bits the virtual tasks have consumed
+    ulonglong2 *recs;          // out: the items, tasks back to back, buckets ascending inside a task
+};
+// bucket of an item inside its task = top lg bits of sub = {virtual task bits, local bits}
+struct BucketMap { u32 lg, lgl, gbase; };
+__device__ __forceinline__ BucketMap bucket_map(const BucketSortArgs &a, const BucketItem &it)
+{
+    BucketMap m; m.lg = a.log2nb[it.task];
+    m.lgl = m.lg > a.vt_shift ? m.lg - a.vt_shift : 0u;
+    m.gbase = m.lg >= a.vt_shift ? ((u32)it.hi << m.lgl) : ((u32)it.hi >> (a.vt_shift - m.lg));
+    return m;
+}
+__device__ __forceinline__ u32 bucket_local(u32 sub, const BucketMap &m) { return m.lgl ? (sub >> (32 - m.lg)) & ((1u << m.lgl) - 1u) : 0u; }
+
+__global__ __launch_bounds__(CS_THREADS) void bucket_hist_kernel(BucketSortArgs a)
+{
+    __shared__ u32 s_h[1 << CS_MAX_LOCAL];
+    const BucketItem it = a.items[blockIdx.x];
+    const BucketMap m = bucket_map(a, it);
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 *sub = a.sm_sub + it.first;
+    for (u32 i0 = threadIdx.x; i0 < it.n; i0 += CS_THREADS * 4) {
+        u32 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * CS_THREADS; v[u] = i < it.n ? sub[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * CS_THREADS < it.n) atomicAdd(&s_h[bucket_local(v[u], m)], 1u);
+    }
+    __syncthreads();
+    const u32 c = s_h[threadIdx.x];
+    if (c) atomicAdd(&a.off[(u64)it.task * a.stride + m.gbase + threadIdx.x], c);
+}
+
+// one workgroup per task: counts -> exclusive offsets (in place, total behind the last bucket) and the scatter's cursors
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(BucketSortArgs a)
+{
+    __shared__ u32 s_w[16];
+    const u32 t = blockIdx.x, nb = 1u << a.log2nb[t];
+    u32 *g = a.off + (u64)t * a.stride, *cu = a.cur + (u64)t * a.stride;
+    const u32 per = (nb + 1023u) / 1024u;
+    const u32 lo = threadIdx.x * per;
+    u32 sum = 0;
+    for (u32 i = lo; i < lo + per && i < nb; ++i) sum += g[i];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(sum);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) { const u32 s = s_w[i]; if (i < w) base += s; tot += s; }
+    u32 run = base + inc - sum;
+    for (u32 i = lo; i < lo + per && i < nb; ++i) { const u32 c = g[i]; g[i] = run; cu[i] = run; run += c; }
+    if (threadIdx.x == 0) g[nb] = tot;
+}
+
+__global__ __launch_bounds__(CS_THREADS) void bucket_scatter_kernel(BucketSortArgs a)
+{
+    __shared__ ulonglong2 s_it[CS_TILE];               // 128 KB: the step's items in bucket order
+    __shared__ unsigned short s_bk[CS_TILE];           // their buckets
+    __shared__ u32 s_cnt[1 << CS_MAX_LOCAL], s_start[1 << CS_MAX_LOCAL], s_gb[1 << CS_MAX_LOCAL];
+    __shared__ u32 s_w[16];
+    const int tid = threadIdx.x;
+    const BucketItem it = a.items[blockIdx.x];
+    const BucketMap m = bucket_map(a, it);
+    const u32 *sub = a.sm_sub + it.first;
+    const ulonglong2 *src = a.sm_item + it.first;
+    ulonglong2 *out = a.recs + a.out_base[it.task];
+    u32 *cu = a.cur + (u64)it.task * a.stride + m.gbase;
+    const int lane = lane_id(), w = tid >> 6;
+    for (u32 t0 = 0; t0 < it.n; t0 += CS_TILE) {
+        const u32 nt = it.n - t0 < CS_TILE ? it.n - t0 : CS_TILE;
+        s_cnt[tid] = 0;
+        __syncthreads();                                  // (also: the previous step's output loop is done with the stage)
+        ulonglong2 x[CS_IPT]; u32 bk[CS_IPT], rk[CS_IPT];
+#pragma unroll
+        for (int u = 0; u < CS_IPT; ++u) {
+            const u32 i = (u32)u * CS_THREADS + (u32)tid;
+            const bool ok = i < nt;
+            x[u] = ok ? src[t0 + i] : make_ulonglong2(0, 0);
+            bk[u] = ok ? bucket_local(sub[t0 + i], m) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < CS_IPT; ++u) rk[u] = bk[u] != 0xFFFFFFFFu ? atomicAdd(&s_cnt[bk[u]], 1u) : 0u;
+        __syncthreads();
+        {
+            const u32 c = s_cnt[tid];
+            const u32 inc = wave_incl_scan(c);
+            if (lane == WAVE - 1) s_w[w] = inc;
+            __syncthreads();
+            u32 base = 0;
+            for (int i = 0; i < 16; ++i) if (i < w) base += s_w[i];
+            const u32 st = base + inc - c;
+            s_start[tid] = st;
+            s_gb[tid] = (c ? atomicAdd(&cu[tid], c) : 0u) - st;      // (mod 2^32: global slot = s_gb + position in the stage)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CS_IPT; ++u) {
+            if (bk[u] == 0xFFFFFFFFu) continue;
+            const u32 p = s_start[bk[u]] + rk[u];
+            s_it[p] = x[u]; s_bk[p] = (unsigned short)bk[u];
+        }
+        __syncthreads();
+        for (u32 i = tid; i < nt; i += CS_THREADS) out[s_gb[s_bk[i]] + i] = s_it[i];
+    }
+}
+
+// ---- 3. the combining extraction -------------------------------------------------------------------------------------------------
+constexpr int CB_THREADS = 256;
+constexpr int CB_WAVES = CB_THREADS / WAVE;
+#ifndef CB_LOG2CAP
+#define CB_LOG2CAP 11
+#endif
+constexpr int CB_CAP = 1 << CB_LOG2CAP;
+constexpr int CB_PER = CB_CAP / CB_THREADS;
+#ifndef CB_GROUP
+#define CB_GROUP 8
+#endif
+static_assert(CB_THREADS == 256, "one lane per digit in the table dump");
+static_assert(CB_CAP <= (XS_SPAN - 1) * XsCfg<1>::CHUNK, "a dump's reservation touches at most XS_SPAN chunks of a digit");
+
+struct CombineTask {
+    const ulonglong2 *recs;    // the task's items in bucket order (place_items_kernel's two words)
+    const u32 *boff;           // [nb + 1] first item of every bucket
+    u32 nb;                    // buckets (0: no task on this XCD)
+    u32 vmax;
+    u64 *chunks, *vchunks;     // chunk stores of the keys and of the counts (same slots)
+    u64 *cursor; u32 *map; u32 *ctl; u64 *ghist;       // as ScatterTask; ctl[0]: bucket ticket
+};
+struct CombineArgs { CombineTask t[8]; int k, shift0, bits0, shift1; u32 *err; };      // first-pass digit: bits0 (<= 8) bits at shift0, second-pass digit: 8 bits at shift1 (both >= 32)
+
+template <int KT = 0>
+__global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a)
+{
+    constexpr int CHUNK = XsCfg<1>::CHUNK;
+    __shared__ __attribute__((aligned(16))) u64 s_key[CB_CAP];
+    __shared__ u32 s_val[CB_CAP];
+    __shared__ u32 s_cnt[256], s_hist[256];
+    __shared__ uint4 s_dl[256];
+    __shared__ u32 s_scr[CB_WAVES];
+    __shared__ u32 s_flag[4];                          // [0] bucket ticket, [1 + round % 3] a lane ran out of probes in that round
+    typedef __attribute__((address_space(1))) u32 G32;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const int tid = threadIdx.x;
+    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
+    const CombineTask &t = a.t[xcc];
+    if (t.nb == 0) return;
+    const int k = KT ? KT : a.k;
+    const int low = 64 - 2 * k;
+    const u64 lastmask = ~0ULL << low;
+    const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u, dm0 = (1u << a.bits0) - 1u;
+    const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_key, val_lds = (u32)(uintptr_t)(LdsPtr)s_val;
+    const int lane = lane_id();
+#pragma unroll
+    for (int j = 0; j < CB_PER; ++j) { s_key[j * CB_THREADS + tid] = AG_EMPTY; s_val[j * CB_THREADS + tid] = 0; }
+    s_cnt[tid] = 0; s_hist[tid] = 0;
+    if (tid == 0) { s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; }
+    u32 round = 0;                                     // insert rounds of this workgroup (the same in every wave)
+
+    // The table's pairs leave for the chunk store of the first radix pass: digits counted, one reservation per digit (cursor, chunk map:
+    // the protocol of expand_scatter2_kernel), every pair straight to its slot, the table empty again.  Called by the whole workgroup
+    // behind a barrier (all inserts done); s_cnt is zero on entry and on exit.
+    auto dump = [&]() {
+        u64 mk[CB_PER]; u32 mv[CB_PER];
+#pragma unroll
+        for (int j = 0; j < CB_PER; ++j) {
+            mk[j] = s_key[j * CB_THREADS + tid]; mv[j] = s_val[j * CB_THREADS + tid];
+            if (mk[j] != AG_EMPTY) atomicAdd(&s_cnt[((u32)(mk[j] >> 32) >> sh0) & dm0], 1u);
+        }
+        xs_barrier();
+        const u32 c = s_cnt[tid];
+        u32 tot;
+        const u32 st = block_excl_scan_xs<CB_WAVES>(c, s_scr, &tot);
+        if (tot) {
+            s_cnt[tid] = st;                                        // from a count to the running cursor of the digit's range
+            if (c) {
+                const u64 p = __hip_atomic_fetch_add(&t.cursor[tid], (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u64 v0 = p / CHUNK;
+                const u32 off0 = (u32)(p % CHUNK);
+                const u32 nv = (off0 + c - 1) / CHUNK + 1;
+                G32 *mp = (G32 *)(t.map + (u64)tid * t.vmax);
+                u32 ph[XS_SPAN] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < XS_SPAN; ++q) {
+                    if ((u32)q >= nv || (q == 0 && off0 != 0)) continue;
+                    ph[q] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    __hip_atomic_store(mp + v0 + q, ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (off0 != 0) {
+                    u32 spins = 0;
+                    while ((ph[0] = __hip_atomic_load(mp + v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                        if (++spins > XS_SPIN_LIMIT) { atomicOr(a.err, 2u); ph[0] = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const u32 split = st + ((u32)CHUNK - off0);
+                s_dl[tid] = make_uint4(split, (ph[0] - 1) * (u32)CHUNK + off0 - st, ((ph[1] ? ph[1] : 1u) - 1) * (u32)CHUNK - split,
+                                       ((ph[2] ? ph[2] : 1u) - 1) * (u32)CHUNK - (split + (u32)CHUNK));
+            }
+            xs_barrier();
+#pragma unroll
+            for (int j = 0; j < CB_PER; ++j) {
+                if (mk[j] == AG_EMPTY) continue;
+                const u32 hi = (u32)(mk[j] >> 32);
+                const u32 d = (hi >> sh0) & dm0;
+                const u32 i = atomicAdd(&s_cnt[d], 1u);
+                const uint4 dl = s_dl[d];
+                const u32 o = i + (i < dl.x ? dl.y : (i < dl.x + (u32)CHUNK ? dl.z : dl.w));   // (mod 2^32)
+                t.chunks[o] = mk[j]; t.vchunks[o] = (u64)mv[j];
+                atomicAdd(&s_hist[(hi >> sh1) & 255u], 1u);
+                s_key[j * CB_THREADS + tid] = AG_EMPTY; s_val[j * CB_THREADS + tid] = 0;
+            }
+            xs_barrier();
+            s_cnt[tid] = 0;
+        }
+        xs_barrier();
+    };
+
+    for (;;) {
+        xs_barrier();                                                 // (table cleared / previous bucket dumped; the ticket word is free)
+        if (tid == 0) s_flag[0] = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        xs_barrier();
+        const u32 b = s_flag[0];
+        if (b >= t.nb) break;
+        const u32 r0 = t.boff[b], r1 = t.boff[b + 1];
+        ulonglong2 nxt = make_ulonglong2(0, 0);
+        if (r0 + (u32)tid < r1) nxt = t.recs[r0 + (u32)tid];
+        for (u32 base = r0; base < r1; base += CB_THREADS) {
+            // ---- this lane's item: a supermer of up to 16 k-mers (the next tile's is asked for before this one is worked on) ----
+            const ulonglong2 itm = nxt;
+            { const u32 s2 = base + CB_THREADS + (u32)tid; nxt = s2 < r1 ? t.recs[s2] : make_ulonglong2(0, 0); }
+            const u64 win0 = itm.x, win1 = itm.y & ~0xFFULL;
+            u32 cnt = (u32)(itm.y & 0xFFULL);
+            if (cnt > 16u) { atomicOr(a.err, 4u); cnt = 0; }
+            // ---- its k-mers into the table.  A key's home is an aligned PAIR of slots.  First sweep: the homes of CB_GROUP k-mers are read
+            //      together (one 16-byte LDS read each, one latency for the group); a k-mer that finds itself there -- at c-fold coverage
+            //      all but one in c, minus the few whose key was pushed past its home -- just adds one.  The others are remembered as a bit
+            //      mask and take the probe loop afterwards, every lane its next one per round: two or three rounds per tile instead of
+            //      one probe loop per k-mer.  A lane whose probes run out keeps its remaining bits, the table is written out behind the
+            //      round's barrier and the lanes go on (every such round starts on an empty table: it ends) ----
+            u32 mm = cnt ? (0xFFFFu >> (16u - cnt)) : 0u;
+            {
+                Mer<1> fw, rc;
+                fw.w[0] = win0 & lastmask;
+                rc = twin<1>(fw, k);
+#pragma unroll 1
+                for (int q0 = 0; q0 < 16; q0 += CB_GROUP) {
+                    if (__ballot((u32)q0 < cnt) == 0) break;
+                    u64 key[CB_GROUP]; u32 h[CB_GROUP]; ulonglong2 cur[CB_GROUP];
+#pragma unroll
+                    for (int q = 0; q < CB_GROUP; ++q) {
+                        const int r = q0 + q;
+                        if (r > 0) {
+                            fw.w[0] = funnel_left(win0, win1, 2 * r) & lastmask;
+                            const u64 nbase = (fw.w[0] >> low) & 3;
+                            rc.w[0] = ((rc.w[0] >> 2) | ((3 - nbase) << 62)) & lastmask;
+                        }
+                        key[q] = rc.w[0] < fw.w[0] ? rc.w[0] : fw.w[0];
+                        h[q] = agg_slot<CB_LOG2CAP>(key[q]) & ~1u;
+                        cur[q] = *reinterpret_cast<const ulonglong2 *>(&s_key[h[q]]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < CB_GROUP; ++q) {
+                        const u32 r = (u32)(q0 + q);
+                        if (r < cnt) {
+                            if (cur[q].x == key[q]) { atomicAdd(&s_val[h[q]], 1u); mm &= ~(1u << r); }
+                            else if (cur[q].y == key[q]) { atomicAdd(&s_val[h[q] + 1u], 1u); mm &= ~(1u << r); }
+                        }
+                    }
+                }
+            }
+            for (;;) {
+                bool stuck = false;
+                for (;;) {
+                    const bool mine = mm != 0 && !stuck;
+                    const u64 act = __ballot(mine);
+                    if (act == 0) break;
+                    const u32 r = mine ? (u32)__builtin_ctz(mm) : 0u;
+                    Mer<1> fw, rc;
+                    fw.w[0] = (r ? funnel_left(win0, win1, 2 * (int)r) : win0) & lastmask;
+                    rc = twin<1>(fw, k);
+                    const u64 key = rc.w[0] < fw.w[0] ? rc.w[0] : fw.w[0];
+                    u32 h = agg_slot<CB_LOG2CAP>(key) & ~1u;
+                    const u64 left = agg_count_keys<(u32)CB_CAP - 1u>(act, key_lds, val_lds, h, key, 1u);
+                    if (mine) { if ((left >> lane) & 1ULL) stuck = true; else mm &= mm - 1u; }
+                }
+                // one barrier per round: the round's flag is one of three taken in turn; the next round's is cleared before the barrier (its
+                // last readers read it two rounds ago, i.e. before they arrived at the previous round's barrier)
+                const u32 fl = 1u + round % 3u;
+                if (tid == 0) s_flag[1u + (round + 1u) % 3u] = 0;
+                if (mm) s_flag[fl] = 1;
+                ++round;
+                xs_barrier();
+                if (s_flag[fl] == 0) break;
+                dump();
+            }
+        }
+        dump();
+    }
+    {
+        const u32 cv = s_hist[tid];
+        if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
+    }
+}
+
+} // namespace hsk

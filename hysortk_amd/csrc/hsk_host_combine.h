@@ -1,0 +1,145 @@
+// hsk_host_combine.h -- host side of the combining extraction (kernels: hsk_combine.h).
+// Part of the single translation unit hsk_api.hip (included in this order; everything here is file-local).
+#pragma once
+
+// HSK_COMBINE=0: the instance path (expand_scatter2_kernel ...) always
+static bool combine_enabled()
+{
+    static const bool on = !(getenv("HSK_COMBINE") && atoi(getenv("HSK_COMBINE")) == 0);
+    return on && !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT | HSK_FLAG_NO_COMBINE));
+}
+// k-mers per bucket the bucket order aims at (a table of CB_CAP slots takes the ~400 distinct k-mers of such a bucket at 32x coverage
+// with room to spare, and still most of them at 5x)
+// bins of the weighted finish: the top combine_prefix_bits() key bits (8 < bits <= 16).  A bin of the instance path's 16 bits would hold
+// ~120 pairs at 32x coverage and its workgroup would mostly wait for its own start-up; 14 bits: ~480 pairs on the 2048-slot table
+static int combine_prefix_bits()
+{
+    static const int v = getenv("HSK_COMBINE_PREFIX") ? std::min(16, std::max(9, atoi(getenv("HSK_COMBINE_PREFIX")))) : 14;
+    return v;
+}
+static u64 combine_bucket_kmers()
+{
+    static const u64 v = getenv("HSK_COMBINE_BUCKET") ? (u64)std::max(256, atoi(getenv("HSK_COMBINE_BUCKET"))) : 12288;
+    return v;
+}
+
+// the supermer items of the owned tasks in bucket order
+struct BucketOrder {
+    ulonglong2 *recs = nullptr; u32 *off = nullptr, *cur = nullptr, *d_log2nb = nullptr; u64 *d_out_base = nullptr; BucketItem *d_items = nullptr;
+    u32 stride = 0;
+    std::vector<u32> log2nb; std::vector<u64> out_base;
+    bool active = false;
+};
+static void bucket_release(hsk_ctx *c, BucketOrder &bo)
+{
+    c->pool.release(bo.recs); c->pool.release(bo.off); c->pool.release(bo.cur); c->pool.release(bo.d_log2nb); c->pool.release(bo.d_out_base); c->pool.release(bo.d_items);
+    bo = BucketOrder();
+}
+
+// tasks: the owned tasks (EMPTY entries ~0u skipped).  Returns HSK_OK with bo.active = false when a task does not fit 32-bit record offsets.
+static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs> &segs, const std::vector<u32> &tasks, const BaseSource &src, u32 vt_shift, BucketOrder &bo)
+{
+    bo = BucketOrder();
+    bo.log2nb.assign(ntasks, 0); bo.out_base.assign(ntasks, 0);
+    std::vector<BucketItem> items;
+    u64 run = 0; u32 maxlg = 0;
+    const u64 target = combine_bucket_kmers();
+    for (u32 t : tasks) {
+        if (t == ~0u) continue;
+        u64 nsup = 0;
+        for (const ExpSeg &sg : segs[t].segs) {
+            for (u64 o = 0; o < sg.n_sup; o += CS_ITEM) { BucketItem it; it.first = sg.sup_off + o; it.n = (u32)std::min<u64>(CS_ITEM, sg.n_sup - o); it.task = (u16)t; it.hi = (u16)sg.byte_off; items.push_back(it); }
+            nsup += sg.n_sup;
+        }
+        if (nsup >= (1ULL << 32)) return HSK_OK;
+        u32 lg = 0;
+        while (lg < (u32)CS_MAX_LOG2NB && lg < (u32)CS_MAX_LOCAL + vt_shift && (segs[t].nkmers >> lg) > target) ++lg;
+        bo.log2nb[t] = lg; maxlg = std::max(maxlg, lg);
+        bo.out_base[t] = run; run += nsup;
+    }
+    if (items.empty()) return HSK_OK;
+    bo.stride = (1u << maxlg) + 1;
+    DALLOC(c, bo.recs, ulonglong2 *, run * 16 + 64);
+    DALLOC(c, bo.off, u32 *, (size_t)ntasks * bo.stride * 4);
+    DALLOC(c, bo.cur, u32 *, (size_t)ntasks * bo.stride * 4);
+    DALLOC(c, bo.d_log2nb, u32 *, (size_t)ntasks * 4);
+    DALLOC(c, bo.d_out_base, u64 *, (size_t)ntasks * 8);
+    DALLOC(c, bo.d_items, BucketItem *, items.size() * sizeof(BucketItem));
+    HIPCHK(c, hipMemsetAsync(bo.off, 0, (size_t)ntasks * bo.stride * 4, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bo.d_log2nb, bo.log2nb.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bo.d_out_base, bo.out_base.data(), (size_t)ntasks * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bo.d_items, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));                  // (the item list is host memory of this function)
+    BucketSortArgs a; memset(&a, 0, sizeof a);
+    a.items = bo.d_items; a.sm_sub = src.sub; a.sm_item = reinterpret_cast<const ulonglong2 *>(src.item); a.off = bo.off; a.cur = bo.cur; a.log2nb = bo.d_log2nb; a.out_base = bo.d_out_base;
+    a.stride = bo.stride; a.recs = bo.recs; a.vt_shift = vt_shift;
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 8; ep.keys = run; (void)hipEventRecord(ep.a, c->stream); }
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3((u32)items.size()), dim3(CS_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(ntasks), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((u32)items.size()), dim3(CS_THREADS), 0, c->stream, a);
+    if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
+    HIPCHK(c, hipGetLastError());
+    bo.active = true;
+    return HSK_OK;
+}
+
+// The batch's tasks (tk[i]: task of XCD i, ~0u: none) from bucket-ordered records to {k-mer, count} pairs in the chunk stores bt[i].kB
+// (keys) / bt[i].vB (counts); the histogram of the second pass's digit goes to ghist[i] + 256.  What follows is sort_batch_prescattered
+// with the counts as payload; sb.h_nout[i] then holds the pairs of task i (read after the stream has passed chunk_tiles_kernel).
+static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *const *ghist, const PassDesc *plan, const BucketOrder &bo,
+                         u64 *h_nout, ScatterBatch &sb, hipStream_t stream)
+{
+    constexpr int CH = XsCfg<1>::CHUNK;
+    const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
+    sb = ScatterBatch();
+    ScatterArgs &a = sb.args; memset(&a, 0, sizeof a);
+    CombineArgs ca; memset(&ca, 0, sizeof ca);
+    bool any = false;
+    for (int i = 0; i < XCD_BATCH; ++i) if (tk[i] != ~0u && bt[i].n) any = true;
+    if (!any) return HSK_OK;
+    DALLOC(c, sb.d_cursor, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    DALLOC(c, sb.d_ctl, u32 *, (size_t)XCD_BATCH * 16);
+    DALLOC(c, sb.d_gbase, u64 *, (size_t)XCD_BATCH * 256 * 8);
+    DALLOC(c, sb.d_ntiles, u32 *, 256);
+    DALLOC(c, sb.d_nout, u64 *, 256);
+    sb.h_nout = h_nout;
+    HIPCHK(c, hipMemsetAsync(sb.d_ntiles, 0, 64, stream));
+    HIPCHK(c, hipMemsetAsync(sb.d_nout, 0, 64, stream));
+    HIPCHK(c, hipMemsetAsync(sb.d_cursor, 0, (size_t)XCD_BATCH * 256 * 8, stream));
+    HIPCHK(c, hipMemsetAsync(sb.d_ctl, 0, (size_t)XCD_BATCH * 16, stream));
+    u64 ntot = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        if (tk[i] == ~0u || !bt[i].n) continue;
+        const u32 tid = tk[i];
+        const u64 n = bt[i].n;                           // k-mers of the task: never fewer than its pairs
+        ScatterTask &t = a.t[i];
+        t.vmax = (u32)(n / CH + 1);
+        DALLOC(c, sb.d_map[i], u32 *, (size_t)256 * t.vmax * 4);
+        DALLOC(c, sb.d_tile_src[i], u64 *, (size_t)(n / CH + 257) * 8);
+        HIPCHK(c, hipMemsetAsync(sb.d_map[i], 0, (size_t)256 * t.vmax * 4, stream));
+        t.ntiles = 1;                                    // (chunk_tiles_kernel: the XCD has a task)
+        t.chunks = bt[i].kB; t.vchunks = bt[i].vB; t.cursor = sb.d_cursor + (size_t)i * 256; t.map = sb.d_map[i]; t.ctl = sb.d_ctl + (size_t)i * 4;
+        t.ghist = ghist[i] + 256; t.tile_src = sb.d_tile_src[i];
+        t.n = ~0ULL; t.n_out = sb.d_nout + i; t.gbase = sb.d_gbase + (size_t)i * 256; t.ntiles_out = sb.d_ntiles + i;
+        CombineTask &q = ca.t[i];
+        q.recs = bo.recs + bo.out_base[tid]; q.boff = bo.off + (size_t)tid * bo.stride; q.nb = 1u << bo.log2nb[tid]; q.vmax = t.vmax;
+        q.chunks = t.chunks; q.vchunks = t.vchunks; q.cursor = t.cursor; q.map = t.map; q.ctl = t.ctl; q.ghist = t.ghist;
+        ntot += n;
+    }
+    a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.chunk = CH; a.err = c->d_err;
+    ca.k = a.k; ca.shift0 = a.shift0; ca.bits0 = plan[0].bits; ca.shift1 = a.shift1; ca.err = c->d_err;
+    static int occ = 0;
+    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, combine_kernel<31>, CB_THREADS, 0) == hipSuccess && nb > 0) ? nb : 2; }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 7; ep.keys = ntot; ep.bytes = 0; (void)hipEventRecord(ep.a, stream); }
+    const u32 grid = (u32)occ * 256u;
+    if (a.k == 31) hipLaunchKernelGGL((combine_kernel<31>), dim3(grid), dim3(CB_THREADS), 0, stream, ca);
+    else hipLaunchKernelGGL((combine_kernel<0>), dim3(grid), dim3(CB_THREADS), 0, stream, ca);
+    if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
+    // the tile lists of the second pass and the pairs of every task (the host sizes the second pass and the finish from them)
+    hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, stream, sb.args);
+    HIPCHK(c, hipMemcpyAsync(sb.h_nout, sb.d_nout, XCD_BATCH * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipGetLastError());
+    sb.active = true; sb.tiles_done = true;
+    return HSK_OK;
+}

@@ -141,6 +141,11 @@ struct hsk_ctx {
     bool agg_off_wide = false;         // the same for multi-word keys and EXTENSION: no prefix passes + tables, the full-width passes and the two-pass counter
     bool agg_off = false;              // one-word keys without payload: the input has too few copies per k-mer for the LDS aggregation (most bins of a
                                        // batch overflowed the 2048-slot table): batches take four prefix passes + the tile finish from here on
+    // combining extraction (hsk_combine.h): combine_now = this call lays the store out for it (one GPU, one-word keys, no payload);
+    // combine_off = the input kept too many pairs per k-mer (or a bin beat the weighted finish): the instance path until another look
+    bool combine_now = false, combine_off = false; int combine_off_calls = 0;
+    u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)
+    bool combine_veto = false;         // this call's store turned out to be no use to the combining extraction (too few tasks for a batch ...): the call again, without it
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 
@@ -173,6 +178,7 @@ static int fail(hsk_ctx *c, int code, const char *fmt, ...)
 
 // HSK_TIMING=1 (diagnostic): host-side wall-clock marks of one hsk_count call on stderr
 #include <chrono>
+constexpr int HSK_RETRY_PLAN = -2000;               // internal: the call is run again with another plan (dispatch_pipeline; never returned to the caller)
 static bool timing_enabled() { static const bool on = getenv("HSK_TIMING") && atoi(getenv("HSK_TIMING")) != 0; return on; }
 static void tmark(const char *what)
 {

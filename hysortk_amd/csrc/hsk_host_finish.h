@@ -198,6 +198,7 @@ struct AggPending {
     u32 *d_list[2] = {nullptr, nullptr};                                    // [AG_BATCH][nbins] overflowing bins, ping-pong between the rungs
     bool own_scratch[AG_BATCH] = {false};
     bool big = false; int first_cap = AG_LOG2CAP_SMALL;
+    bool weighted = false;                              // the records are {key, count} pairs (combining extraction): counts are added, no long way
     u32 nbins = 0, slot_shift = 0; int K = 0; u64 ntot = 0;
     hipEvent_t ev = nullptr;
     AggHostRead *h = nullptr;                           // pinned
@@ -242,6 +243,13 @@ static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u
         else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else
+    if (p.weighted) {
+        if constexpr (NW == 1) {
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_MEDIUM, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_LARGE, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        }
+    } else
     if (p.big || log2cap == AG_LOG2CAP_HUGE) hipLaunchKernelGGL(agg_big_kernel, dim3(grid_x, AG_BATCH), dim3(AGB_THREADS), 0, c->stream, a);
     else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
@@ -263,13 +271,14 @@ static int agg_launch_scan(hsk_ctx *c, AggPending &p)
 
 // slot: which of the two pinned read-back areas (two batches can be between their stages at once)
 template <int NW>
-static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, int slot, AggPending &p)
+static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, int slot, AggPending &p, bool weighted = false)
 {
     static_assert(NW <= 3, "the aggregating finish handles keys of one to three words");
     constexpr u32 EW = NW + 1;                          // words per entry
     p = AggPending();
     const u32 L = (u32)c->cfg.lower_freq;
-    p.slot_shift = L >= 2 ? 1 : 0;                      // a bin of n records keeps at most n / L entries
+    p.weighted = weighted;
+    p.slot_shift = (L >= 2 && !weighted) ? 1 : 0;       // a bin of n records keeps at most n / L entries (pairs: every record may be an entry)
     p.big = false;                                      // (8-bit bins: the one-pass experiment of rounds 1-2, removed)
     p.nbins = 1u << prefix_bits; p.K = K;
     p.h = (AggHostRead *)((char *)c->pinned + c->pinned_bytes - 4096 + (size_t)slot * 512);
@@ -292,7 +301,7 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
         p.bt[i] = bt[i];
         if (bt[i].n == 0) continue;
         u64 *other = (bt[i].out_k == bt[i].kA) ? bt[i].kB : bt[i].kA;
-        t.keys = bt[i].out_k; t.n = bt[i].n; t.bounds = p.d_bounds + per * i; t.bin_cnt = p.d_cnt + per * i; t.bin_off = p.d_off + per * i; t.flags = p.d_flags + i;
+        t.keys = bt[i].out_k; t.vals = weighted ? bt[i].out_v : nullptr; t.n = bt[i].n; t.bounds = p.d_bounds + per * i; t.bin_cnt = p.d_cnt + per * i; t.bin_off = p.d_off + per * i; t.flags = p.d_flags + i;
         t.slot_shift = p.slot_shift; t.active = 1; p.ntot += bt[i].n; nmax = std::max(nmax, bt[i].n);
         if (!p.big) { t.ovf_list = p.d_list[0] + (size_t)nbins * i; t.ovf_n = p.d_flags + 2 * AG_BATCH + i; }      // first rung: all bins, overflowing ones listed
         if (p.slot_shift) t.scratch = other;             // the idle ping-pong buffer: n / 2 entries
@@ -306,6 +315,10 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     // slots, reads with ~1 % errors move to 2048 after their first batch); bins of 6144 records and more on average (tasks far
     // above 2^28 k-mers) start on the large table.  Two-word keys: small / large only.
     p.first_cap = p.big ? AG_LOG2CAP_SMALL : std::max(c->agg_first_cap, nmax / nbins >= 6144 ? AG_LOG2CAP_LARGE : AG_LOG2CAP_SMALL);
+    if (weighted) {                                      // pairs are (nearly) all distinct: the table that takes the average bin twice over
+        const u64 avg = nmax / nbins + 1;
+        p.first_cap = avg * 2 <= 600 ? AG_LOG2CAP_SMALL : avg * 2 <= 1200 ? AG_LOG2CAP_MEDIUM : AG_LOG2CAP_LARGE;
+    }
     int rc = agg_launch_rung<NW>(c, p, p.first_cap, nbins, p.ntot); if (rc) return rc;
     rc = agg_launch_scan(c, p); if (rc) return rc;
     p.ev = ev_get(c);
@@ -330,7 +343,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     int rc = HSK_OK, nact = 0;
     u64 ovf_bins = 0;
     for (int i = 0; i < AG_BATCH; ++i) { done[i] = bt[i].n == 0 || !h.flags[i]; if (bt[i].n) { ++nact; ovf_bins += h.ovf[0][i]; } }
-    if (!big && !c->forbid_long_way && nact) {
+    if (!big && !c->forbid_long_way && !p.weighted && nact) {
         // next batch (and next call): one table size up when more than one bin in twenty did not fit this one (each of them is
         // read twice), one size down again when nothing overflowed and no bin came anywhere near this size's limit (one-word
         // keys: the kernel reports its fullest bin; multi-word keys: after four batches without an overflow)
@@ -340,7 +353,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
                  (NW == 1 ? maxd < (1u << (p.first_cap - 1)) * 3 / 4 : ++c->agg_clean_batches >= 4)) { c->agg_first_cap = p.first_cap - 1; c->agg_clean_batches = 0; }
     }
     { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
-      if (force_off && !c->forbid_long_way) { if (NW == 1) c->agg_off = true; else c->agg_off_wide = true; } }
+      if (force_off && !c->forbid_long_way && !p.weighted) { if (NW == 1) c->agg_off = true; else c->agg_off_wide = true; } }
     // ---- the ladder, bin by bin: the listed bins again one table size up, until no bin is left or the rungs are ----------------
     if (!big && ovf_bins) {
         AggArgs keep = a;
@@ -350,7 +363,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             u32 longest = 0; u64 nb = 0; for (int i = 0; i < AG_BATCH; ++i) { longest = std::max(longest, n_cur[i]); nb += n_cur[i]; }
             if (!longest) break;
             static const int max_rung = getenv("HSK_AGG_MAXRUNG") ? atoi(getenv("HSK_AGG_MAXRUNG")) : AG_LOG2CAP_HUGE;     // (tests: stop the ladder early, the listed bins' tasks take the long way)
-            int next = (NW >= 2) ? (cap < AG_LOG2CAP_LARGE ? cap + 1 : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
+            int next = (NW >= 2 || p.weighted) ? (cap < AG_LOG2CAP_LARGE ? cap + 1 : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
             if (next > max_rung) next = 0;
             if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
             // More than half of all bins did not fit 2048 slots: this input has (nearly) as many distinct k-mers as k-mers -- reads with
@@ -358,13 +371,13 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
             // now, the batches after it (and later calls on this context) four prefix passes + the tile finish instead of two + tables.
             static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
             // (multi-word keys have no tile finish to change to: their tasks just stop climbing a ladder that ends in the long way anyway)
-            if (adapt && !c->forbid_long_way && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
+            if (adapt && !c->forbid_long_way && !p.weighted && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
                 if (NW == 1) c->agg_off = true; else c->agg_off_wide = true;
                 for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false;
                 break;
             }
             cap = next;
-            const bool last = (NW >= 2) ? cap == AG_LOG2CAP_LARGE : cap == AG_LOG2CAP_HUGE;
+            const bool last = (NW >= 2 || p.weighted) ? cap == AG_LOG2CAP_LARGE : cap == AG_LOG2CAP_HUGE;
             HIPCHK(c, hipMemsetAsync(p.d_flags + (2 + (cur ^ 1)) * AG_BATCH, 0, sizeof(u32) * AG_BATCH, c->stream));
             for (int i = 0; i < AG_BATCH; ++i) {
                 AggTask &t = a.t[i];
@@ -402,7 +415,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         }
     }
     if (any && rc == HSK_OK) hipLaunchKernelGGL(agg_compact_kernel, dim3(big ? 64 : 256, AG_BATCH), dim3(AG_THREADS), 0, c->stream, ca);
-    if (!big && !c->forbid_long_way && rc == HSK_OK) {
+    if (!big && !c->forbid_long_way && !p.weighted && rc == HSK_OK) {
         bool redo[AG_BATCH]; int nredo = 0;
         for (int i = 0; i < AG_BATCH; ++i) { redo[i] = bt[i].n != 0 && !done[i]; nredo += redo[i]; }
         if (nredo >= 3) {
@@ -413,7 +426,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     }
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
-        if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
+        if (big || c->forbid_long_way || p.weighted) { outs[i].failed = true; continue; }      // (pairs: the caller goes back to the instance path)
         // the long way for this task: full-width passes from the current order, then the two-pass counter
         c->stats.redone_tasks++;
         if (p.own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; p.own_scratch[i] = false; }   // (stream-ordered reuse)

@@ -10,6 +10,7 @@ struct BaseSource {
     const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
     const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
     const u32 *boff = nullptr;                                  // byte-store mode: supermer s starts at byte seg.byte_off + boff[s] of the stream
+    const u32 *sub = nullptr; const u64 *item = nullptr;        // item mode (combining extraction): minimizer bits and the two item words of every supermer (SupermerStore::sm_sub / sm_item); nothing else
 };
 static bool reads_in_place(const BaseSource &b) { return b.gpos != nullptr || b.boff != nullptr; }   // no prefix sums needed to find a supermer's bases
 static BaseSource source_from_packed(const u8 *d_packed, u64 packed_bytes, const u64 *gpos)
@@ -28,6 +29,8 @@ struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
     u32 *sm_boff = nullptr;       // byte-store mode (place_bytes_kernel): sm_bytes is complete, sm_boff[slot] = offset inside the task's byte run
+    u32 *sm_sub = nullptr;        // combining extraction (hsk_combine.h): 32 mixed bits of the supermer's minimizer hash ...
+    u64 *sm_item = nullptr;       // ... and the supermer itself (place_items_kernel); sm_len / sm_gpos do not exist in this mode
     u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers
     std::vector<u64> task_base;   // [ntasks][3] slot, byte, kmer bases (tasks stored in `order`)
@@ -38,14 +41,14 @@ struct SupermerStore {
 
 static void free_store(hsk_ctx *c, SupermerStore &s)
 {
-    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid); c->pool.release(s.sm_boff);
+    c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid); c->pool.release(s.sm_boff); c->pool.release(s.sm_sub); s.sm_sub = nullptr; c->pool.release(s.sm_item); s.sm_item = nullptr;
     s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr; s.sm_boff = nullptr;
 }
 
 // where the extraction finds the bases of the store's supermers: the store's own byte runs, or (position mode) the packed reads
 static BaseSource source_from_store(const SupermerStore &st, const u8 *d_packed, u64 packed_bytes)
 {
-    if (!st.sm_boff) return source_from_packed(d_packed, packed_bytes, st.sm_gpos);
+    if (!st.sm_boff) { BaseSource b = source_from_packed(d_packed, packed_bytes, st.sm_gpos); b.sub = st.sm_sub; b.item = st.sm_item; return b; }
     BaseSource b = source_from_bytes(st.sm_bytes, st.tot_bytes);
     b.boff = st.sm_boff;
     return b;
@@ -69,7 +72,7 @@ static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_byte
 {
     ParseArgs a; memset(&a, 0, sizeof a);
     a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
-    a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks);
+    a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks >> c->vt_shift); a.vt_shift = c->vt_shift;      // (virtual tasks: `ntasks` counts them)
     a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
     u32 nblocks = (u32)std::min<u64>(a.ntiles, c->scan_blocks ? c->scan_blocks : 1024);
     a.rid_base = rid_base;
@@ -99,16 +102,24 @@ struct ParseJob {
     const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
     u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
     u32 *d_tile_r0 = nullptr;     // EXTENSION: first read of every tile (hint for the (pos, rid) lookup)
+    u32 *d_tile_sub = nullptr;    // combining extraction: minimizer bits of every record
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
 };
 
 static void parse_release(hsk_ctx *c, ParseJob &j)
 {
     c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
-    c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr;
+    c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; c->pool.release(j.d_tile_sub); j.d_tile_sub = nullptr;
     j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
 }
 
+// place_items_kernel stages 16384 records + 32 tiles of packed words: ~158 KB of dynamic LDS, which the runtime wants announced
+static size_t place_items_lds(u32 ntasks)
+{
+    static bool announced = false;
+    if (!announced) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(place_items_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); announced = true; }
+    return (size_t)ntasks * 16 + 8 + (size_t)PLACE_ITEM_REC * 8 + (size_t)PLACE_ITEM_WORDS * 4;
+}
 static bool parse_fast_enabled()
 {
     static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
@@ -156,6 +167,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipMemsetAsync(j.d_overflow, 0, 4, c->stream));
         a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec; a.overflow = j.d_overflow;
         if (c->cfg.extension && nreads < (1ULL << 32)) { DALLOC(c, j.d_tile_r0, u32 *, (size_t)a.ntiles * 4 + 64); a.tile_r0 = j.d_tile_r0; }
+        if (c->combine_now && a.rec_cap <= PLACE_ITEM_REC) { DALLOC(c, j.d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64); a.tile_sub = j.d_tile_sub; }
         const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
@@ -217,6 +229,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             c->index_unchecked = false;
             if (h_ovf[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }
         }
+        if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return HSK_RETRY_PLAN; }      // (the general kernels know no virtual tasks: the call again, without them)
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
             if (a.nslabs > 1) {                                       // the general kernels know one tile range per workgroup
@@ -227,6 +240,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; a.tile_r0 = nullptr;
             c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); j.d_tile_rec = j.d_tile_nrec = nullptr;
             a.tile_rec = a.tile_nrec = nullptr;
+            c->pool.release(j.d_tile_sub); j.d_tile_sub = nullptr; a.tile_sub = nullptr;
         }
     }
     if (c->zc_src) {                                                  // the general kernels read the reads more than once: plain copy first
@@ -283,18 +297,21 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     }
     a.task_skip = d_skip;
     hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base);
-    DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
+    const bool item_mode = j.fast && a.tile_sub && !skip && !supermers_travel && !ext;      // combining extraction: the slots hold the supermers themselves
+    if (!item_mode) DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
     // byte-store mode (fast parse path): the supermers' bases are copied into per-task byte runs while the reads stream through
     // place_bytes_kernel once; positions are kept only where something still needs them (EXTENSION: pos / rid lookup)
-    bool bytes_mode = j.fast && place_bytes_enabled(supermers_travel) && a.rec_cap <= PLACE_BYTES_REC;
+    bool bytes_mode = !item_mode && j.fast && place_bytes_enabled(supermers_travel) && a.rec_cap <= PLACE_BYTES_REC;
     for (u32 t = 0; t < ntasks && bytes_mode; ++t) if (st.task_tot[3 * t + 1] >= (1ULL << 32)) bytes_mode = false;     // 32-bit offsets inside a task's run
     if (bytes_mode) {
         DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 256);
         DALLOC(c, st.sm_boff, u32 *, st.tot_sup * 4 + 64);
         HIPCHK(c, hipMemsetAsync(st.sm_bytes + st.tot_bytes, 0, 256, c->stream));     // the extraction's windows read a few words past the last supermer
     }
-    if (!bytes_mode || ext) DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);      // position mode: bases stay in the packed reads
+    if ((!bytes_mode && !item_mode) || ext) DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);      // position mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
+    a.sm_sub = nullptr; a.sm_item = nullptr;
+    if (item_mode) { DALLOC(c, st.sm_sub, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, st.tot_sup * 16 + 64); a.sm_sub = st.sm_sub; a.sm_item = st.sm_item; }
     a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.sm_bytes = st.sm_bytes; a.sm_boff = st.sm_boff; a.task_base3 = d_task_base;
     if (st.tot_sup) {
         if (j.fast) {
@@ -304,6 +321,10 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
                 ParseArgs ab = a;
                 ab.place_group = std::max<u32>(1, std::min<u32>(PLACE_BYTES_TILES, PLACE_BYTES_REC / a.rec_cap));
                 hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4, c->stream, ab);
+            } else if (item_mode) {
+                ParseArgs ai = a;
+                ai.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));
+                hipLaunchKernelGGL(place_items_kernel, dim3(j.nblocks), dim3(PLACE_ITEM_THREADS), place_items_lds(ntasks), c->stream, ai);
             } else hipLaunchKernelGGL(place_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, c->stream, a);
             if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         }
@@ -342,7 +363,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     a.rec_cap = parse_rec_cap(c->cfg.kmer_size - c->cfg.minimizer_size + 1);
     a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
     a.place_one = 1;
-    u64 *d_blk_cnt, *d_blk_base, *d_tot, *d_task_base, *d_run; u32 *d_order, *d_tile_rec, *d_tile_nrec, *d_overflow;
+    u64 *d_blk_cnt, *d_blk_base, *d_tot, *d_task_base, *d_run; u32 *d_order, *d_tile_rec, *d_tile_nrec, *d_overflow, *d_tile_sub = nullptr;
     const size_t mat = (size_t)nblocks * ntasks;
     DALLOC(c, d_blk_cnt, u64 *, mat * 3 * 8 * nsl);
     DALLOC(c, d_blk_base, u64 *, mat * 2 * 8);
@@ -353,13 +374,15 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     DALLOC(c, d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
     DALLOC(c, d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
     DALLOC(c, d_overflow, u32 *, 256);
+    if (c->combine_now && a.rec_cap <= PLACE_ITEM_REC) DALLOC(c, d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
     // the store holds at most rec_cap supermers per tile (a tile beyond that falls back); its real size is known when the last slab is in
     const u64 cap_sup = a.ntiles * (u64)a.rec_cap;
     st = SupermerStore();
     st.ntasks = ntasks; st.nblocks = nblocks;
-    DALLOC(c, st.sm_len, u8 *, cap_sup + 64);
-    DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64);
+    if (d_tile_sub) { DALLOC(c, st.sm_sub, u32 *, cap_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, cap_sup * 16 + 64); }      // item mode (combining extraction)
+    else { DALLOC(c, st.sm_len, u8 *, cap_sup + 64); DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64); }
     auto release_all = [&]() {
+        c->pool.release(d_tile_sub);
         c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_tot); c->pool.release(d_task_base); c->pool.release(d_run);
         c->pool.release(d_order); c->pool.release(d_tile_rec); c->pool.release(d_tile_nrec); c->pool.release(d_overflow);
     };
@@ -373,6 +396,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     HIPCHK(c, hipMemcpyAsync(d_order, h_order, (size_t)ntasks * 4, hipMemcpyHostToDevice, sA));
     a.tile_rec = d_tile_rec; a.tile_nrec = d_tile_nrec; a.overflow = d_overflow;
     a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.blk_base = d_blk_base; a.task_base3 = d_task_base;
+    a.tile_sub = d_tile_sub; a.sm_sub = st.sm_sub; a.sm_item = st.sm_item;
+    if (d_tile_sub) a.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));
     EvList evs(c);
     hipEvent_t ready = evs.get();                                          // the small buffers above are set up; the second stream may start
     HIPCHK(c, hipEventRecord(ready, sA));
@@ -402,7 +427,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         HIPCHK(c, hipStreamWaitEvent(sB, scanned[sl], 0));
         hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, sB, (const u64 *)a.blk_cnt, nblocks, ntasks, (const u32 *)d_order, (const u8 *)nullptr,
                            d_tot + (size_t)sl * ntasks * 3, d_task_base, d_blk_base, d_run);
-        hipLaunchKernelGGL(place_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, sB, a);
+        if (d_tile_sub) hipLaunchKernelGGL(place_items_kernel, dim3(nblocks), dim3(PLACE_ITEM_THREADS), place_items_lds(ntasks), sB, a);
+        else hipLaunchKernelGGL(place_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, sB, a);
     }
     if (profile) { (void)hipEventRecord(sp.b, sA); c->ev_pending.push_back(sp); (void)hipEventRecord(pp.b, sB); }
     // the verdicts and the totals

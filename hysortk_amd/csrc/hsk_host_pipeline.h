@@ -273,6 +273,7 @@ struct HeavyIn { u32 task; u64 *d_entries; u64 n; };       // a heavy task this 
 struct ProcExtra {
     bool force_batch = false;                              // every task through the batch kernels (partial batches padded)
     const std::vector<HeavyIn> *heavy_in = nullptr;        // merged and filtered here (they have no supermers)
+    u32 vt_shift = 0;                                      // item-mode store: minimizer bits the parse's virtual tasks have consumed (a segment's virtual task: ExpSeg::byte_off)
 };
 
 // Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
@@ -304,7 +305,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const u32 EMPTY_TASK = ~0u;
     TaskSegs empty_segs;
     std::vector<TaskOut> touts(ntasks);
-    const bool forced = ex && ex->force_batch && batch_enabled;
+    const bool forced = ((ex && ex->force_batch) || x_src.item != nullptr) && batch_enabled;      // (item-mode store: every task goes through whole batches)
     // a caller's task count below eight (the reference's default for one rank is five): three to seven tasks of some size still
     // go faster as one padded batch (5/8 of the batch path's rate) than one by one on the single-task path (about 1/3 of it)
     u64 mine_kmers = 0; for (u32 t : mine) mine_kmers += segs[t].nkmers;
@@ -339,6 +340,15 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     constexpr int XS_CH = XsCfg<(NW <= 2 ? NW : 1)>::CHUNK;
     const bool xs = batch && (NW == 1 ? (!ext || xs_ext_enabled) : (NW == 2 && !ext && xs_wide_enabled && prefix_top_bits(K, NW) == 16)) && scatter_enabled() &&
                     scatter_store_keys(max_task, XS_CH) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
+    // the combining extraction (hsk_combine.h): the store carries the supermers' minimizer bits, whole batches, the aggregating finish
+    bool combine = false;
+    // (an item-mode store -- x_src.item -- holds nothing the instance path could read: every batch takes the combining extraction, or the
+    //  call starts again without it)
+    const bool item_mode = x_src.item != nullptr;
+    if constexpr (NW == 1) combine = item_mode && xs && agg && !c->agg_off && !ext && !feeder && mine.size() % XCD_BATCH == 0;
+    if (item_mode && !combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+    BucketOrder border;
+    bool slot_combine[2] = {false, false};
     ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];
     u64 *kAs[2][XCD_BATCH] = {{nullptr}}, *kBs[2][XCD_BATCH] = {{nullptr}}, *vAs[2][XCD_BATCH] = {{nullptr}}, *vBs[2][XCD_BATCH] = {{nullptr}};
@@ -350,7 +360,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
                 DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
                 DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * NW * 8 + 64);   // xs: the chunk store of the first pass
-                if (ext) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
+                if (ext || combine) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
             }
             int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
         }
@@ -499,10 +509,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         slot_agg[sl] = agg && !(NW == 1 ? c->agg_off : c->agg_off_wide);
         slot_fext[sl] = fused_ext && !c->agg_off_wide;
         slot_follow[sl] = slot_agg[sl] || slot_fext[sl] || (NW == 1 && fused);
-        const int prefix_bits = (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        const bool will_combine = combine && border.active && slot_agg[sl];
+        if (combine && !will_combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+        const int prefix_bits = will_combine ? combine_prefix_bits() : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
-        const int npass = batch_pass_plan<NW>(c, K, slot_follow[sl], prefix_bits, plan);
+        int npass = batch_pass_plan<NW>(c, K, slot_follow[sl], will_combine ? AG_PREFIX_BITS : prefix_bits, plan);
+        if (will_combine) { npass = 2; plan[0] = PassDesc{0, 64 - prefix_bits, prefix_bits - 8}; plan[1] = PassDesc{0, 56, 8}; }      // the pairs' two digits: the low prefix bits, then the top 8
         pt.begin(PH_EXTRACT);
         HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
         ExpandJob jobs[XCD_BATCH];
@@ -510,7 +523,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             const u32 t = mine[bpos + i];
             BatchTask &b = bts[sl][i];
             b = BatchTask();
-            b.kA = kAs[sl][i]; b.kB = kBs[sl][i]; b.vA = vAs[sl][i]; b.vB = vBs[sl][i];
+            b.kA = kAs[sl][i]; b.kB = kBs[sl][i];
+            if (ext || will_combine) { b.vA = vAs[sl][i]; b.vB = vBs[sl][i]; }      // (the payload buffers mean "records carry a payload" to everything downstream)
             if (t == EMPTY_TASK) { jobs[i] = ExpandJob(); jobs[i].ts = &empty_segs; continue; }
             b.n = segs[t].nkmers;
             const TaskInput in = feeder ? feeder->input(t) : dflt;
@@ -518,6 +532,17 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             jobs[i].keys = b.kA; jobs[i].vals = b.vA; jobs[i].ghist = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256;
         }
         int rc;
+        slot_combine[sl] = false;
+        if (will_combine) {
+            if constexpr (NW == 1) {
+                u32 tk[XCD_BATCH]; u64 *gh[XCD_BATCH];
+                for (int i = 0; i < XCD_BATCH; ++i) { tk[i] = mine[bpos + i]; gh[i] = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256; }
+                memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
+                u64 *h_nout = (u64 *)((char *)c->pinned + c->pinned_bytes - 2048 + (size_t)sl * 128);
+                rc = combine_batch(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc;
+                slot_combine[sl] = sbatch[sl].active;
+            }
+        } else
         if (xs && (slot_agg[sl] || slot_fext[sl]) && npass == 2 && plan[0].bits == 8 && plan[1].bits == 8) {
             if constexpr (NW <= 2) {
                 for (int i = 0; i < XCD_BATCH; ++i) { jobs[i].keys = bts[sl][i].kB; jobs[i].vals = bts[sl][i].vB; }
@@ -540,11 +565,22 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             if (rc) return rc;
             u32 tk[XCD_BATCH];
             for (int i = 0; i < XCD_BATCH; ++i) { tk[i] = mine[pend_pos[sl] + i]; if (tk[i] != EMPTY_TASK) touts[tk[i]] = fo[i]; }
-            for (int i = 0; i < XCD_BATCH; ++i) if (tk[i] != EMPTY_TASK && fo[i].failed) early = false;
+            for (int i = 0; i < XCD_BATCH; ++i) if (tk[i] != EMPTY_TASK && fo[i].failed) {
+                early = false;
+                // a bin of pairs beyond the last table of the weighted finish: this call again, on the instance path (dispatch_pipeline)
+                if (combine) { c->combine_off = true; c->combine_off_calls = 0; return HSK_RETRY_PLAN; }
+            }
             return early_copy(tk, XCD_BATCH);
         }
         return HSK_OK;
     };
+    if (combine) {
+        pt.begin(PH_EXTRACT);
+        int rc = bucket_order_tasks(c, ntasks, segs, mine, x_src, ex ? ex->vt_shift : 0, border); if (rc) return rc;
+        pt.end(PH_EXTRACT);
+        if (!border.active) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+    }
+    u64 comb_pairs = 0, comb_kmers = 0;                   // pairs the combining extraction has written / k-mers they stand for (this call)
     size_t pos = 0;
     const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
     for (size_t b = 0; b < nbatch; ++b, pos += XCD_BATCH) {
@@ -560,6 +596,19 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         BatchTask *bt = bts[sl];
         if (feeder) feeder->release_below((pos + XCD_BATCH < mine.size() && mine[pos + XCD_BATCH] != EMPTY_TASK) ? feeder->group_of[mine[pos + XCD_BATCH]] : feeder->ngroups);
         const int prefix_bits = slot_prefix[sl];
+        if (slot_combine[sl]) {
+            // the pairs of every task are known on the device only: one wait per batch (the kernels behind it are sized from the answer)
+            c->stats.host_syncs++;
+            HIPCHK(c, hsk_sync(c, c->stream));
+            const u64 *h_nout = (const u64 *)((char *)c->pinned + c->pinned_bytes - 2048 + (size_t)sl * 128);
+            u64 bp = 0, bk = 0;
+            for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK || !bt[i].n) continue; bk += bt[i].n; bt[i].n = h_nout[i]; bp += h_nout[i]; }
+            comb_pairs += bp; comb_kmers += bk; c->stats.combine_pairs += bp;
+            if (timing_enabled()) fprintf(stderr, "[hsk] combining extraction: %llu pairs for %llu k-mers\n", (unsigned long long)bp, (unsigned long long)bk);
+            // More than one pair per three k-mers: the table is not where this input's copies meet (few copies per k-mer, or buckets
+            // with far more distinct k-mers than slots); the batches after this one, and the next calls, take the instance path
+            if (bk && bp * 3 > bk) { c->combine_off = true; c->combine_off_calls = 0; }
+        }
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
         else { int rc = sort_batch_device<NW>(c, bt, K, slot_follow[sl], prefix_bits, d_ghist_slot[sl]); if (rc) return rc; }
@@ -580,7 +629,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 // (stage 2 of the previous batch BEFORE this batch's stage 1 would start its result copy one kernel earlier, but a
                 // device-to-host copy running beside agg_finish_kernel stretches a batch from 19 to 32 ms: measured in round 2, gone)
                 pt.begin(PH_COUNT);
-                int rc = agg_stage1<NW>(c, bt, K, prefix_bits, sl, pend[sl]);
+                int rc = agg_stage1<NW>(c, bt, K, prefix_bits, sl, pend[sl], slot_combine[sl]);
                 pt.end(PH_COUNT);
                 if (rc) return rc;
                 pend_pos[sl] = pos;
@@ -613,12 +662,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (feeder) { pt.begin(PH_EXCH); rc = feeder->need(feeder->group_of[t]); pt.end(PH_EXCH); if (rc) return rc; }
         pt.begin(PH_EXTRACT);
         const TaskInput in = feeder ? feeder->input(t) : dflt;
-        rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[0], vA[0]); if (rc) return rc;
+        rc = expand_task<NW>(c, segs[t], in.len, in.src, in.pos, in.rid, kA[0], ext ? vA[0] : nullptr); if (rc) return rc;
         pt.end(PH_EXTRACT);
         if (feeder) feeder->release_below(pos + 1 < mine.size() ? feeder->group_of[mine[pos + 1]] : feeder->ngroups);
         pt.begin(PH_SORT);
         u64 *sk, *sv;
-        rc = sort_task_device<NW>(c, kA[0], kB[0], vA[0], vB[0], n, K, sc, &sk, &sv); if (rc) return rc;
+        rc = sort_task_device<NW>(c, kA[0], kB[0], ext ? vA[0] : nullptr, ext ? vB[0] : nullptr, n, K, sc, &sk, &sv); if (rc) return rc;
         pt.end(PH_SORT);
         pt.begin(PH_COUNT);
         rc = count_task_device<NW>(c, sk, sv, n, pay_before[t], d_histo, histo_len, touts[t]); if (rc) return rc;
@@ -637,6 +686,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
     free_sort_scratch(c, sc);
+    bucket_release(c, border);
     c->pool.release(d_ghist_slot[0]); c->pool.release(d_ghist_slot[1]);
 
     // ---- result ----------------------------------------------------------------------------------------
@@ -775,6 +825,16 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     ResultPriv *rp = new ResultPriv();
     out->priv = rp; out->nw = NW;
     if ((c->agg_off || c->agg_off_wide) && ++c->agg_off_calls >= 8) { c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
+    if (c->combine_off && ++c->combine_off_calls >= 8) { c->combine_off = false; c->combine_off_calls = 0; }
+    // the combining extraction pays from a few hundred million k-mers on (a bucket order of the supermers comes first); HSK_COMBINE_MIN_BYTES
+    // moves the limit (tests: 0)
+    static const u64 combine_min = getenv("HSK_COMBINE_MIN_BYTES") ? (u64)atoll(getenv("HSK_COMBINE_MIN_BYTES")) : (64ULL << 20);
+    c->combine_now = NW == 1 && nranks == 1 && !ext && !c->combine_off && !c->combine_veto && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
+                     c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok;
+    c->combine_veto = false;
+    // the combining extraction wants buckets of ~12 k k-mers: the parse itself splits every task by the top minimizer bits (virtual
+    // tasks, up to 16 per task and HSK_MAX_TASKS in all: ParseArgs::vt_shift), the bucket order does the rest (hsk_combine.h)
+    c->vt_shift = 0;
     PhaseTimer pt(c);
     pt.begin(PH_TOTAL);
 
@@ -785,6 +845,9 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         ntasks = (u32)v;
     }
     out->ntasks = (int32_t)ntasks;
+    // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records)
+    if (c->combine_now) { u32 sh = 0; while (sh < 4 && ((u64)ntasks << (sh + 1)) <= 768) ++sh; c->vt_shift = sh; }
+    const u32 vts = c->vt_shift, nvt = ntasks << vts;       // what the parse calls tasks
     std::vector<int32_t> owner(ntasks, 0);
     std::vector<u32> order(ntasks);
     for (u32 t = 0; t < ntasks; ++t) order[t] = t;
@@ -803,17 +866,29 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     static const bool pipe_enabled = !(getenv("HSK_INGEST_PIPELINE") && atoi(getenv("HSK_INGEST_PIPELINE")) == 0);
     if (nranks == 1 && !ext && c->h2d_src && pipe_enabled && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M) {
         const u8 *src = c->h2d_src; c->h2d_src = nullptr;
-        const int prc = parse_ingest_pipelined(c, src, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, st, segs);
-        if (prc == HSK_OK) pipelined = true;
-        else if (prc != PARSE_FALLBACK) return prc;
+        std::vector<TaskSegs> segs_v;
+        const int prc = parse_ingest_pipelined(c, src, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, nvt, st, vts ? segs_v : segs);
+        if (prc == HSK_OK) {
+            pipelined = true;
+            if (vts) {                                          // a task's segments: those of its virtual tasks (which one: ExpSeg::byte_off, unused in item mode)
+                for (u32 v = 0; v < nvt; ++v) {
+                    TaskSegs &ts = segs[v >> vts];
+                    for (ExpSeg sg : segs_v[v].segs) { sg.byte_off = v & ((1u << vts) - 1u); sg.kmer_off = 0; ts.segs.push_back(sg); }
+                    ts.nkmers += segs_v[v].nkmers;
+                }
+            }
+        }
+        else if (prc == PARSE_FALLBACK && vts) { c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }      // (the fallback parse knows no virtual tasks: the call again, without them)
+        else if (prc != PARSE_FALLBACK) { c->vt_shift = 0; return prc; }
         else c->stats.parse_fallbacks++;                        // (the packed reads are in HBM now: the two-step parse below takes it from there)
     }
     if (!pipelined) {
         // the reads are hashed once (parse_count); multi-GPU: the dispatcher needs the global task sizes
         // before the storage order (tasks grouped by owner rank) is known, then parse_place lays the supermers out
         ParseJob job;
-        int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, job);
-        if (rc && nranks == 1) { parse_release(c, job); return rc; }
+        int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, nvt, job);
+        if (rc && nranks == 1) { parse_release(c, job); c->vt_shift = 0; return rc; }
+        if (vts && !job.d_tile_sub && !job.empty) { parse_release(c, job); c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }   // (the parse left its fast path: no items)
         if (nranks > 1) {
             // Several ranks: a rank that fails must not return alone (its peers would wait for it in the next collective for
             // ever).  Every all-reduce below carries the ranks' status as one more element; a failed rank keeps taking part
@@ -857,12 +932,14 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             if (rc) { parse_release(c, job); return fail(c, HSK_ERR_DISPATCH, "%s", hsk_strerror(HSK_ERR_DISPATCH)); }      // (same input on every rank: all of them fail here)
             std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return owner[x] < owner[y]; });
         }
-        rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr, nranks > 1);
+        if (vts) { std::vector<u32> order_v(nvt); for (u32 v = 0; v < nvt; ++v) order_v[v] = v; rc = parse_place(c, job, order_v, st, nullptr, false); }
+        else rc = parse_place(c, job, order, st, any_heavy ? &is_heavy : nullptr, nranks > 1);
         parse_release(c, job);
         if (rc && nranks == 1) return rc;
         place_rc = rc;                                           // several ranks: carried into the size-matrix all-reduce below
     }
     pt.end(PH_PARSE);
+    c->vt_shift = 0;
     tmark("parse enqueued (task totals read)");
     out->total_supermers = st.tot_sup; out->total_supermer_bytes = st.tot_bytes + st.tot_sup * (ext ? 9 : 1);
 
@@ -894,6 +971,14 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             x_len = xb.len; x_pos = xb.pos; x_rid = xb.rid;
             x_src = source_from_bytes(xb.bytes, xb.nbytes);
             free_store(c, st);
+        }
+    } else if (!pipelined && vts) {
+        for (u32 v = 0; v < nvt; ++v) {
+            TaskSegs &ts = segs[v >> vts];
+            ts.nkmers += st.task_tot[3 * v + 2];
+            if (st.task_tot[3 * v] == 0) continue;
+            ExpSeg sg; sg.sup_off = st.task_base[3 * v]; sg.n_sup = st.task_tot[3 * v]; sg.byte_off = v & ((1u << vts) - 1u); sg.kmer_off = 0; sg.tile_start = 0;
+            ts.segs.push_back(sg);
         }
     } else if (!pipelined) {
         for (u32 t = 0; t < ntasks; ++t) {
@@ -958,7 +1043,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         for (auto &to : hlists) free_task_out(c, to);
     }
     pt.end(PH_EXCH);
-    ProcExtra ex; ex.heavy_in = &hin;
+    ProcExtra ex; ex.heavy_in = &hin; ex.vt_shift = vts;
     const std::vector<void *> before_rank = (fed && c->comm.active()) ? c->pool.snapshot() : std::vector<void *>();
     int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
     if (fed && feeder.live) {

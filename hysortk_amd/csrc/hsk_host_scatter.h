@@ -11,8 +11,10 @@ struct ScatterBatch {
     u64 *d_tile_src[XCD_BATCH] = {nullptr};
     u64 *d_gbase = nullptr;                      // [XCD_BATCH][256] digit bases of the second pass (chunk_tiles_kernel)
     u32 *d_ntiles = nullptr;                     // [XCD_BATCH] tiles of the second pass (chunk_tiles_kernel)
+    u64 *d_nout = nullptr; u64 *h_nout = nullptr; // combining extraction: [XCD_BATCH] pairs in every task's chunk store (device word / pinned copy asked for behind chunk_tiles_kernel)
     ExpandScratch x[EXP_BATCH];                  // segment lists (and tile offsets) the kernel reads
     bool active = false;
+    bool tiles_done = false;                     // chunk_tiles_kernel has run already (combining extraction: the host reads the pair counts before the second pass is sized)
 };
 
 static bool scatter_enabled()
@@ -25,7 +27,7 @@ static size_t scatter_store_keys(u64 n, int chunk) { return (size_t)(n / chunk +
 
 static void scatter_release(hsk_ctx *c, ScatterBatch &sb)
 {
-    c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl); c->pool.release(sb.d_gbase); c->pool.release(sb.d_ntiles);
+    c->pool.release(sb.d_cursor); c->pool.release(sb.d_ctl); c->pool.release(sb.d_gbase); c->pool.release(sb.d_ntiles); c->pool.release(sb.d_nout);
     for (int i = 0; i < XCD_BATCH; ++i) { c->pool.release(sb.d_map[i]); c->pool.release(sb.d_tile_src[i]); expand_release(c, sb.x[i]); }
     sb = ScatterBatch();
 }
@@ -150,7 +152,7 @@ static int sort_batch_prescattered(hsk_ctx *c, BatchTask *bt, const PassDesc *pl
     DALLOC(c, d_lookback, void *, lb_off[XCD_BATCH] + 256);
     HIPCHK(c, hipMemsetAsync(d_tickets, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(d_lookback, 0, lb_off[XCD_BATCH], c->stream));
-    hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, c->stream, sb.args);
+    if (!sb.tiles_done) hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, c->stream, sb.args);
     MultiSortArgs ms; memset(&ms, 0, sizeof ms);
     for (int i = 0; i < XCD_BATCH; ++i) {
         SortArgs &a = ms.t[i];

@@ -77,6 +77,13 @@ struct ParseArgs {
     u32 place_group;           // tiles placed together by one place_kernel step (rec_cap * place_group <= PLACE_MAX_REC)
     u32 *overflow;             // set when a tile holds more than rec_cap supermers (the host then takes parse_kernel)
     u32 *tile_r0;              // optional [ntiles] (EXTENSION): first read overlapping the tile, kept for resolve_pos_rid_kernel
+    // optional (combining extraction, hsk_combine.h): 32 well-mixed bits of every supermer's minimizer hash, [ntiles][rec_cap] beside
+    // tile_rec; the placement carries them to sm_sub[slot].  Supermers with the same minimizer m-mer -- all instances of a canonical
+    // k-mer among them -- get the same value, independent of the task id (which is the hash modulo the task count)
+    u32 *tile_sub;
+    u32 *sm_sub;
+    u32 vt_shift;              // virtual tasks: `ntasks` = real tasks << vt_shift, task id = (hash mod real tasks) << vt_shift | top vt_shift minimizer bits (fm is the real count's)
+    u64 *sm_item;              // place_items_kernel: two words per supermer -- its first 64 bases, left-aligned, the k-mer count (<= 16) in the low byte of the second
     const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
     // byte-store placement (place_bytes_kernel): the supermer's re-aligned bases (SupermerEncoder::copy_bits, reference
     // src/kmerops.cpp:1096-1107: (len + 3) / 4 bytes, tail bits zero) are written next to its length, task by task, so that the
@@ -699,9 +706,32 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             for (int i = 0; i < PARSE_PPT; ++i) { neq8 |= (mn[i] != pm ? 1u : 0u) << i; pm = mn[i]; }
             const u32 cut8 = ((tid & (SUPERMER_CUT / PARSE_PPT - 1)) == 0) ? 1u : 0u;
             const u32 prev8 = (vmask << 1) | pv;                         // bit i: position i - 1 holds a k-mer
-            const u32 bnd8 = (~vmask | cut8 | ~prev8 | neq8) & 0xFFu;
-            start8 = vmask & bnd8;
+            u32 bnd8 = (~vmask | cut8 | ~prev8 | neq8) & 0xFFu;
             s_bnd8[tid] = (u8)bnd8;
+            if (a.tile_sub) {
+                // combining extraction (hsk_combine.h): no supermer longer than 16 k-mers -- one work item, one 16-byte record.  A window
+                // minimum lives for at most W <= 15 positions unless its m-mer repeats (homopolymers, tandem repeats): rare, and cut here
+                // every 16 positions from the run's natural start (two more barriers per tile on this path only)
+                lds_barrier();
+                const u64 *bw0 = reinterpret_cast<const u64 *>(s_bnd8);
+                const u32 w = (u32)p0 >> 6, sh = (u32)p0 & 63u;
+                const u64 below = sh ? (bw0[w] & ((1ULL << sh) - 1ULL)) : 0ULL;
+                u32 last;                                                // last natural boundary before p0 (the group's first position always is one)
+                if (below) last = w * 64u + 63u - (u32)__builtin_clzll(below);
+                else if (w & 1u) { const u64 m2 = bw0[w - 1]; last = m2 ? (w - 1) * 64u + 63u - (u32)__builtin_clzll(m2) : (u32)p0; }
+                else last = (u32)p0;                                     // (p0 is the group's first position: its own bit is set)
+                u32 add = 0;
+#pragma unroll
+                for (int i = 0; i < PARSE_PPT; ++i) {
+                    const u32 p = (u32)p0 + (u32)i;
+                    if ((bnd8 >> i) & 1u) last = p;
+                    else if (((p - last) & 15u) == 0u) add |= 1u << i;
+                }
+                lds_barrier();                                           // (everybody has read the natural boundaries)
+                bnd8 |= add;
+                s_bnd8[tid] = (u8)bnd8;
+            }
+            start8 = vmask & bnd8;
         }
         u32 nrec;
         u32 off = block_excl_scan_256_lds<u32>((u32)__popc(start8), s_scan, &nrec);   // (barriers inside: s_hash is free from here on)
@@ -719,7 +749,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             u32 *trec = a.tile_rec + tile * (u64)a.rec_cap;
             for (u32 r = tid; r < nrec; r += PARSE_THREADS) {
                 const u32 p = s_plist[r];
-                const u32 d = fastmod64(s_hash[r], a.fm);
+                u32 d = fastmod64(s_hash[r], a.fm);
+                const u32 sub = (u32)((s_hash[r] * 0x9E3779B97F4A7C15ULL) >> 32);
+                if (a.vt_shift) d = (d << a.vt_shift) | (sub >> (32u - a.vt_shift));
                 const u32 w = p >> 6;
                 const u64 m = ((p & 63) == 63) ? 0ULL : (bw[w] & (~0ULL << ((p & 63) + 1)));
                 u32 nb = (p | (SUPERMER_CUT - 1)) + 1;
@@ -728,7 +760,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 const u32 nk = nb - p;
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((nk + K - 1 + 3) >> 2));
-                if (r < a.rec_cap) trec[r] = p | ((nk - 1) << 11) | (d << 18);
+                if (r < a.rec_cap) { trec[r] = p | ((nk - 1) << 11) | (d << 18); if (a.tile_sub) a.tile_sub[tile * (u64)a.rec_cap + r] = sub; }
             }
             if (tid == 0) {
                 a.tile_nrec[tile] = nrec;
@@ -826,6 +858,114 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
         }
         __syncthreads();
         for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) s_cur[t] += s_tcnt[t];
+    }
+    }                                                                   // slabs
+}
+
+// Item placement (combining extraction, hsk_combine.h): same job as place_kernel, but what lands in a supermer's slot is the supermer
+// ITSELF -- two words: its first 64 bases left-aligned (a supermer of <= 16 k-mers has at most K + 15 <= 47 of them for one-word keys),
+// the k-mer count in the low byte of the second word -- and the 32 minimizer bits beside it (sm_sub).  The bases are read here, once
+// and in order, from the packed words of the step's tiles staged in LDS (as place_bytes_kernel does): nothing downstream gathers
+// windows from the packed reads any more.  The parse's tasks are VIRTUAL tasks here (16 per task, ParseArgs::vt_shift: 640 bins
+// instead of 40), so a step takes 16384 records (1024 threads, 32 tiles): a bin's run is ~25 items = 400 bytes, not 6.
+// dynamic LDS: u64 cur[nt], u32 tcnt[nt], u32 tpre[nt], u64 srt[PLACE_ITEM_REC], u32 words[PLACE_ITEM_WORDS]
+constexpr int PLACE_ITEM_THREADS = 1024;
+constexpr u32 PLACE_ITEM_REC = 16384;                  // records of one step (rec_cap * place_group)
+constexpr u32 PLACE_ITEM_TILES = 32;                   // tiles per step at most
+constexpr u32 PLACE_ITEM_WORDS = PLACE_ITEM_TILES * (PARSE_TILE / 16) + 8;      // their packed words + the reach of the last supermer's second word
+__global__ __launch_bounds__(PLACE_ITEM_THREADS) void place_items_kernel(ParseArgs a)
+{
+    constexpr int RPT = PLACE_ITEM_REC / PLACE_ITEM_THREADS;
+    constexpr int T = PLACE_ITEM_THREADS;
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_go[PLACE_ITEM_TILES + 4];
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];
+    const int tid = threadIdx.x;
+    const u32 nt = a.ntasks;
+    u32 *s_tcnt = reinterpret_cast<u32 *>(s_cur + nt);
+    u32 *s_tpre = s_tcnt + nt;
+    u64 *s_srt = reinterpret_cast<u64 *>(s_tpre + nt + (nt & 1u));
+    u32 *s_words = reinterpret_cast<u32 *>(s_srt + PLACE_ITEM_REC);
+    for (u32 t = tid; t < nt; t += T) s_cur[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2];
+    const u32 G = a.place_group < PLACE_ITEM_TILES ? a.place_group : PLACE_ITEM_TILES;
+    const u32 *p32 = reinterpret_cast<const u32 *>(a.packed);
+    const u32 nsl = a.nslabs > 1 ? a.nslabs : 1;
+    const int lane = lane_id(), wv = tid >> 6;
+    for (u32 sl = a.place_one ? a.slab : 0; sl < (a.place_one ? a.slab + 1 : nsl); ++sl) {
+    const u64 tile0 = (u64)sl * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
+    const u64 tile_end = (nsl > 1 && ((u64)sl + 1) * a.slab_tiles < a.ntiles) ? ((u64)sl + 1) * a.slab_tiles : a.ntiles;
+    for (u32 t0 = 0; t0 < a.tiles_per_block; t0 += G) {
+        const u64 tfirst = tile0 + t0;
+        if (tfirst >= tile_end) break;
+        u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
+        if (tfirst + ng > tile_end) ng = (u32)(tile_end - tfirst);
+        __syncthreads();                                                // previous step done with s_go / s_tcnt / s_srt / s_words
+        if (tid < WAVE) {                                               // record offsets of the step's tiles (one wave: 32 tiles)
+            u32 n = 0;
+            if ((u32)tid < ng) { n = a.tile_nrec[tfirst + tid]; n = n < a.rec_cap ? n : a.rec_cap; }
+            const u32 inc = wave_incl_scan(n);
+            if ((u32)tid < ng) s_go[tid] = inc - n;
+            const u32 tot = __shfl(inc, WAVE - 1);
+            if ((u32)tid >= ng && (u32)tid <= PLACE_ITEM_TILES) s_go[tid] = tot;
+        }
+        for (u32 t = tid; t < nt; t += T) s_tcnt[t] = 0;
+        {   // the packed words of the step's tiles (+ reach) as big-endian words
+            const u64 w0 = tfirst * (PARSE_TILE / 16);
+            const u32 nw = ng * (PARSE_TILE / 16) + 8;
+            for (u32 i = tid; i < nw; i += T) {
+                const u64 b = (w0 + i) * 4;
+                u32 wv2 = 0;
+                if (b + 4 <= a.packed_bytes) wv2 = __builtin_bswap32(p32[w0 + i]);
+                else if (b < a.packed_bytes) { for (u64 q = b; q < a.packed_bytes; ++q) wv2 |= (u32)a.packed[q] << (24 - 8 * (q & 3)); }
+                s_words[i] = wv2;
+            }
+        }
+        __syncthreads();
+        const u32 total = s_go[PLACE_ITEM_TILES];
+        // a record here: position in tile (11 bits) | k-mers - 1 (4) << 11 | tile of the step (5) << 15 | task (10) << 20
+        u32 rec[RPT], rnk[RPT], sub[RPT];
+#pragma unroll
+        for (int x = 0; x < RPT; ++x) {
+            const u32 i = x * T + tid;
+            rec[x] = 0xFFFFFFFFu; rnk[x] = 0; sub[x] = 0;
+            if (i < total) {
+                u32 lo = 0, hi = ng;                                    // the tile of record i: last j with s_go[j] <= i
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_go[mid] <= i) lo = mid; else hi = mid; }
+                const u64 at = (tfirst + lo) * (u64)a.rec_cap + (i - s_go[lo]);
+                const u32 r = a.tile_rec[at];
+                sub[x] = a.tile_sub[at];
+                const u32 d = (r >> 18) & 1023u;
+                rec[x] = (r & 2047u) | (((r >> 11) & 15u) << 11) | (lo << 15) | (d << 20);
+                rnk[x] = atomicAdd(&s_tcnt[d], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive prefix of the per-task record counts (one lane per task)
+            const u32 cnt = (u32)tid < nt ? s_tcnt[tid] : 0u;
+            const u32 inc = wave_incl_scan(cnt);
+            if (lane == WAVE - 1) s_w[wv] = inc;
+            __syncthreads();
+            u32 base = 0;
+            for (int i = 0; i < 16; ++i) if (i < wv) base += s_w[i];
+            if ((u32)tid < nt) s_tpre[tid] = base + inc - cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < RPT; ++x)
+            if (rec[x] != 0xFFFFFFFFu) s_srt[s_tpre[rec[x] >> 20] + rnk[x]] = (u64)rec[x] | ((u64)sub[x] << 32);
+        __syncthreads();
+        for (u32 i = tid; i < total; i += T) {
+            const u64 e = s_srt[i];
+            const u32 r = (u32)e;
+            const u32 d = r >> 20;
+            const u64 slot = s_cur[d] + (i - s_tpre[d]);
+            const u32 bit0 = 2u * (((r >> 15) & 31u) * (u32)PARSE_TILE + (r & 2047u));
+            const u64 w0 = bits64_be32(s_words, bit0), w1 = bits64_be32(s_words, bit0 + 64u);
+            reinterpret_cast<ulonglong2 *>(a.sm_item)[slot] = make_ulonglong2(w0, (w1 & ~0xFFULL) | (u64)(((r >> 11) & 15u) + 1u));
+            a.sm_sub[slot] = (u32)(e >> 32);
+        }
+        __syncthreads();
+        for (u32 t = tid; t < nt; t += T) s_cur[t] += s_tcnt[t];
     }
     }                                                                   // slabs
 }

@@ -72,6 +72,7 @@ struct ScatterTask {
     u32 *ntiles_out;                                 // out (chunk_tiles_kernel): number of second-pass tiles
     const u32 *sm_pos; const int32_t *sm_rid;        // EXTENSION: position in read and read id of every supermer
     u64 *vchunks;                                    // EXTENSION: payload chunk store (same slots as `chunks`)
+    u64 *n_out;                                      // optional out (chunk_tiles_kernel): records in the chunk store (combining extraction: n = ~0, not known before)
 };
 struct ScatterArgs { ScatterTask t[8]; int k, shift0, shift1, chunk; u32 *err; };     // shift0, shift1 >= 32 (the digits are in the top 16 bits)
 
@@ -674,7 +675,8 @@ __global__ __launch_bounds__(256) void chunk_tiles_kernel(ScatterArgs a)
     if (t.gbase) t.gbase[d] = gb;
     if (d == 0) {
         if (t.ntiles_out) *t.ntiles_out = (u32)tot_ch;
-        if (placed != t.n || hsum != t.n) atomicOr(a.err, 8u);
+        if (t.n_out) *t.n_out = placed;
+        if (t.n == ~0ULL ? placed != hsum : (placed != t.n || hsum != t.n)) atomicOr(a.err, 8u);
     }
     const u32 *mp = t.map + (u64)d * t.vmax;
     constexpr int U = 8;                                          // map entries requested per step (a load per step is a latency per chunk)

@@ -65,6 +65,10 @@ typedef struct {
  * `coverage` times; the library leaves it by itself when the input turns out to hold (nearly) only unique k-mers. */
 #define HSK_FLAG_NO_AGGREGATION 8   /* never aggregate in LDS tables: four scatter passes on the top 32 bits + an in-LDS finish per
                                        tile (one-word keys), the full sort below for every other record shape */
+#define HSK_FLAG_NO_COMBINE     32   /* never take the combining extraction (one GPU, one-word keys, no payload, from 64 MB of packed reads on:
+                                       the supermers are ordered by minimizer bucket, every bucket's k-mers are counted in an LDS table where
+                                       they are extracted, and only the {k-mer, count} pairs enter the passes above); the library leaves it by
+                                       itself when the input yields more than one pair per three k-mers */
 #define HSK_FLAG_FULL_SORT     16   /* the reference's own algorithm: LSD radix sort over ALL key bytes of every task
                                        (sort_task, kmerops.cpp:1382) + adjacent-equal merge-count over the sorted array
                                        (count_sorted_kmers, kmerops.cpp:1410); nothing fused, nothing skipped */
@@ -142,6 +146,14 @@ typedef struct {
     uint64_t d2h_bytes;           /* result bytes copied to the host */
     double   h2d_ms;              /* duration of the input copies (0 when the parse reads pinned host memory in place) */
     double   d2h_ms;              /* duration of the result copies, whether or not they overlapped the kernels */
+    /* --- ABI 3, combining extraction (hsk_combine.h) --- */
+    uint64_t bucket_launches;     /* bucket order of the supermer items (histogram + scatter launches), items moved, duration */
+    uint64_t bucket_items;
+    double   bucket_ms;
+    uint64_t combine_launches;    /* combine_kernel: launches, k-mers counted in LDS tables, {k-mer, count} pairs written, duration */
+    uint64_t combine_kmers;
+    uint64_t combine_pairs;
+    double   combine_ms;
 } hsk_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -1,0 +1,100 @@
+"""The combining extraction (hysortk_amd/csrc/hsk_combine.h: supermers ordered by minimizer bucket, k-mers counted in LDS tables
+where they are extracted, {k-mer, count} pairs through one scatter pass and the weighted finish) against the instance path and
+the oracle.  Its switches are read once per process, so every case runs tests/_combine_worker.py in a subprocess;
+HSK_COMBINE_MIN_BYTES=0 lets inputs of test size take it (the library's own limit is 64 MB of packed reads)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(util.ROOT, "tests", "_combine_worker.py")
+BASE = dict(K=31, M=17, L=2, U=200, ntasks=16, genome=1500000, read_len=150, nreads=400000, seed=77, calls=["device"])
+
+
+def run(spec, env):
+    e = dict(os.environ, **env)
+    out = subprocess.check_output([sys.executable, WORKER, json.dumps(spec)], env=e, timeout=600).decode().strip().splitlines()
+    return [json.loads(l) for l in out if l.startswith("{")]
+
+
+@pytest.fixture(scope="module")
+def instance():
+    """digest of the base input on the instance path (HSK_COMBINE=0)"""
+    r = run(BASE, {"HSK_COMBINE": "0"})[0]
+    assert r["combine_launches"] == 0 and r["entries"] > 100000
+    return r
+
+
+@pytest.mark.parametrize("env,why", [
+    ({}, "defaults"),
+    ({"HSK_COMBINE_BUCKET": "1000000000"}, "one bucket per virtual task: the table fills and is written out again and again inside a bucket, k-mers leave in partial pairs"),
+    ({"HSK_COMBINE_BUCKET": "300"}, "as many buckets as the order allows: nearly empty tables"),
+    ({"HSK_COMBINE_PREFIX": "16"}, "bins of the instance path's width"),
+    ({"HSK_COMBINE_PREFIX": "11"}, "few, long bins: the ladder of the weighted finish"),
+])
+def test_combining_extraction_equals_instance_path(instance, env, why):
+    r = run(BASE, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
+    assert r["combine_launches"] > 0, why
+    assert r["combine_kmers"] == r["total_kmers"] and 0 < r["combine_pairs"] <= r["combine_kmers"], why
+    assert (r["digest"], r["entries"]) == (instance["digest"], instance["entries"]), why
+
+
+def test_combining_extraction_vs_oracle(tmp_path):
+    """the list itself, k-mer by k-mer, against the CPU oracle (K = 21 and 29 take the kernel's generic instance, M = 11 a wide window)"""
+    from oracle import hsk_oracle as O
+    for K, M, nt in ((31, 17, 8), (21, 11, 24), (29, 19, 40)):
+        dump = str(tmp_path / ("c%d.npz" % K))
+        spec = dict(BASE, K=K, M=M, ntasks=nt, L=1, U=65535, genome=400000, nreads=60000, dump=dump)
+        r = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
+        assert r["combine_launches"] > 0
+        z = np.load(dump)
+        want = O.count(z["packed"], z["off"], z["lens"], k=K, m=M, L=1, U=65535, ntasks=nt, fast=True)
+        assert np.array_equal(want.task_off, z["task_off"]) and np.array_equal(want.keys, z["kmers"]) and np.array_equal(want.cnt, z["cnt"]), (K, M, nt)
+
+
+def test_input_without_copies_leaves_the_combining_extraction():
+    """uniform random reads: as many pairs as k-mers.  The first call finishes on the pairs (correct, slow) and switches the context
+    to the instance path; the second call takes it.  Same list both times."""
+    spec = dict(BASE, L=1, U=65535, error_rate=0.75, nreads=150000, calls=["device", "device"])
+    a, b = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})
+    ref = run(dict(spec, calls=["device"]), {"HSK_COMBINE": "0"})[0]
+    assert a["combine_launches"] > 0 and a["combine_pairs"] * 3 > a["combine_kmers"]
+    assert b["combine_launches"] == 0
+    assert a["digest"] == b["digest"] == ref["digest"] and a["entries"] == ref["entries"]
+
+
+@pytest.mark.parametrize("env,spec,why", [
+    ({"HSK_XCD_BATCH": "0"}, dict(), "the one-task-per-XCD kernels are switched off: no batch to run the combining extraction on; the call starts again without it"),
+    ({"HSK_COMBINE_PREFIX": "9"}, dict(L=1, ntasks=1), "one task in 512 bins of ~2900 pairs: bins beyond the weighted finish's last table; the call starts again on the instance path"),
+    ({"HSK_PARSE_REC_CAP": "200"}, dict(), "tiles beyond the record capacity: the parse leaves its fast path, and the virtual tasks with it"),
+])
+def test_calls_that_start_again_without_the_combining_extraction(env, spec, why):
+    sp = dict(BASE, **spec)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"]), why
+    assert r["redone_tasks"] >= 1 or r["combine_launches"] == 0, why
+
+
+def test_two_tasks_are_padded_to_a_batch():
+    """an item-mode store pads any task count to whole batches (the instance path would take two tasks one by one)"""
+    sp = dict(BASE, ntasks=2)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
+    assert r["combine_launches"] == 1 and (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+
+
+def test_host_paths_through_the_combining_extraction(instance):
+    """hsk_count() from pageable and from pinned host memory (slab ingest pipelined with scan and item placement: the store is laid out
+    [slab][virtual task]) give the list of the device-resident call"""
+    spec = dict(BASE, genome=3000000, nreads=1100000, calls=["device", "host", "pinned", "pinned"])      # 41 MB of packed reads: above the slab-ingest limit
+    rs = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})
+    ref = run(dict(spec, calls=["device"]), {"HSK_COMBINE": "0"})[0]
+    assert all(r["combine_launches"] > 0 for r in rs)
+    assert {r["digest"] for r in rs} == {ref["digest"]}
