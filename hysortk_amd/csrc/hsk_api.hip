@@ -224,6 +224,7 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
 {
     int rc;
     const std::vector<void *> before = c->pool.snapshot();
+    const hsk_stats stats_before = c->stats;
     switch (c->nw) {
     case 1: rc = run_pipeline<1>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
     case 2: rc = run_pipeline<2>(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out); break;
@@ -238,8 +239,10 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
         (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
     }
     if (rc == HSK_RETRY_PLAN) {
-        // the combining extraction gave up (hsk_ctx::combine_off is set): once more, from the reads in HBM, on the instance path
-        c->stats.redone_tasks++;
+        // the combining extraction gave up (hsk_ctx::combine_off or combine_veto is set): once more, from the reads in HBM, on the instance path;
+        // the statistics describe the attempt that produces the result
+        drain_profile_events(c);
+        c->stats = stats_before;
         return dispatch_pipeline(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out);
     }
     return rc;

@@ -1,25 +1,31 @@
 // hsk_combine.h -- the combining extraction: k-mers are counted where they are born, per MINIMIZER BUCKET, and only the distinct
-// {k-mer, count} pairs of a bucket enter the radix passes (one-word keys, no payload, one GPU).
+// {k-mer, count} pairs of a bucket enter the radix pass (one GPU, one-word keys, no payload; from 64 MB of packed reads on).
 //
 // The reference extracts every k-mer instance of a task, sorts all of them and counts runs (src/kmerops.cpp:1382-1445); so does the
-// path of hsk_scatter.h + hsk_sort.h + hsk_agg.h, which writes every instance to HBM once and moves it once before the LDS tables of
-// the finish see it (4 x 8 bytes of HBM traffic per instance).  Sequencing data repeats every k-mer ~coverage times, and all instances
-// of a canonical k-mer share its minimizer: the supermers that carry them meet in the same (task, minimizer) bucket long before anything
-// is sorted.  So:
-//   1. scan_kernel hands out 32 mixed bits of every supermer's minimizer hash (ParseArgs::tile_sub), place_kernel carries them to the
-//      supermer's slot (sm_sub);
-//   2. bucket_hist / bucket_scan / bucket_scatter order a task's supermer RECORDS (8 bytes each: position | length << 56, one per
-//      ~8 k-mers) by the top bits of those 32: buckets of ~12 k k-mers;
-//   3. combine_kernel: a workgroup takes a bucket, rolls the k-mers of its supermers straight into an LDS hash table (the probe loop of
-//      the finish, agg_count_keys) and then writes the table's {key, count} pairs into the chunk store of the first radix pass exactly
-//      as expand_scatter2_kernel writes keys (cursor / map / chunk protocol of hsk_scatter.h), the counts into the payload chunks;
-//      a table that fills up in the middle of a bucket is written out and started again, so a key may leave a bucket in several
-//      partial pairs: nothing downstream assumes otherwise;
+// instance path of this library (hsk_scatter.h + hsk_sort.h + hsk_agg.h), which writes every instance to HBM once and moves it once
+// before the LDS tables of the finish see it: 4 x 8 bytes of HBM traffic per instance.  Sequencing data repeats every k-mer
+// ~coverage times, and all instances of a canonical k-mer share its minimizer: the supermers that carry them can meet in one
+// (task, minimizer) bucket long before anything is sorted -- and a supermer is 16 bytes for ~8 k-mers.  So:
+//   1. scan_kernel hands out 32 mixed bits of every supermer's minimizer hash (ParseArgs::tile_sub), splits every task into 16
+//      VIRTUAL tasks by the top four of them (ParseArgs::vt_shift: the parse's counting sort takes the first bits in its stride) and
+//      cuts no supermer longer than 16 k-mers; place_items_kernel (hsk_parse.h) writes the supermer ITSELF to its slot -- a 16-byte
+//      item: 64 bases + the k-mer count -- reading the packed reads once, in order;
+//   2. bucket_hist / bucket_scan / bucket_scatter order the items of a virtual task by the next <= 10 minimizer bits: buckets of
+//      ~12 k k-mers (8192 items staged and ordered in LDS per step, every bucket's run written in one piece);
+//   3. combine_kernel: a workgroup takes a bucket, reads its items back to back, rolls their k-mers straight into a 2048-slot LDS
+//      hash table (the probe loop of the finish, agg_count_keys, behind a first sweep that finds most k-mers in their home slots)
+//      and then writes the table's {key, count} pairs into the chunk store of the first radix pass exactly as expand_scatter2_kernel
+//      writes keys (cursor / map / chunk protocol of hsk_scatter.h), the counts into the payload chunks; a table that fills up in
+//      the middle of a bucket is written out and started again, so a key may leave a bucket in several partial pairs: nothing
+//      downstream assumes otherwise;
 //   4. the second radix pass carries the counts as the payload (onesweep_multi_kernel<1, true>), and the finish adds them up instead
-//      of counting records (agg_finish_kernel<cap, true>): same bins, same order, same filter, same list.
-// At ~32 instances per k-mer the passes and the finish then move 1/32 of the records; what remains per instance is the roll and one
-// LDS insert.  With (nearly) unique k-mers the pairs are as many as the instances and 16 instead of 8 bytes each: the host watches the
-// ratio and goes back to the instance path (hsk_ctx::combine_off).
+//      of counting records (agg_finish_kernel<cap, true>) over bins of the top 14 key bits: same order, same filter, same list.
+// At 32 instances per k-mer the pass and the finish move 1/26 of the records (a k-mer next to a read end misses some windows); what
+// remains per instance is the roll and one LDS read + add.  With (nearly) unique k-mers the pairs are as many as the instances and
+// 16 instead of 8 bytes each: the host watches the ratio (one pair per three k-mers) and goes back to the instance path
+// (hsk_ctx::combine_off); an item-mode store holds nothing the instance path could read, so a call that cannot go on here (a bin
+// beyond the weighted finish's last table, no batch of eight tasks, a parse that left its fast path) starts again from the reads
+// in HBM (HSK_RETRY_PLAN, dispatch_pipeline).
 #pragma once
 #include "hsk_scatter.h"
 #include "hsk_agg.h"

@@ -41,7 +41,7 @@ def main():
         st = ctx.stats(reset=True)
         print(json.dumps({"how": how, "digest": digest(r), "entries": len(r), "total_kmers": int(r.info["total_kmers"]),
                           "combine_launches": int(st["combine_launches"]), "combine_pairs": int(st["combine_pairs"]), "combine_kmers": int(st["combine_kmers"]),
-                          "redone_tasks": int(st["redone_tasks"]), "fused_tasks": int(st["fused_tasks"])}), flush=True)
+                          "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"])}), flush=True)
     if spec.get("dump"):
         np.savez(spec["dump"], kmers=r.kmers, cnt=r.cnt, task_off=r.task_off, packed=packed, off=off, lens=lens)
     if pinned is not None:
