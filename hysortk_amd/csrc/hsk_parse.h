@@ -1186,11 +1186,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void roff_write_kernel(const u32 *rl
 #pragma unroll
     for (int i = 0; i < 8; ++i) { if (base + i < nreads) roff[base + i] = ex; ex += nb[i]; }
 }
-// column sums of the COUNT matrix for task t; eight rows are requested before the first is added (one thread walks
+// column sums of the COUNT matrix for task t; sixteen rows are requested before the first is added (one thread walks
 // ~1000 rows: a load per step would be a memory latency per row)
 __device__ __forceinline__ void col_sums(const u64 *blk_cnt, u32 nblocks, u32 ntasks, u32 t, u64 &s, u64 &b, u64 &k)
 {
-    constexpr int U = 8;
+    constexpr int U = 16;
     u32 blk = 0;
     for (; blk + U <= nblocks; blk += U) {
         u64 v[U][3];
@@ -1230,19 +1230,30 @@ __global__ void parse_scan_kernel(const u64 *blk_cnt, u32 nblocks, u32 ntasks, c
         task_tot[3 * t] = s; task_tot[3 * t + 1] = b; task_tot[3 * t + 2] = k;
     }
     __syncthreads();
-    if (t == 0) {
-        u64 s = run ? run[0] : 0, b = run ? run[1] : 0, k = run ? run[2] : 0;
-        for (u32 i = 0; i < ntasks; ++i) {
-            const u32 task = order[i];
-            task_base[3 * task] = s; task_base[3 * task + 1] = b; task_base[3 * task + 2] = k;
-            s += s_tot[3 * task]; b += s_tot[3 * task + 1]; k += s_tot[3 * task + 2];
+    {
+        // bases of the tasks in storage order: an exclusive scan over order[] (one lane per position; the virtual tasks of the combining
+        // extraction make this 640 long, and a serial walk of it was a fifth of the kernel)
+        __shared__ u64 s_part[3][16];
+        const u32 task = t < ntasks ? order[t] : 0u;
+        u64 v0 = t < ntasks ? s_tot[3 * task] : 0, v1 = t < ntasks ? s_tot[3 * task + 1] : 0, v2 = t < ntasks ? s_tot[3 * task + 2] : 0;
+        const int lane = lane_id(), w = (int)(t >> 6);
+        const u64 i0 = wave_incl_scan(v0), i1 = wave_incl_scan(v1), i2 = wave_incl_scan(v2);
+        if (lane == WAVE - 1) { s_part[0][w] = i0; s_part[1][w] = i1; s_part[2][w] = i2; }
+        __syncthreads();
+        u64 b0 = run ? run[0] : 0, b1 = run ? run[1] : 0, b2 = run ? run[2] : 0, t0 = 0, t1 = 0, t2 = 0;
+        for (int i = 0; i < 16; ++i) {
+            const u64 p0 = s_part[0][i], p1 = s_part[1][i], p2 = s_part[2][i];
+            if (i < w) { b0 += p0; b1 += p1; b2 += p2; }
+            t0 += p0; t1 += p1; t2 += p2;
         }
-        if (run) { run[0] = s; run[1] = b; run[2] = k; }
+        if (t < ntasks) { task_base[3 * task] = b0 + i0 - v0; task_base[3 * task + 1] = b1 + i1 - v1; task_base[3 * task + 2] = b2 + i2 - v2; }
+        __syncthreads();                                       // (everybody has read run[] before it moves)
+        if (t == 0 && run) { run[0] += t0; run[1] += t1; run[2] += t2; }
     }
     __syncthreads();
     if (t < ntasks) {
         u64 s = task_base[3 * t], b = task_base[3 * t + 1];
-        constexpr int U = 8;
+        constexpr int U = 16;
         u32 blk = 0;
         for (; blk + U <= nblocks; blk += U) {
             u64 v[U][2];
