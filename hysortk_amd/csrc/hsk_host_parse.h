@@ -120,6 +120,23 @@ static size_t place_items_lds(u32 ntasks)
     if (!announced) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(place_items_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); announced = true; }
     return (size_t)ntasks * 16 + 8 + (size_t)PLACE_ITEM_REC * 8 + (size_t)PLACE_ITEM_WORDS * 4;
 }
+// the scan of the COUNT matrix: parse_scan_kernel (one workgroup) for the usual few dozen tasks, the three-kernel form from 128 columns on
+static int launch_parse_scan(hsk_ctx *c, hipStream_t st, const u64 *blk_cnt, u32 nblocks, u32 ntasks, const u32 *d_order, const u8 *d_skip,
+                             u64 *d_task_tot, u64 *d_task_base, u64 *d_blk_base, u64 *d_run = nullptr, u64 *d_scratch = nullptr)
+{
+    if (ntasks < 128) {
+        hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, st, blk_cnt, nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base, d_run);
+        return HSK_OK;
+    }
+    u64 *d_part = d_scratch;                              // [PS_SEGS][ntasks][3]
+    if (!d_part) DALLOC(c, d_part, u64 *, (size_t)PS_SEGS * ntasks * 3 * 8);
+    const dim3 grid((ntasks + PS_THREADS - 1) / PS_THREADS, PS_SEGS);
+    hipLaunchKernelGGL(parse_scan_part_kernel, grid, dim3(PS_THREADS), 0, st, blk_cnt, nblocks, ntasks, d_skip, d_part);
+    hipLaunchKernelGGL(parse_scan_base_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, st, (const u64 *)d_part, ntasks, d_order, d_task_tot, d_task_base, d_run);
+    hipLaunchKernelGGL(parse_scan_fill_kernel, grid, dim3(PS_THREADS), 0, st, blk_cnt, nblocks, ntasks, d_skip, (const u64 *)d_part, (const u64 *)d_task_base, d_blk_base);
+    if (!d_scratch) c->pool.release(d_part);              // (stream-ordered reuse: the caller's later work is enqueued on the same stream)
+    return HSK_OK;
+}
 static bool parse_fast_enabled()
 {
     static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
@@ -296,7 +313,7 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
         HIPCHK(c, hsk_sync(c, c->stream));          // the mask is host memory of the caller
     }
     a.task_skip = d_skip;
-    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base);
+    { int prc = launch_parse_scan(c, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base); if (prc) return prc; }
     const bool item_mode = j.fast && a.tile_sub && !skip && !supermers_travel && !ext;      // combining extraction: the slots hold the supermers themselves
     if (!item_mode) DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
     // byte-store mode (fast parse path): the supermers' bases are copied into per-task byte runs while the reads stream through
@@ -375,6 +392,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     DALLOC(c, d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
     DALLOC(c, d_overflow, u32 *, 256);
     if (c->combine_now && a.rec_cap <= PLACE_ITEM_REC) DALLOC(c, d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+    u64 *d_ps; DALLOC(c, d_ps, u64 *, (size_t)PS_SEGS * ntasks * 3 * 8);
     // the store holds at most rec_cap supermers per tile (a tile beyond that falls back); its real size is known when the last slab is in
     const u64 cap_sup = a.ntiles * (u64)a.rec_cap;
     st = SupermerStore();
@@ -382,7 +400,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     if (d_tile_sub) { DALLOC(c, st.sm_sub, u32 *, cap_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, cap_sup * 16 + 64); }      // item mode (combining extraction)
     else { DALLOC(c, st.sm_len, u8 *, cap_sup + 64); DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64); }
     auto release_all = [&]() {
-        c->pool.release(d_tile_sub);
+        c->pool.release(d_tile_sub); c->pool.release(d_ps);
         c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_tot); c->pool.release(d_task_base); c->pool.release(d_run);
         c->pool.release(d_order); c->pool.release(d_tile_rec); c->pool.release(d_tile_nrec); c->pool.release(d_overflow);
     };
@@ -425,8 +443,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         HIPCHK(c, hipEventRecord(scanned[sl], sA));
         // the slab's placement on the second stream: totals, bases (behind everything the slabs before laid out), supermers to their slots
         HIPCHK(c, hipStreamWaitEvent(sB, scanned[sl], 0));
-        hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, sB, (const u64 *)a.blk_cnt, nblocks, ntasks, (const u32 *)d_order, (const u8 *)nullptr,
-                           d_tot + (size_t)sl * ntasks * 3, d_task_base, d_blk_base, d_run);
+        { int prc = launch_parse_scan(c, sB, (const u64 *)a.blk_cnt, nblocks, ntasks, (const u32 *)d_order, (const u8 *)nullptr,
+                                      d_tot + (size_t)sl * ntasks * 3, d_task_base, d_blk_base, d_run, d_ps); if (prc) return prc; }
         if (d_tile_sub) hipLaunchKernelGGL(place_items_kernel, dim3(nblocks), dim3(PLACE_ITEM_THREADS), place_items_lds(ntasks), sB, a);
         else hipLaunchKernelGGL(place_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, sB, a);
     }
