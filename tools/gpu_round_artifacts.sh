@@ -12,10 +12,10 @@ done
 cd $GRAFT_REPO_ROOT
 python3 tools/traffic_from_pmc.py $OUT $OUT/traffic.json
 mkdir -p profiles && cp $OUT/traffic.json profiles/traffic.json && cp $OUT/traffic.json profiles/${TAG}_traffic.json
-# the same two passes with the byte-store placement forced on (one GPU: off by default): what the extraction fetches then
+# the same two passes on the instance path with the byte-store placement forced on (one GPU: off by default): what the extraction fetches then
 cd /tmp
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  HSK_PLACE_BYTES=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/bytes/pmc_$set -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-variants > $OUT/bytes_pmc_$set.json 2> $OUT/bytes_pmc_$set.err
+  HSK_COMBINE=0 HSK_PLACE_BYTES=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/bytes/pmc_$set -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-variants > $OUT/bytes_pmc_$set.json 2> $OUT/bytes_pmc_$set.err
 done
 cd $GRAFT_REPO_ROOT
 python3 tools/traffic_from_pmc.py $OUT/bytes $OUT/traffic_place_bytes.json > /dev/null && cp $OUT/traffic_place_bytes.json profiles/${TAG}_traffic_place_bytes.json
