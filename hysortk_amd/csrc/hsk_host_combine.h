@@ -12,10 +12,24 @@ static bool combine_enabled()
 // with room to spare, and still most of them at 5x)
 // bins of the weighted finish: the top combine_prefix_bits() key bits (8 < bits <= 16).  A bin of the instance path's 16 bits would hold
 // ~120 pairs at 32x coverage and its workgroup would mostly wait for its own start-up; 14 bits: ~480 pairs on the 2048-slot table
-static int combine_prefix_bits()
+// More pairs per task than ~900 per bin (larger genomes, lower coverage) widen the prefix for the batches that follow, up to the instance
+// path's 16 bits; a bin that beats the last table before that has happened sends the call round again with 16.  HSK_COMBINE_PREFIX pins it.
+constexpr int COMBINE_PREFIX_DEFAULT = 14, COMBINE_PREFIX_MAX = 16;
+static int combine_prefix_forced()
 {
-    static const int v = getenv("HSK_COMBINE_PREFIX") ? std::min(16, std::max(9, atoi(getenv("HSK_COMBINE_PREFIX")))) : 14;
+    static const int v = getenv("HSK_COMBINE_PREFIX") ? std::min(16, std::max(9, atoi(getenv("HSK_COMBINE_PREFIX")))) : 0;
     return v;
+}
+static int combine_prefix_bits(const hsk_ctx *c)
+{
+    if (combine_prefix_forced()) return combine_prefix_forced();
+    return c->combine_prefix ? c->combine_prefix : COMBINE_PREFIX_DEFAULT;
+}
+static int combine_prefix_for(u64 max_pairs_per_task)
+{
+    int p = COMBINE_PREFIX_DEFAULT;
+    while (p < COMBINE_PREFIX_MAX && (max_pairs_per_task >> p) > 900) ++p;
+    return p;
 }
 static u64 combine_bucket_kmers()
 {

@@ -145,6 +145,8 @@ struct hsk_ctx {
     // combine_off = the input kept too many pairs per k-mer (or a bin beat the weighted finish): the instance path until another look
     bool combine_now = false, combine_off = false; int combine_off_calls = 0;
     u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)
+    int combine_prefix_floor = 0;      // ... never below this again (set when a bin beat the last table with fewer bits)
+    int combine_prefix = 0;            // key bits of the weighted finish's bins the next batch is planned with (0: the default; follows the pairs per task)
     bool combine_veto = false;         // this call's store turned out to be no use to the combining extraction (too few tasks for a batch ...): the call again, without it
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };

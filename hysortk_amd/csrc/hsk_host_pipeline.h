@@ -511,7 +511,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         slot_follow[sl] = slot_agg[sl] || slot_fext[sl] || (NW == 1 && fused);
         const bool will_combine = combine && border.active && slot_agg[sl];
         if (combine && !will_combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
-        const int prefix_bits = will_combine ? combine_prefix_bits() : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        const int prefix_bits = will_combine ? combine_prefix_bits(c) : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
         int npass = batch_pass_plan<NW>(c, K, slot_follow[sl], will_combine ? AG_PREFIX_BITS : prefix_bits, plan);
@@ -568,7 +568,11 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             for (int i = 0; i < XCD_BATCH; ++i) if (tk[i] != EMPTY_TASK && fo[i].failed) {
                 early = false;
                 // a bin of pairs beyond the last table of the weighted finish: this call again, on the instance path (dispatch_pipeline)
-                if (combine) { c->combine_off = true; c->combine_off_calls = 0; return HSK_RETRY_PLAN; }
+                if (combine) {
+                    if (!combine_prefix_forced() && slot_prefix[sl] < COMBINE_PREFIX_MAX) c->combine_prefix = c->combine_prefix_floor = COMBINE_PREFIX_MAX;      // once more with the narrowest bins
+                    else { c->combine_off = true; c->combine_off_calls = 0; }
+                    return HSK_RETRY_PLAN;
+                }
             }
             return early_copy(tk, XCD_BATCH);
         }
@@ -601,8 +605,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             c->stats.host_syncs++;
             HIPCHK(c, hsk_sync(c, c->stream));
             const u64 *h_nout = (const u64 *)((char *)c->pinned + c->pinned_bytes - 2048 + (size_t)sl * 128);
-            u64 bp = 0, bk = 0;
-            for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK || !bt[i].n) continue; bk += bt[i].n; bt[i].n = h_nout[i]; bp += h_nout[i]; }
+            u64 bp = 0, bk = 0, pmax = 0;
+            for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK || !bt[i].n) continue; bk += bt[i].n; bt[i].n = h_nout[i]; bp += h_nout[i]; pmax = std::max<u64>(pmax, h_nout[i]); }
+            c->combine_prefix = std::max(c->combine_prefix_floor, combine_prefix_for(pmax));      // (the batches and calls after this one)
             comb_pairs += bp; comb_kmers += bk; c->stats.combine_pairs += bp;
             if (timing_enabled()) fprintf(stderr, "[hsk] combining extraction: %llu pairs for %llu k-mers\n", (unsigned long long)bp, (unsigned long long)bk);
             // More than one pair per three k-mers: the table is not where this input's copies meet (few copies per k-mer, or buckets

@@ -82,6 +82,17 @@ def test_calls_that_start_again_without_the_combining_extraction(env, spec, why)
     assert r["instance_extractions"] > 0, why                     # (the instance path's extraction kernel ran: the second attempt)
 
 
+def test_many_pairs_per_task_widen_the_finish_bins():
+    """one task of a 20 Mbp genome at 20-fold coverage: ~1200 pairs per 14-bit bin of the weighted finish (its largest table); the second
+    call on the context plans with 15 bits (hsk_ctx::combine_prefix follows the pairs per task).  Same list both times."""
+    sp = dict(BASE, ntasks=1, genome=20000000, nreads=2700000, L=1, U=65535, calls=["device", "device"])
+    a, b = run(sp, {"HSK_COMBINE_MIN_BYTES": "0"})
+    ref = run(dict(sp, calls=["device"]), {"HSK_COMBINE": "0"})[0]
+    for r in (a, b):
+        assert r["combine_launches"] > 0 and r["instance_extractions"] == 0 and r["combine_pairs"] * 3 < r["combine_kmers"]
+        assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+
+
 def test_two_tasks_are_padded_to_a_batch():
     """an item-mode store pads any task count to whole batches (the instance path would take two tasks one by one)"""
     sp = dict(BASE, ntasks=2)
