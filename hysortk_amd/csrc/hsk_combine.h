@@ -22,7 +22,7 @@
 //      of counting records (agg_finish_kernel<cap, true>) over bins of the top 14 key bits: same order, same filter, same list.
 // At 32 instances per k-mer the pass and the finish move 1/26 of the records (a k-mer next to a read end misses some windows); what
 // remains per instance is the roll and one LDS read + add.  With (nearly) unique k-mers the pairs are as many as the instances and
-// 16 instead of 8 bytes each: the host watches the ratio (one pair per three k-mers) and goes back to the instance path
+// 16 instead of 8 bytes each: the host watches the ratio (more than one pair per sixteen k-mers: reads with errors, low coverage) and goes back to the instance path
 // (hsk_ctx::combine_off); an item-mode store holds nothing the instance path could read, so a call that cannot go on here (a bin
 // beyond the weighted finish's last table, no batch of eight tasks, a parse that left its fast path) starts again from the reads
 // in HBM (HSK_RETRY_PLAN, dispatch_pipeline).

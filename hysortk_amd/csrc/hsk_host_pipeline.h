@@ -610,9 +610,11 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             c->combine_prefix = std::max(c->combine_prefix_floor, combine_prefix_for(pmax));      // (the batches and calls after this one)
             comb_pairs += bp; comb_kmers += bk; c->stats.combine_pairs += bp;
             if (timing_enabled()) fprintf(stderr, "[hsk] combining extraction: %llu pairs for %llu k-mers\n", (unsigned long long)bp, (unsigned long long)bk);
-            // More than one pair per three k-mers: the table is not where this input's copies meet (few copies per k-mer, or buckets
-            // with far more distinct k-mers than slots); the batches after this one, and the next calls, take the instance path
-            if (bk && bp * 3 > bk) { c->combine_off = true; c->combine_off_calls = 0; }
+            // More than one pair per sixteen k-mers: this input has too few copies per k-mer for the detour to pay (measured on 10 Gbp, DESIGN.md 3.2d:
+            // one pair per 25.6 k-mers 102 against 126 ms, one per 6.6 -- reads with 0.3 % errors -- 171 against 138: the tables overflow inside
+            // the buckets and the parse side's extra 20 ms buy nothing; at one per sixteen a bucket's table is already 37 % full); the batches of this call finish on the pairs, the next calls take the
+            // instance path
+            if (bk && bp * 16 > bk) { c->combine_off = true; c->combine_off_calls = 0; }
         }
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }

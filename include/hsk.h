@@ -68,7 +68,7 @@ typedef struct {
 #define HSK_FLAG_NO_COMBINE     32   /* never take the combining extraction (one GPU, one-word keys, no payload, from 64 MB of packed reads on:
                                        the supermers are ordered by minimizer bucket, every bucket's k-mers are counted in an LDS table where
                                        they are extracted, and only the {k-mer, count} pairs enter the passes above); the library leaves it by
-                                       itself when the input yields more than one pair per three k-mers */
+                                       itself when the input yields more than one pair per sixteen k-mers (reads with ~0.2 % errors and more, coverage below ~20) */
 #define HSK_FLAG_FULL_SORT     16   /* the reference's own algorithm: LSD radix sort over ALL key bytes of every task
                                        (sort_task, kmerops.cpp:1382) + adjacent-equal merge-count over the sorted array
                                        (count_sorted_kmers, kmerops.cpp:1410); nothing fused, nothing skipped */
