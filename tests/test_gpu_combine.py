@@ -82,14 +82,15 @@ def test_calls_that_start_again_without_the_combining_extraction(env, spec, why)
     assert r["instance_extractions"] > 0, why                     # (the instance path's extraction kernel ran: the second attempt)
 
 
-def test_many_pairs_per_task_widen_the_finish_bins():
-    """one task of a 20 Mbp genome at 26-fold coverage: ~1200 pairs per 14-bit bin of the weighted finish (its largest table); the second
-    call on the context plans with 15 bits (hsk_ctx::combine_prefix follows the pairs per task).  Same list both times."""
+def test_one_large_task_overflows_its_tables_and_leaves_the_plan():
+    """ONE task of 420 M k-mers has twice the k-mers per bucket the bucket order aims at (2^14 buckets per task at most): ~1200 distinct
+    k-mers per bucket overflow the 2048-slot tables, k-mers leave in partial pairs (more than one pair per sixteen k-mers; bins of the finish may overflow
+    on top: the call then goes round again), and the context takes the instance path from the next call on.  Same list both times."""
     sp = dict(BASE, ntasks=1, genome=20000000, nreads=3500000, L=1, U=65535, calls=["device", "device"])
     a, b = run(sp, {"HSK_COMBINE_MIN_BYTES": "0"})
     ref = run(dict(sp, calls=["device"]), {"HSK_COMBINE": "0"})[0]
+    assert b["combine_launches"] == 0 and b["instance_extractions"] > 0      # (the first call ends on the pairs or goes round again: either way the plan is off afterwards)
     for r in (a, b):
-        assert r["combine_launches"] > 0 and r["instance_extractions"] == 0 and r["combine_pairs"] * 16 < r["combine_kmers"]
         assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
 
 
