@@ -614,7 +614,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             // one pair per 25.6 k-mers 102 against 126 ms, one per 6.6 -- reads with 0.3 % errors -- 171 against 138: the tables overflow inside
             // the buckets and the parse side's extra 20 ms buy nothing; at one per sixteen a bucket's table is already 37 % full); the batches of this call finish on the pairs, the next calls take the
             // instance path
-            if (bk && bp * 16 > bk) { c->combine_off = true; c->combine_off_calls = 0; }
+            static const u64 ratio_env = getenv("HSK_COMBINE_RATIO") ? (u64)std::max(1, atoi(getenv("HSK_COMBINE_RATIO"))) : 16;      // (measurements: 1 = never leave)
+            if (bk && bp * ratio_env > bk) { c->combine_off = true; c->combine_off_calls = 0; }
         }
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
