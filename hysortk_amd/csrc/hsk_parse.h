@@ -706,31 +706,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             for (int i = 0; i < PARSE_PPT; ++i) { neq8 |= (mn[i] != pm ? 1u : 0u) << i; pm = mn[i]; }
             const u32 cut8 = ((tid & (SUPERMER_CUT / PARSE_PPT - 1)) == 0) ? 1u : 0u;
             const u32 prev8 = (vmask << 1) | pv;                         // bit i: position i - 1 holds a k-mer
-            u32 bnd8 = (~vmask | cut8 | ~prev8 | neq8) & 0xFFu;
+            const u32 bnd8 = (~vmask | cut8 | ~prev8 | neq8) & 0xFFu;
             s_bnd8[tid] = (u8)bnd8;
-            if (a.tile_sub) {
-                // combining extraction (hsk_combine.h): no supermer longer than 16 k-mers -- one work item, one 16-byte record.  A window
-                // minimum lives for at most W <= 15 positions unless its m-mer repeats (homopolymers, tandem repeats): rare, and cut here
-                // every 16 positions from the run's natural start (two more barriers per tile on this path only)
-                lds_barrier();
-                const u64 *bw0 = reinterpret_cast<const u64 *>(s_bnd8);
-                const u32 w = (u32)p0 >> 6, sh = (u32)p0 & 63u;
-                const u64 below = sh ? (bw0[w] & ((1ULL << sh) - 1ULL)) : 0ULL;
-                u32 last;                                                // last natural boundary before p0 (the group's first position always is one)
-                if (below) last = w * 64u + 63u - (u32)__builtin_clzll(below);
-                else if (w & 1u) { const u64 m2 = bw0[w - 1]; last = m2 ? (w - 1) * 64u + 63u - (u32)__builtin_clzll(m2) : (u32)p0; }
-                else last = (u32)p0;                                     // (p0 is the group's first position: its own bit is set)
-                u32 add = 0;
-#pragma unroll
-                for (int i = 0; i < PARSE_PPT; ++i) {
-                    const u32 p = (u32)p0 + (u32)i;
-                    if ((bnd8 >> i) & 1u) last = p;
-                    else if (((p - last) & 15u) == 0u) add |= 1u << i;
-                }
-                lds_barrier();                                           // (everybody has read the natural boundaries)
-                bnd8 |= add;
-                s_bnd8[tid] = (u8)bnd8;
-            }
+            if (tid == 0) s_scan[10] = 0;                                // extra records of this tile (combining extraction, step 5)
             start8 = vmask & bnd8;
         }
         u32 nrec;
@@ -757,17 +735,32 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 u32 nb = (p | (SUPERMER_CUT - 1)) + 1;
                 if (m) nb = w * 64 + (u32)__builtin_ctzll(m);
                 else if ((w & 1) == 0) { const u64 m2 = bw[w + 1]; if (m2) nb = (w + 1) * 64 + (u32)__builtin_ctzll(m2); }
-                const u32 nk = nb - p;
+                u32 nk = nb - p;
+                if (a.tile_sub && nk > 16u) {
+                    // combining extraction (hsk_combine.h): no supermer longer than 16 k-mers -- one work item, one 16-byte record.  A window
+                    // minimum lives for at most W <= 15 positions unless its m-mer repeats (homopolymers, tandem repeats): rare; the rest of
+                    // such a run leaves as extra records of 16 k-mers behind the tile's regular ones (their order does not matter)
+                    for (u32 pp = p + 16u, rest = nk - 16u; rest; ) {
+                        const u32 piece = rest < 16u ? rest : 16u;
+                        const u32 rx = nrec + atomicAdd(&s_scan[10], 1u);
+                        atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)piece);
+                        atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((piece + K - 1 + 3) >> 2));
+                        if (rx < a.rec_cap) { trec[rx] = pp | ((piece - 1) << 11) | (d << 18); a.tile_sub[tile * (u64)a.rec_cap + rx] = sub; }
+                        pp += piece; rest -= piece;
+                    }
+                    nk = 16u;
+                }
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((nk + K - 1 + 3) >> 2));
                 if (r < a.rec_cap) { trec[r] = p | ((nk - 1) << 11) | (d << 18); if (a.tile_sub) a.tile_sub[tile * (u64)a.rec_cap + r] = sub; }
             }
-            if (tid == 0) {
-                a.tile_nrec[tile] = nrec;
-                if (nrec > a.rec_cap) atomicOr(a.overflow, 1u);
-            }
         }
         lds_barrier();
+        if (tid == 0) {
+            const u32 nall = nrec + s_scan[10];                           // (the extra records have been counted: barrier above)
+            a.tile_nrec[tile] = nall;
+            if (nall > a.rec_cap) atomicOr(a.overflow, 1u);
+        }
 #ifdef HSK_DIAG
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[5] = t_; }
 #endif
