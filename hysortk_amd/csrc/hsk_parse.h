@@ -863,8 +863,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
 // instead of 40), so a step takes 16384 records (1024 threads, 32 tiles): a bin's run is ~25 items = 400 bytes, not 6.
 // dynamic LDS: u64 cur[nt], u32 tcnt[nt], u32 tpre[nt], u64 srt[PLACE_ITEM_REC], u32 words[PLACE_ITEM_WORDS]
 constexpr int PLACE_ITEM_THREADS = 1024;
-constexpr u32 PLACE_ITEM_REC = 16384;                  // records of one step (rec_cap * place_group)
-constexpr u32 PLACE_ITEM_TILES = 32;                   // tiles per step at most
+#ifndef PLACE_ITEM_RPT
+#define PLACE_ITEM_RPT 16
+#endif
+constexpr u32 PLACE_ITEM_REC = PLACE_ITEM_RPT * 1024;  // records of one step (rec_cap * place_group)
+constexpr u32 PLACE_ITEM_TILES = PLACE_ITEM_REC / 512; // tiles per step at most
 constexpr u32 PLACE_ITEM_WORDS = PLACE_ITEM_TILES * (PARSE_TILE / 16) + 8;      // their packed words + the reach of the last supermer's second word
 __global__ __launch_bounds__(PLACE_ITEM_THREADS) void place_items_kernel(ParseArgs a)
 {
