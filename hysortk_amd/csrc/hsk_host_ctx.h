@@ -144,6 +144,10 @@ struct hsk_ctx {
     // combining extraction (hsk_combine.h): combine_now = this call lays the store out for it (one GPU, one-word keys, no payload);
     // combine_off = the input kept too many pairs per k-mer (or a bin beat the weighted finish): the instance path until another look
     bool combine_now = false, combine_off = false; int combine_off_calls = 0;
+    // ... another look after combine_off_period calls: 8, and twice as many every time the look finds the same kind of input again (up
+    // to 64: a look costs the call ~2 x, reads with errors should not pay that every eighth call); back to 8 once a call has gone through
+    int combine_off_period = 8, combine_good_calls = 0;
+    void leave_combine() { combine_off_period = combine_good_calls ? 8 : std::min(combine_off_period * 2, 64); combine_good_calls = 0; combine_off = true; combine_off_calls = 0; }
     u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)
     int combine_prefix_floor = 0;      // ... never below this again (set when a bin beat the last table with fewer bits)
     int combine_prefix = 0;            // key bits of the weighted finish's bins the next batch is planned with (0: the default; follows the pairs per task)

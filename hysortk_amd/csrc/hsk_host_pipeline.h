@@ -570,7 +570,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 // a bin of pairs beyond the last table of the weighted finish: this call again, on the instance path (dispatch_pipeline)
                 if (combine) {
                     if (!combine_prefix_forced() && slot_prefix[sl] < COMBINE_PREFIX_MAX) c->combine_prefix = c->combine_prefix_floor = COMBINE_PREFIX_MAX;      // once more with the narrowest bins
-                    else { c->combine_off = true; c->combine_off_calls = 0; }
+                    else if (!c->combine_off) c->leave_combine();
                     return HSK_RETRY_PLAN;
                 }
             }
@@ -615,7 +615,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             // the buckets and the parse side's extra 20 ms buy nothing; at one per sixteen a bucket's table is already 37 % full); the batches of this call finish on the pairs, the next calls take the
             // instance path
             static const u64 ratio_env = getenv("HSK_COMBINE_RATIO") ? (u64)std::max(1, atoi(getenv("HSK_COMBINE_RATIO"))) : 16;      // (measurements: 1 = never leave)
-            if (bk && bp * ratio_env > bk) { c->combine_off = true; c->combine_off_calls = 0; }
+            if (bk && bp * ratio_env > bk && !c->combine_off) c->leave_combine();
         }
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
@@ -694,6 +694,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     if (feeder) { int rc = feeder->finish(); if (rc) return rc; }
     for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) { c->pool.release(kAs[sl][i]); c->pool.release(kBs[sl][i]); c->pool.release(vAs[sl][i]); c->pool.release(vBs[sl][i]); }
     free_sort_scratch(c, sc);
+    if (combine && !c->combine_off) c->combine_good_calls++;
     bucket_release(c, border);
     c->pool.release(d_ghist_slot[0]); c->pool.release(d_ghist_slot[1]);
 
@@ -833,7 +834,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     ResultPriv *rp = new ResultPriv();
     out->priv = rp; out->nw = NW;
     if ((c->agg_off || c->agg_off_wide) && ++c->agg_off_calls >= 8) { c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
-    if (c->combine_off && ++c->combine_off_calls >= 8) { c->combine_off = false; c->combine_off_calls = 0; }
+    if (c->combine_off && ++c->combine_off_calls >= c->combine_off_period) { c->combine_off = false; c->combine_off_calls = 0; }
     // the combining extraction pays from a few hundred million k-mers on (a bucket order of the supermers comes first); HSK_COMBINE_MIN_BYTES
     // moves the limit (tests: 0)
     static const u64 combine_min = getenv("HSK_COMBINE_MIN_BYTES") ? (u64)atoll(getenv("HSK_COMBINE_MIN_BYTES")) : (64ULL << 20);
