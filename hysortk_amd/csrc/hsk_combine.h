@@ -53,6 +53,7 @@ struct BucketSortArgs {
     const u64 *out_base;       // [ntasks] first item of every task in `recs`
     u32 stride;
     u32 vt_shift;              // minimizer bits the virtual tasks have consumed
+    u32 *err;                  // sticky error word (bit 64: an item list whose virtual task does not fit its task's buckets: nothing is written)
     ulonglong2 *recs;          // out: the items, tasks back to back, buckets ascending inside a task
 };
 // bucket of an item inside its task = top lg bits of sub = {virtual task bits, local bits}
@@ -64,6 +65,13 @@ __device__ __forceinline__ BucketMap bucket_map(const BucketSortArgs &a, const B
     m.gbase = m.lg >= a.vt_shift ? ((u32)it.hi << m.lgl) : ((u32)it.hi >> (a.vt_shift - m.lg));
     return m;
 }
+// a work item must address buckets of its own task only (anything else would be a bug upstream, never an address)
+__device__ __forceinline__ bool bucket_map_ok(const BucketSortArgs &a, const BucketMap &m)
+{
+    const bool ok = m.lg <= (u32)CS_MAX_LOG2NB && m.lgl <= (u32)CS_MAX_LOCAL && (u64)m.gbase + (1ULL << m.lgl) <= (1ULL << m.lg);
+    if (!ok && threadIdx.x == 0) atomicOr(a.err, 64u);
+    return ok;
+}
 __device__ __forceinline__ u32 bucket_local(u32 sub, const BucketMap &m) { return m.lgl ? (sub >> (32 - m.lg)) & ((1u << m.lgl) - 1u) : 0u; }
 
 __global__ __launch_bounds__(CS_THREADS) void bucket_hist_kernel(BucketSortArgs a)
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(CS_THREADS) void bucket_hist_kernel(BucketSortArgs 
     __shared__ u32 s_h[1 << CS_MAX_LOCAL];
     const BucketItem it = a.items[blockIdx.x];
     const BucketMap m = bucket_map(a, it);
+    if (!bucket_map_ok(a, m)) return;
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const u32 *sub = a.sm_sub + it.first;
@@ -116,6 +125,7 @@ __global__ __launch_bounds__(CS_THREADS) void bucket_scatter_kernel(BucketSortAr
     const int tid = threadIdx.x;
     const BucketItem it = a.items[blockIdx.x];
     const BucketMap m = bucket_map(a, it);
+    if (!bucket_map_ok(a, m)) return;
     const u32 *sub = a.sm_sub + it.first;
     const ulonglong2 *src = a.sm_item + it.first;
     ulonglong2 *out = a.recs + a.out_base[it.task];

@@ -62,7 +62,7 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
         if (t == ~0u) continue;
         u64 nsup = 0;
         for (const ExpSeg &sg : segs[t].segs) {
-            for (u64 o = 0; o < sg.n_sup; o += CS_ITEM) { BucketItem it; it.first = sg.sup_off + o; it.n = (u32)std::min<u64>(CS_ITEM, sg.n_sup - o); it.task = (u16)t; it.hi = (u16)sg.byte_off; items.push_back(it); }
+            for (u64 o = 0; o < sg.n_sup; o += CS_ITEM) { BucketItem it; it.first = sg.sup_off + o; it.n = (u32)std::min<u64>(CS_ITEM, sg.n_sup - o); it.task = (u16)t; it.hi = vt_shift ? (u16)sg.byte_off : (u16)0; items.push_back(it); }      // (without virtual tasks byte_off is a real byte offset)
             nsup += sg.n_sup;
         }
         if (nsup >= (1ULL << 32)) return HSK_OK;
@@ -86,7 +86,7 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
     HIPCHK(c, hsk_sync(c, c->stream));                  // (the item list is host memory of this function)
     BucketSortArgs a; memset(&a, 0, sizeof a);
     a.items = bo.d_items; a.sm_sub = src.sub; a.sm_item = reinterpret_cast<const ulonglong2 *>(src.item); a.off = bo.off; a.cur = bo.cur; a.log2nb = bo.d_log2nb; a.out_base = bo.d_out_base;
-    a.stride = bo.stride; a.recs = bo.recs; a.vt_shift = vt_shift;
+    a.stride = bo.stride; a.recs = bo.recs; a.vt_shift = vt_shift; a.err = c->d_err;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 8; ep.keys = run; (void)hipEventRecord(ep.a, c->stream); }
     hipLaunchKernelGGL(bucket_hist_kernel, dim3((u32)items.size()), dim3(CS_THREADS), 0, c->stream, a);

@@ -94,6 +94,17 @@ def test_one_large_task_overflows_its_tables_and_leaves_the_plan():
         assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
 
 
+@pytest.mark.parametrize("ntasks", [200, 500])
+def test_many_tasks(ntasks):
+    """200 tasks: two virtual tasks each (at most 768 in all); 500: none, the bucket order does all the bits (and the parse scan takes its
+    three-kernel form from 128 columns on, with or without the combining extraction)"""
+    sp = dict(BASE, ntasks=ntasks, genome=3000000, nreads=800000)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
+    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+
+
 def test_two_tasks_are_padded_to_a_batch():
     """an item-mode store pads any task count to whole batches (the instance path would take two tasks one by one)"""
     sp = dict(BASE, ntasks=2)

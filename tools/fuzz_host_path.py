@@ -62,7 +62,7 @@ def main():
         K = int(rng.choice([17, 21, 31, 31, 31, 33, 51, 63, 77]))
         M = int(rng.integers(7, min(K, 26))); M = min(M, K - 1)
         EXT = int(rng.random() < 0.2)
-        ntasks = int(rng.choice([1, 3, 8, 16, 40, 96]))
+        ntasks = int(rng.choice([1, 3, 8, 16, 40, 96, 200, 500]))
         total = int(rng.choice([2_000_000, 40_000_000, 150_000_000, max_bases]))
         total = min(total, max_bases)
         if EXT:
