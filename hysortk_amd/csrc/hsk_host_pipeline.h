@@ -854,7 +854,8 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         ntasks = (u32)v;
     }
     out->ntasks = (int32_t)ntasks;
-    // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records)
+    // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records; more real tasks than that: the instance path)
+    if (ntasks > 768) c->combine_now = false;
     if (c->combine_now) { u32 sh = 0; while (sh < 4 && ((u64)ntasks << (sh + 1)) <= 768) ++sh; c->vt_shift = sh; }
     const u32 vts = c->vt_shift, nvt = ntasks << vts;       // what the parse calls tasks
     std::vector<int32_t> owner(ntasks, 0);

@@ -94,14 +94,17 @@ def test_one_large_task_overflows_its_tables_and_leaves_the_plan():
         assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
 
 
-@pytest.mark.parametrize("ntasks", [200, 500])
+@pytest.mark.parametrize("ntasks", [200, 500, 1000])
 def test_many_tasks(ntasks):
     """200 tasks: two virtual tasks each (at most 768 in all); 500: none, the bucket order does all the bits (and the parse scan takes its
-    three-kernel form from 128 columns on, with or without the combining extraction)"""
+    three-kernel form from 128 columns on, with or without the combining extraction); 1000: more than the item placement takes, the instance path"""
     sp = dict(BASE, ntasks=ntasks, genome=3000000, nreads=800000)
     ref = run(sp, {"HSK_COMBINE": "0"})[0]
     r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
-    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    if ntasks <= 768:
+        assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    else:                                                     # (more tasks than the item placement's LDS has room for: the instance path)
+        assert r["combine_launches"] == 0 and r["instance_extractions"] > 0
     assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
 
 
