@@ -413,10 +413,13 @@ def main():
                 kern("bucket_scatter_kernel", st["bucket_ms"], st["bucket_launches"], items * 40.0, "hbm-scattered",
                      "bucket order of the items inside a virtual task (histogram launch + scatter launch): 8192 items staged and ordered in LDS, every bucket's run written in one piece (~8 items = 128 bytes)",
                      pmc_prefix="bucket_scatter_kernel"),
-                kern("combine_kernel", st["combine_ms"], st["combine_launches"], items * 16.0 + st["combine_pairs"] * 16.0, "lds-latency",
+                kern("combine_kernel", st["combine_ms"], st["combine_launches"], items * 16.0 + st["combine_pairs"] * 16.0, "valu",
                      "extraction + counting per minimizer bucket: reads the bucket's items (16 B per supermer), rolls the k-mers into a 2048-slot LDS hash table, writes the table's "
-                     "{k-mer, count} pairs into the digit bins of the first radix pass; bound by the LDS round trips of the inserts and the table dumps, not by HBM "
-                     "(%.1f k-mers per pair in this run)" % (st["combine_kmers"] / max(st["combine_pairs"], 1))),
+                     "{k-mer, count} pairs into the digit bins of the first radix pass; bound by VALU issue, not by HBM or LDS latency: 99 VALU lane-instructions per k-mer, the "
+                     "SIMDs 79 %% busy (profiles/r03_pmc_summary_scale0.2.txt) -- an item is a supermer of 7.6 k-mers on average in 16 slots, so the waves work at ~47 %% of their lanes "
+                     "(%.1f k-mers per pair in this run); frac_of_valu_issue_peak here = 99 x k-mers / time / (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) = %.2f" % (
+                         st["combine_kmers"] / max(st["combine_pairs"], 1),
+                         (99.0 * st["combine_kmers"] / (st["combine_ms"] * 1e-3) / (256 * 4 * 16 * 2.4e9)) if st["combine_ms"] > 0 else 0.0)),
             ]
         kernels.sort(key=lambda d: -d["ms_per_step"])
         # The roofline block declares an HBM bound, so it names the time-dominant kernel AMONG THE HBM-BOUND ones; when a kernel with
