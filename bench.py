@@ -227,9 +227,17 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
     """One short device-resident leg of another record shape / plan: k-mers/s, ms per step, the scatter passes' GB/s."""
     ctx = H.Context(K=KK, M=M, L=Lv, U=Uv, EXT=ext, device=local, profile=True, keep_device=True, plan=plan)
     dp, nb, do, dl = ctx.synth_reads(genome_len, READ_LEN, nreads, seed, error_rate=error_rate)
-    for _ in range(2):                                    # warm-up: the adaptive choices (first table, aggregation on / off) settle in the first call,
-        r = ctx.count_device(dp, nb, do, dl, nreads)      # the memory pools for the path they settled on in the second
-        del r
+    # the FIRST call of a fresh context, timed on its own: the plan is chosen inside the call (estimate_plan), so what it costs beyond the
+    # steady state is the context's memory pools growing (hipMalloc of tens of GB), not a plan tried and abandoned
+    ctx.stats(reset=True)
+    t0 = time.perf_counter()
+    r = ctx.count_device(dp, nb, do, dl, nreads)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    first_dev_ms = r.info["ms_total"]
+    st1 = ctx.stats(reset=True)
+    del r
+    r = ctx.count_device(dp, nb, do, dl, nreads)          # second call: the pools have the sizes of this path now
+    del r
     ctx.stats(reset=True)
     t0 = time.perf_counter()
     info = None
@@ -244,6 +252,9 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
     nk = nreads * (READ_LEN - KK + 1)
     out = {"name": name, "what": note, "K": KK, "EXT": ext, "L": Lv, "U": Uv, "plan": plan or "default", "error_rate": error_rate, "kmers": nk, "steps": steps,
            "value": nk / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3, "device_ms_total": info["ms_total"], "entries": info.get("n"), "ntasks": info["ntasks"],
+           "first_call_ms": first_ms, "first_call_device_ms": first_dev_ms, "first_call_combine_launches": int(st1.get("combine_launches", 0)),
+           "first_call_note": "fresh context, no warm-up call: host wall clock incl. the memory pools growing; first_call_device_ms = the device time of that call (HIP events)",
+           "combine_launches_per_step": st.get("combine_launches", 0) / steps,
            "phases_ms": {k_: round(v, 2) for k_, v in info.items() if k_.startswith("ms_")},
            "scatter_pass": {"launches_per_step": st["scatter_launches"] / steps, "ms_per_step": st["scatter_ms"] / steps,
                             "GBs": (st["scatter_bytes"] / (st["scatter_ms"] * 1e-3) / 1e9) if st["scatter_ms"] > 0 else None},
@@ -252,6 +263,44 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
         out["reference_algorithm_GBs"] = ref_bytes_per_kmer * nk / dt / 1e9
         out["reference_algorithm_frac_of_hbm_peak"] = out["reference_algorithm_GBs"] / HBM_PEAK_GBS
         out["reference_algorithm_bytes_per_kmer"] = ref_bytes_per_kmer
+    return out
+
+
+def first_call_leg(H, local, genome_len, nreads, seed):
+    """Does a call depend on what the context counted before?  ONE context (pools grown once per kind of input, untimed), then for every
+    kind: a call on ANOTHER kind (error-free reads; uniform reads for the error-free kind), the call on this kind right after it = `after_other_input_ms`
+    (the context's memory points the wrong way), and two more = `steady_ms`.  hysortk::kmer_count() is called once per process (reference
+    src/hysortk.cpp:36-96): the two must agree."""
+    ctx = H.Context(K=K, M=M, L=1, U=65535, device=local, keep_device=True, profile=True)
+    kinds = [("error_free", 0.0), ("errors_0.3pct", 0.003), ("errors_1pct", 0.01), ("uniform", 0.75)]
+    data = {name: ctx.synth_reads(genome_len, READ_LEN, nreads, seed + i, error_rate=er) for i, (name, er) in enumerate(kinds)}
+    nk = nreads * (READ_LEN - K + 1)
+
+    def call(name):
+        dp, nb, do, dl = data[name]
+        ctx.stats(reset=True)
+        t0 = time.perf_counter()
+        r = ctx.count_device(dp, nb, do, dl, nreads)
+        ms = (time.perf_counter() - t0) * 1e3
+        st = ctx.stats(reset=True)
+        dev = r.info["ms_total"]
+        del r
+        return ms, dev, int(st.get("combine_launches", 0)), int(st.get("hist_launches", 0))
+    for name, _ in kinds:                                  # pools
+        call(name)
+    out = []
+    for name, er in kinds:
+        other = "uniform" if name == "error_free" else "error_free"
+        call(other)
+        a = call(name)
+        b = [call(name) for _ in range(2)]
+        steady = sum(x[0] for x in b) / len(b)
+        out.append({"input": name, "error_rate": er, "kmers": nk, "after_other_input_ms": a[0], "steady_ms": steady, "ratio": a[0] / steady,
+                    "after_other_input_device_ms": a[1], "steady_device_ms": sum(x[1] for x in b) / len(b),
+                    "combine_launches": {"after_other_input": a[2], "steady": b[-1][2]}, "instance_extraction_launches": {"after_other_input": a[3], "steady": b[-1][3]}})
+    for d in data.values():
+        ctx.synth_free(d[0], d[2], d[3])
+    ctx.close()
     return out
 
 
@@ -355,31 +404,36 @@ def main():
         avg_ms = st["scatter_ms"] / launches
         bytes_per_launch = st["scatter_bytes"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, path_traffic = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes (rocprofv3 passes of an earlier run of this build)
-        if os.path.exists(tfile):
+        # PMC evidence of this build (tools/gpu_profile_round.sh -> profiles/pmc.json: per kernel and step, HBM bytes and instruction counts)
+        # and the VALU issue cost of the VALU-bound kernels' instruction mix (tools/valu_floor.py -> profiles/valu_mix.json, from
+        # profiles/r04_valu_rates.txt).  Nothing below is a literal: every count comes from those files.
+        import hashlib
+
+        def load_json(name):
             try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("onesweep_bytes_per_launch")
-                path_traffic = tj.get("path_bytes_per_step")
+                return json.load(open(os.path.join(ROOT, "profiles", name)))
             except Exception:
-                pass
+                return {}
+        pmc, mix = load_json("pmc.json"), load_json("valu_mix.json")
+        try:
+            lib_sha = hashlib.sha256(open(os.path.join(ROOT, "hysortk_amd", "libhsk.so"), "rb").read()).hexdigest()[:16]
+        except Exception:
+            lib_sha = None
+        pmc_kmers = (pmc.get("workload") or {}).get("kmers_per_step")
+        pmc_scale = (nk_rank / pmc_kmers) if pmc_kmers else 1.0           # (a --scale run: the counts scale with the workload)
+        pmc_src = {"file": "profiles/pmc.json", "produced_by": "tools/gpu_profile_round.sh (rocprofv3 --pmc, one counter set per pass, kernel trace only)",
+                   "build_sha16_of_passes": pmc.get("build_sha16"), "build_sha16_running": lib_sha, "same_build": bool(lib_sha) and pmc.get("build_sha16") == lib_sha,
+                   "scaled_by": pmc_scale, "measured_in_this_run": False}
+
+        def pmc_get(prefix, field):
+            vals = [d[field] for name, d in (pmc.get("kernels") or {}).items() if name.startswith(prefix) and field in d]
+            return sum(vals) * pmc_scale if vals else None
+        path_traffic = (pmc.get("path_hbm_bytes_per_step") or 0) * pmc_scale or None
         rec = 8 * ((KK + 31) // 32)
         copy_peak = ctx.copy_peak(1 << 32, 3) if world == 1 else None      # hand-written 16-byte-per-lane copy (hsk_copy_peak), measured in this run
-        tkern = {}
-        try:
-            tkern = json.load(open(tfile)).get("kernels", {}) if os.path.exists(tfile) else {}
-        except Exception:
-            pass
+        NSIMD, CLK = 256 * 4, 2.4e9
 
-        def pmc_bytes(prefix):
-            """HBM bytes per launch of the kernel from the committed PMC passes (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or None"""
-            for name, d in tkern.items():
-                if name.startswith(prefix):
-                    return (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
-            return None
-
-        def kern(name, ms, n, alg_bytes, bound, note, pmc_prefix=None):
+        def kern(name, ms, n, alg_bytes, bound, note, pmc_prefix=None, mix_key=None):
             d = {"kernel": name, "ms_per_step": ms / S, "launches_per_step": n / S, "avg_launch_ms": (ms / n) if n else None, "bound": bound, "note": note}
             if alg_bytes and ms > 0:
                 d["algorithmic_bytes_per_launch"] = alg_bytes / max(n, 1)
@@ -387,56 +441,69 @@ def main():
                 d["frac_of_hbm_peak"] = d["algorithmic_GBs"] / HBM_PEAK_GBS
                 if copy_peak:
                     d["frac_of_copy_peak"] = d["algorithmic_GBs"] / copy_peak
-            d["pmc_traffic_bytes_per_launch"] = pmc_bytes(pmc_prefix or name)
+            hb = pmc_get(pmc_prefix or name, "hbm_bytes_per_step")
+            d["pmc_traffic_bytes_per_launch"] = (hb / (n / S)) if hb and n else None
+            if hb and ms > 0:
+                d["pmc_traffic_GBs"] = hb / (ms / S * 1e-3) / 1e9
+            vi = pmc_get(pmc_prefix or name, "SQ_INSTS_VALU_per_step")
+            mk = (mix.get("kernels") or {}).get(mix_key or "")
+            if bound == "valu" and vi and mk and ms > 0:
+                cyc = mk["avg_cycles_per_valu_wave_instruction"]
+                floor_ms = vi * cyc / (NSIMD * CLK) * 1e3
+                d["valu"] = {"wave_instructions_per_step": vi, "lane_ops_per_s": vi * 64 / (ms / S * 1e-3), "avg_issue_cycles_per_wave_instruction": cyc,
+                             "mix_ceiling_lane_ops_per_s": 64 * NSIMD * CLK / cyc, "floor_ms_per_step": floor_ms, "frac_of_issue_floor": floor_ms / (ms / S),
+                             "salu_wave_instructions_per_step": pmc_get(pmc_prefix or name, "SQ_INSTS_SALU_per_step"), "lds_wave_instructions_per_step": pmc_get(pmc_prefix or name, "SQ_INSTS_LDS_per_step"),
+                             "how": "floor = SQ_INSTS_VALU (profiles/pmc.json) x the average issue cycles of the kernel's static instruction mix (profiles/valu_mix.json: every mnemonic "
+                                    "priced with profiles/r04_valu_rates.txt at 4 waves per SIMD) / (1024 SIMDs x 2.4 GHz).  Measured rates: v_mov / v_and / v_or / v_sub / v_add / v_xor / v_not / "
+                                    "v_lshrrev_b32 / v_bitop3 issue in 2.3 - 2.8 cycles per wave-instruction (the SIMD-32 rate: 0.72 - 0.84 of 78.6 T lane-ops/s); every multiply, 64-bit "
+                                    "operation, left shift, three-operand add / logic, compare, select, DPP and cross-lane instruction in 4.1 - 5.2 cycles (31 - 38 T lane-ops/s)"}
             return d
+        nsup = st["place_supermers"]
+        item_mode = bool(st.get("combine_launches"))
         kernels = [
-            kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] * 1.45, "valu",
-                 "minimizer hashes + supermer records: bound by VALU issue (time follows the instruction count: ~97 VALU instructions per base position, 46 of them the six 64-bit multiplies and xor-shifts of MurmurHash3); algorithmic bytes = packed reads + 4-byte supermer records, so its HBM fraction says nothing about it"),
+            kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] + nsup * (8.0 if item_mode else 4.0), "valu",
+                 "minimizer hashes + supermer records: bound by VALU issue (MurmurHash3 of every m-mer: six 64-bit multiplies and the xor-shifts, then window minima and supermer cuts); "
+                 "algorithmic bytes = packed reads in + 4 bytes of record per supermer out (8 with the minimizer bits of the combining extraction), so its HBM fraction says nothing about it",
+                 pmc_prefix="scan_kernel", mix_key="scan_kernelILi%dELi17E" % KK if KK in (31, 51) else "scan_kernelILi31ELi17E"),
             kern("expand_scatter2_kernel" if KK <= 32 and not a.ext else "expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins; "
                  "a chain of short phases per 3700-key flush, no unit of the CU saturated: bound by how many workgroups a CU holds (three since round 3: the two-sweep kernel)", pmc_prefix="expand_scatter"),
             kern("onesweep_multi_kernel", st["scatter_ms"], st["scatter_launches"], st["scatter_bytes"], "hbm", "second radix scatter pass over chunk tiles: 2 x record bytes per key"),
-            kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"], "lds-issue", "per-prefix-bin LDS hash aggregation: reads every record once; bound by instruction issue around the LDS probes (scalar unit + LDS queue; the probe loop is hand-written assembly for that reason), not by HBM"),
-            kern("place_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 13.0, "hbm-scattered",
+            kern("agg_finish_kernel", st["agg_ms"], st["agg_launches"], st["agg_bytes"] + (info.get("n", 0) or 0) * (rec + 8.0) * S, "lds-issue",
+                 "per-prefix-bin LDS hash aggregation: reads every record once (with the combining extraction: 16-byte {k-mer, count} pairs), writes the kept entries (16 B each); bound by "
+                 "instruction issue around the LDS probes (scalar unit + LDS queue; the probe loop is hand-written assembly for that reason), not by HBM"),
+            kern("place_kernel", st["place_ms"], st["place_launches"], nsup * 13.0, "hbm-scattered",
                  "supermers to their task slots: 4-byte records in, 9 bytes per supermer out in short runs"),
         ]
-        if st.get("combine_launches"):
+        if item_mode:
             # the combining extraction ran (hsk_combine.h): no instance extraction, the scatter pass and the finish work on {k-mer, count} pairs.
             # Per supermer item (16 bytes + 4 of minimizer bits): the placement reads its 4 + 4 bytes of records and ~2.4 bytes of packed bases and
             # writes 20; the bucket order reads 4 (histogram), then 4 + 16 and writes 16.
             kernels = [k_ for k_ in kernels if k_["kernel"] not in ("expand_scatter2_kernel", "expand_scatter_kernel", "place_kernel")]
             items = st["bucket_items"]
             kernels += [
-                kern("place_items_kernel", st["place_ms"], st["place_launches"], st["place_supermers"] * 30.4, "hbm-scattered",
+                kern("place_items_kernel", st["place_ms"], st["place_launches"], nsup * 30.4, "hbm-scattered",
                      "supermers (as 16-byte items: 64 bases + k-mer count, with 4 bytes of minimizer bits) to their virtual-task slots (16 virtual tasks per task: the top "
                      "minimizer bits); bases read once from the packed reads staged in LDS; 8 bytes of records in, 20 out in runs of ~25 items"),
                 kern("bucket_scatter_kernel", st["bucket_ms"], st["bucket_launches"], items * 40.0, "hbm-scattered",
                      "bucket order of the items inside a virtual task (histogram launch + scatter launch): 8192 items staged and ordered in LDS, every bucket's run written in one piece (~8 items = 128 bytes)",
-                     pmc_prefix="bucket_scatter_kernel"),
+                     pmc_prefix="bucket_"),
                 kern("combine_kernel", st["combine_ms"], st["combine_launches"], items * 16.0 + st["combine_pairs"] * 16.0, "valu",
                      "extraction + counting per minimizer bucket: reads the bucket's items (16 B per supermer), rolls the k-mers into a 2048-slot LDS hash table, writes the table's "
-                     "{k-mer, count} pairs into the digit bins of the first radix pass; bound by VALU issue, not by HBM or LDS latency: 99 VALU lane-instructions per k-mer, the "
-                     "SIMDs 79 %% busy (profiles/r03_pmc_summary_scale0.2.txt) -- an item is a supermer of 7.6 k-mers on average in 16 slots, so the waves work at ~47 %% of their lanes "
-                     "(%.1f k-mers per pair in this run); frac_of_valu_issue_peak here = 99 x k-mers / time / (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) = %.2f" % (
-                         st["combine_kmers"] / max(st["combine_pairs"], 1),
-                         (99.0 * st["combine_kmers"] / (st["combine_ms"] * 1e-3) / (256 * 4 * 16 * 2.4e9)) if st["combine_ms"] > 0 else 0.0)),
+                     "{k-mer, count} pairs into the digit bins of the first radix pass; bound by VALU issue, not by HBM or LDS latency -- an item is a supermer of 7.6 k-mers on average in "
+                     "16 slots, so the waves work at ~47 %% of their lanes (%.1f k-mers per pair in this run)" % (st["combine_kmers"] / max(st["combine_pairs"], 1)),
+                     pmc_prefix="combine_kernel", mix_key="combine_kernelILi31E"),
             ]
         kernels.sort(key=lambda d: -d["ms_per_step"])
-        # The roofline block declares an HBM bound, so it names the time-dominant kernel AMONG THE HBM-BOUND ones; when a kernel with
-        # another bound leads the list (the VALU-bound minimizer scan, since the extraction got faster in round 3) it is named beside
-        # it with the fraction of ITS ceiling: VALU issue = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second.
+        # The roofline block names the kernel with the MOST TIME, whatever bounds it, with its own ceiling (a VALU-bound kernel: the issue floor above); the
+        # time-dominant HBM-bound kernel stands beside it (`hbm_leader`) with the block's usual fields.
         dom = next(d for d in kernels if d["bound"].startswith("hbm"))
         lead = kernels[0]
-        VALU_PEAK = 256 * 4 * 16 * 2.4e9
-        scan_instr_per_pos = 97.0                          # rocprofv3 SQ_INSTS_VALU x 64 / base positions (profiles/r02_pmc_summary_scale0.2.txt)
-        lead_note = None
-        if lead is not dom:
-            lead_note = {"kernel": lead["kernel"], "ms_per_step": lead["ms_per_step"], "bound": lead["bound"]}
-            if lead["kernel"] == "scan_kernel" and st["scan_ms"] > 0:
-                rate = scan_instr_per_pos * (st["scan_bytes"] * 4.0) / (st["scan_ms"] * 1e-3)
-                lead_note.update({"valu_lane_instr_per_s": rate, "valu_issue_peak": VALU_PEAK, "frac_of_valu_issue_peak": rate / VALU_PEAK,
-                                  "note": "97 VALU instructions per base position (SQ_INSTS_VALU, round-2 PMC pass) x positions / kernel time against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; "
-                                          "its HBM fraction (kernels[]) says nothing about it"})
+
+        def hbm_block(d):
+            return {"bound": "hbm", "kernel": d["kernel"], "ms_per_step": d["ms_per_step"], "achieved": d.get("algorithmic_GBs", 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d.get("frac_of_hbm_peak", 0.0), "traffic": d["pmc_traffic_bytes_per_launch"], "launches": int(d["launches_per_step"] * S),
+                    "avg_launch_ms": d["avg_launch_ms"], "bytes_per_launch": d.get("algorithmic_bytes_per_launch"), "frac_of_copy_peak": d.get("frac_of_copy_peak")}
         ms_total = phase.get("ms_total", 0) / S
         ref_b = 152.3 if KK <= 32 and not a.ext else (464.4 if KK > 32 else 304.3)
         dev = {"value": value, "unit": "k-mers/s", "ms_per_step": ms_step, "input": "resident in HBM", "output": "left in HBM"}
@@ -452,16 +519,19 @@ def main():
                 "input": "resident in HBM", "output": "left in HBM (entries=%d on rank 0)" % info.get("n", -1),
                 "exchange": "RCCL send/recv all-to-all-v" if world > 1 else "none"},
             "device_resident": dev,
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"] + " (the time-dominant HBM-bound kernel of this run: %.1f of %.1f ms per step)" % (dom["ms_per_step"], ms_total),
-                         "time_dominant_overall": lead_note,
-                         "achieved": dom.get("algorithmic_GBs", 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom.get("frac_of_hbm_peak", 0.0), "traffic": dom["pmc_traffic_bytes_per_launch"],
-                         "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this build (tools/gpu_round_artifacts.sh), NOT measured in this run",
-                         "launches": int(dom["launches_per_step"] * S), "avg_launch_ms": dom["avg_launch_ms"], "bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
+            "roofline": {**({"bound": "valu", "kernel": lead["kernel"], "ms_per_step": lead["ms_per_step"], "of_ms_per_step": ms_total,
+                             "achieved": lead["valu"]["lane_ops_per_s"] / 1e12, "peak": lead["valu"]["mix_ceiling_lane_ops_per_s"] / 1e12, "unit": "T lane-op/s (integer VALU issue; no MFMA on this path)",
+                             "frac": lead["valu"]["frac_of_issue_floor"], "floor_ms": lead["valu"]["floor_ms_per_step"], "traffic": lead["pmc_traffic_bytes_per_launch"],
+                             "launches": int(lead["launches_per_step"] * S), "avg_launch_ms": lead["avg_launch_ms"], "valu": lead["valu"],
+                             "as_hbm": {"achieved": lead.get("algorithmic_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lead.get("frac_of_hbm_peak"),
+                                        "pmc_GBs": lead.get("pmc_traffic_GBs"), "note": "the same kernel against the HBM roofline: it is not what bounds it"}}
+                            if lead.get("valu") else hbm_block(lead)),
+                         "time_dominant": "%s: %.1f of %.1f ms per step" % (lead["kernel"], lead["ms_per_step"], ms_total),
+                         "hbm_leader": hbm_block(dom),
+                         "traffic_source": pmc_src,
                          "measured_copy_peak_GBs": copy_peak, "measured_copy_peak_source": "hsk_copy_peak in this run: hand-written kernel, 16 B per lane, 4 GiB read + 4 GiB written, best of 12 launches",
-                         "frac_of_copy_peak": dom.get("frac_of_copy_peak"),
                          "whole_path": {
-                             "traffic_bytes_per_step": path_traffic, "traffic_source": "profiles/traffic.json (PMC, earlier run of this build; not this run)",
+                             "traffic_bytes_per_step": path_traffic, "traffic_source": "profiles/pmc.json (see roofline.traffic_source)",
                              "GBs": (path_traffic / (ms_total * 1e-3) / 1e9) if path_traffic and ms_total else None,
                              "frac_of_hbm_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_traffic and ms_total else None,
                              "frac_of_copy_peak": (path_traffic / (ms_total * 1e-3) / 1e9 / copy_peak) if path_traffic and ms_total and copy_peak else None,
@@ -494,6 +564,8 @@ def main():
                 ("no_aggregation", "the headline workload with HSK_FLAG_NO_AGGREGATION: four scatter passes on the top 32 bits + in-LDS tile finish", 31, 0, "no_aggregation", L, U, G, nreads, 0.0, 152.3),
                 ("full_sort", "the headline workload with HSK_FLAG_FULL_SORT = the algorithm north_star names: LSD radix sort over all 8 key bytes "
                               "(reference sort_task, src/kmerops.cpp:1383) + adjacent-equal merge-count (count_sorted_kmers, :1410)", 31, 0, "full_sort", L, U, G, nreads, 0.0, 152.3),
+                ("errors_0.3pct", "the headline workload with 0.3 % substitution errors per base (instance path: one k-mer in eleven is an error k-mer)", 31, 0, None, L, U, G, nreads, 0.003, 152.3),
+                ("errors_1pct", "the headline workload with 1 % substitution errors per base (a realistic short-read error rate; instance path)", 31, 0, None, L, U, G, nreads, 0.01, 152.3),
                 ("uniform", "uniform random reads (error rate 0.75 makes every base uniform: all counts 1), L=1 U=65535: SURVEY 8(d)'s worst case for output volume, "
                             "half the headline's bases so that the 16 B per k-mer of output stay in HBM", 31, 0, None, 1, 65535, G // 2, nreads // 2, 0.75, 152.3),
             ]
@@ -503,6 +575,11 @@ def main():
                     out["variants"].append(run_variant(H, local, name, note, vk, vext, plan, Lv, Uv, vg, vn, seed, er, 3, refb))
                 except Exception as e:
                     out["variants"].append({"name": name, "error": str(e)[:300]})
+        if world == 1 and not a.no_variants:
+            try:
+                out["first_calls"] = first_call_leg(H, local, int(GENOME_PER_GPU * a.scale) // 2, nreads // 2, seed + 100)
+            except Exception as e:
+                out["first_calls"] = {"error": str(e)[:300]}
         if world == 1 and not a.no_cpu:
             ncores = os.cpu_count() or 1
             div = max(a.cpu_div, 1)

@@ -187,7 +187,7 @@ static void drain_profile_events(hsk_ctx *c)
         float f = 0;
         if (hipEventElapsedTime(&f, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { c->stats.scatter_launches++; c->stats.scatter_keys += p.keys; c->stats.scatter_bytes += p.bytes; c->stats.scatter_ms += f; }
-            else if (p.kind == 2) { c->stats.agg_launches++; c->stats.agg_bytes += p.bytes; c->stats.agg_ms += f; }
+            else if (p.kind == 2) { if (p.keys) c->stats.agg_launches++; c->stats.agg_bytes += p.bytes; c->stats.agg_ms += f; }      // (a rung with no listed bins is no launch of work)
             else if (p.kind == 3) { c->stats.scan_launches++; c->stats.scan_bytes += p.bytes; c->stats.scan_ms += f; }
             else if (p.kind == 4) { c->stats.place_launches++; c->stats.place_supermers += p.keys; c->stats.place_ms += f; }
             else if (p.kind == 5) { c->stats.h2d_ms += f; }
@@ -219,10 +219,102 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 #include "hsk_host_finish.h"
 #include "hsk_host_pipeline.h"
 
+// ------------------------------------------------------------------------------------------------
+// The plan is chosen INSIDE the call (hysortk::kmer_count() is called once per process, reference src/hysortk.cpp:36-96: there is
+// no "next call" that could profit from what this one learned).  Before anything is parsed, the reads that lie inside the first
+// 1/64 of the packed buffer (4 - 64 MB) are counted by the instance path with L = 1: a complete, small hsk_count_device() whose
+// histogram gives the sample's k-mer spectrum.  Two components explain it: genomic k-mers, Poisson with mean lambda_s copies inside
+// the sample (lambda_s = 3 n3 / n2, their number G = 2 n2 exp(lambda_s) / lambda_s^2 -- doubletons and tripletons are nearly free of
+// sequencing errors), and k-mers that occur once whatever the depth (errors, a uniform input): E_s = n1 - G lambda_s exp(-lambda_s).
+// In the whole input (1 / f times the sample) the first kind is seen at least once with probability 1 - exp(-lambda_s / f), the
+// second kind grows with the input:   distinct per k-mer = (f G (1 - exp(-lambda_s / f)) + E_s) / N_s.
+// Error-free 32x reads: 1 / 25.8 (the combining extraction then writes one pair per 25.6 k-mers); 0.3 % substitution errors: ~0.13;
+// uniform reads: 1.  Reads in genome order (a sorted alignment turned back into reads) make the prefix deeper than the model thinks and
+// the first term smaller than it is; the second term, which is what moves the decision for deep data, is unaffected.
+// HSK_PLAN_SAMPLE=0 turns the estimate off (the context's memory of earlier calls decides, as in rounds 2-3).
+// ------------------------------------------------------------------------------------------------
+static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads)
+{
+    c->est = PlanEstimate();
+    static const bool enabled = !(getenv("HSK_PLAN_SAMPLE") && atoi(getenv("HSK_PLAN_SAMPLE")) == 0);
+    constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 64ULL << 20;
+    // who would use it: one-word keys without payload on one GPU (combining extraction or not, first table, aggregation or not)
+    if (!enabled || c->comm.active() || c->nw != 1 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;
+    if (c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT)) return HSK_OK;         // nothing to choose
+    const auto t0 = std::chrono::steady_clock::now();
+    if (c->index_unchecked) {
+        // the sample goes through the whole pipeline: the device-side verdict on the caller's read index first (parse_count would read it after the scan)
+        u32 *h = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
+        HIPCHK(c, hipMemcpyAsync(h + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
+        c->index_unchecked = false;
+        if (h[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }
+    }
+    const u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);
+    u64 *d_pr; DALLOC(c, d_pr, u64 *, 256);
+    u64 *h_pr = (u64 *)((char *)c->pinned + c->pinned_bytes - 512);
+    hipLaunchKernelGGL(prefix_reads_kernel, dim3(1), dim3(64), 0, c->stream, d_roff, nreads, want, d_pr);
+    HIPCHK(c, hipMemcpyAsync(h_pr, d_pr, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
+    c->pool.release(d_pr);
+    const u64 s_reads = h_pr[0], s_bytes = h_pr[1];
+    if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes) return HSK_OK;      // (long reads, a strange index: no estimate, the context's memory decides)
+    // host input: the sample's bytes first (the main run copies them again with its first slab)
+    const u8 *zc = c->zc_src, *h2d = c->h2d_src;
+    if (h2d || zc) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), h2d ? h2d : zc, s_bytes, hipMemcpyDefault, c->stream));
+    // the sample's count must leave no trace in the context: configuration, plan memory, statistics, the host path's pending verdicts
+    const hsk_config cfg0 = c->cfg; const hsk_stats st0 = c->stats; const int flags0 = g_plan_flags;
+    const int a_cap = c->agg_first_cap, a_clean = c->agg_clean_batches, a_calls = c->agg_off_calls; const bool a_off = c->agg_off, a_offw = c->agg_off_wide;
+    const bool cb_off = c->combine_off, cb_veto = c->combine_veto; const int cb_calls = c->combine_off_calls, cb_period = c->combine_off_period, cb_good = c->combine_good_calls, cb_pf = c->combine_prefix_floor, cb_p = c->combine_prefix;
+    const double epk = c->entries_per_kmer;
+    std::future<bool> verdict = std::move(c->roff_check);
+    const bool r_bad = c->roff_bad; const uint32_t *rl_h = c->rlen_host; const uint64_t *ro_h = c->roff_host; u64 *ro_g = c->roff_given;
+    c->zc_src = nullptr; c->h2d_src = nullptr; c->roff_bad = false; c->rlen_host = nullptr; c->roff_host = nullptr; c->roff_given = nullptr;
+    c->cfg.lower_freq = 1; c->cfg.upper_freq = 65535; c->cfg.ntasks = 0;
+    c->cfg.flags = (cfg0.flags | HSK_FLAG_KEEP_DEVICE | HSK_FLAG_NO_COMBINE) & ~HSK_FLAG_PROFILE;
+    g_plan_flags = c->cfg.flags;
+    c->agg_first_cap = 10; c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0;
+    const std::vector<void *> before = c->pool.snapshot();
+    hsk_result tmp; memset(&tmp, 0, sizeof tmp);
+    int rc = run_pipeline<1>(c, d_packed, s_bytes, d_roff, d_rlen, s_reads, 0, &tmp);
+    u64 n1 = 0, n2 = 0, n3 = 0, ds = 0; const u64 ns = tmp.total_kmers;
+    if (rc == HSK_OK && tmp.histo && tmp.histo_len > 3) { n1 = tmp.histo[1]; n2 = tmp.histo[2]; n3 = tmp.histo[3]; ds = tmp.n; }
+    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream); (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); }
+    hsk_result_free(c, &tmp);
+    if (rc != HSK_OK) c->pool.release_all_but(before);
+    c->cfg = cfg0; c->stats = st0; g_plan_flags = flags0;
+    c->agg_first_cap = a_cap; c->agg_clean_batches = a_clean; c->agg_off_calls = a_calls; c->agg_off = a_off; c->agg_off_wide = a_offw;
+    c->combine_off = cb_off; c->combine_veto = cb_veto; c->combine_off_calls = cb_calls; c->combine_off_period = cb_period; c->combine_good_calls = cb_good; c->combine_prefix_floor = cb_pf; c->combine_prefix = cb_p;
+    c->entries_per_kmer = epk; c->vt_shift = 0; c->combine_now = false;
+    c->zc_src = zc; c->h2d_src = h2d; c->roff_check = std::move(verdict); c->roff_bad = r_bad; c->rlen_host = rl_h; c->roff_host = ro_h; c->roff_given = ro_g;
+    { drain_profile_events(c); c->stats = st0; }
+    if (rc != HSK_OK || ns < (1u << 16)) return HSK_OK;                    // (no estimate; an input that breaks the small count will break the real one and report there)
+    PlanEstimate &e = c->est;
+    e.fraction = (double)s_bytes / (double)packed_bytes; e.sample_kmers = ns; e.n1 = n1; e.n2 = n2; e.n3 = n3; e.distinct_sample = ds;
+    double G = 0, lam = 0, Es = (double)n1;
+    if (n2 >= 64 && n3 >= 16 && (double)n2 * 2000.0 > (double)n1) {       // (a genomic component exists: more than one doubleton per 2000 singletons)
+        lam = std::min(30.0, std::max(1e-3, 3.0 * (double)n3 / (double)n2));
+        G = 2.0 * (double)n2 * std::exp(lam) / (lam * lam);
+        G = std::min(G, (double)ds + (double)ds * std::exp(-lam) / std::max(1e-9, 1.0 - std::exp(-lam)));      // (never more genomic k-mers than the sample's distinct ones can stand for)
+        Es = std::max(0.0, (double)n1 - G * lam * std::exp(-lam));
+    }
+    e.lambda_sample = lam;
+    const double D = e.fraction * G * (1.0 - std::exp(-lam / e.fraction)) + Es;
+    e.distinct_per_kmer = std::min(1.0, std::max(D / (double)ns, 1.0 / 65536.0));
+    e.valid = true;
+    e.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (timing_enabled()) fprintf(stderr, "[hsk] plan estimate: sample %.1f MB (%llu k-mers, 1/%.0f of the input), n1 %llu n2 %llu n3 %llu distinct %llu: lambda_s %.3f, %.4f distinct per k-mer (one in %.1f), %.2f ms\n",
+                                  s_bytes / 1048576.0, (unsigned long long)ns, 1.0 / e.fraction, (unsigned long long)n1, (unsigned long long)n2, (unsigned long long)n3, (unsigned long long)ds, lam, e.distinct_per_kmer, 1.0 / e.distinct_per_kmer, e.ms);
+    return HSK_OK;
+}
+
 static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
-                             int64_t rid_base, hsk_result *out)
+                             int64_t rid_base, hsk_result *out, int attempt = 0)
 {
     int rc;
+    if (attempt == 0) c->combine_left_now = false;
+    if (attempt == 0) { rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads); if (rc) return rc; }
+    c->plan_attempt = attempt;                          // (from the third attempt on run_pipeline does not consider the combining extraction at all)
     const std::vector<void *> before = c->pool.snapshot();
     const hsk_stats stats_before = c->stats;
     switch (c->nw) {
@@ -243,8 +335,10 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
         // the statistics describe the attempt that produces the result
         drain_profile_events(c);
         c->stats = stats_before;
-        return dispatch_pipeline(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out);
+        if (attempt >= 3) return fail(c, HSK_ERR_INTERNAL, "the call was started again %d times without settling on a plan", attempt);
+        return dispatch_pipeline(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out, attempt + 1);
     }
+    c->plan_attempt = 0; c->est.valid = false;
     return rc;
 }
 
@@ -406,7 +500,10 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     const bool slab_ingest = zc != nullptr && slabs_env > 1 && packed_bytes >= (32u << 20);
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     static const bool derive_enabled = !(getenv("HSK_DERIVE_OFFSETS") && atoi(getenv("HSK_DERIVE_OFFSETS")) == 0);
-    const bool derive = zc != nullptr && device_check && derive_enabled;       // only the read lengths travel ahead of the scan (see roff_tilesum_kernel)
+    // only the read lengths travel ahead of the scan (see roff_tilesum_kernel).  The host threads' verdict on the derived index is read by the
+    // fast parse (parse_count's scan branch, parse_ingest_pipelined): with the general parse kernels from the start (M > SCAN_MAX_M, HSK_PARSE_FAST=0)
+    // the caller's index travels and is checked on the device like a pageable one
+    const bool derive = zc != nullptr && device_check && derive_enabled && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
     DevInput d;
     u64 *d_given = nullptr, *d_tsum = nullptr;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 5; (void)hipEventRecord(ep.a, c->stream); }
@@ -489,6 +586,7 @@ extern "C" int hsk_stage_destinations(hsk_ctx *c, const uint8_t *packed, uint64_
 {
     if (!c || !dest_off || (cap && !dest)) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
     const int K = c->cfg.kmer_size;
     uint64_t total = 0;
@@ -556,6 +654,7 @@ extern "C" int hsk_stage_task_kmers(hsk_ctx *c, const uint8_t *packed, uint64_t 
     if (!c || !n || (cap && !keys)) return HSK_ERR_INVALID_ARG;
     *n = 0;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
     if (!nreads || !packed_bytes) return HSK_OK;
     DevInput d; rc = upload_input(c, packed, packed_bytes, off, len, nreads, d); if (rc) return rc;
@@ -596,6 +695,7 @@ extern "C" int hsk_stage_sort(hsk_ctx *c, uint64_t *keys, uint64_t *vals, uint64
     if (!c || (n && !keys) || nw < 1 || nw > 3) return HSK_ERR_INVALID_ARG;
     if (n == 0) return HSK_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     switch (nw) {
     case 1: return stage_sort_impl<1>(c, keys, vals, n);
     case 2: return stage_sort_impl<2>(c, keys, vals, n);
@@ -630,6 +730,7 @@ extern "C" int hsk_stage_count_sorted(hsk_ctx *c, const uint64_t *keys, uint64_t
     *n_out = 0;
     if (n == 0) return HSK_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
     switch (nw) {
     case 1: return stage_count_impl<1>(c, keys, n, out_entries, cap, n_out);
     case 2: return stage_count_impl<2>(c, keys, n, out_entries, cap, n_out);

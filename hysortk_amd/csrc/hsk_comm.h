@@ -53,7 +53,10 @@ inline RcclApi *rccl_api(std::string *err)
     // HSK_RCCL_LIB (honoured only when set): another library exporting the same nine entry points, e.g. the stand-in
     // transport of tests/fakerccl that lets the ranks of tests/test_gpu_rccl.py share ONE GPU (RCCL refuses that)
     const char *forced = getenv("HSK_RCCL_LIB");
-    if (forced && *forced) { h = dlopen(forced, RTLD_NOW | RTLD_LOCAL); if (!h) { if (err) *err = std::string("dlopen(HSK_RCCL_LIB=") + forced + ") failed: " + dlerror(); return nullptr; } }
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL); if (!h) { if (err) *err = std::string("dlopen(HSK_RCCL_LIB=") + forced + ") failed: " + dlerror(); return nullptr; }
+        fprintf(stderr, "[hsk] WARNING: collective transport loaded from HSK_RCCL_LIB=%s instead of librccl (a test hook: never set it in production)\n", forced);
+    }
     else for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { if (err) *err = std::string("dlopen(librccl) failed: ") + dlerror(); return nullptr; }
 #define HSK_SYM(field, name) *(void **)(&api.field) = dlsym(h, name); if (!api.field) { if (err) *err = std::string("missing RCCL symbol ") + name; return nullptr; }

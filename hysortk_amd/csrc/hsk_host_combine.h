@@ -31,6 +31,12 @@ static int combine_prefix_for(u64 max_pairs_per_task)
     while (p < COMBINE_PREFIX_MAX && (max_pairs_per_task >> p) > 900) ++p;
     return p;
 }
+// more than one pair per combine_ratio() k-mers: the instance path (break-even measured at one per ~15); HSK_COMBINE_RATIO=1: never leave (measurements)
+static u64 combine_ratio()
+{
+    static const u64 v = getenv("HSK_COMBINE_RATIO") ? (u64)std::max(1, atoi(getenv("HSK_COMBINE_RATIO"))) : 16;
+    return v;
+}
 static u64 combine_bucket_kmers()
 {
     static const u64 v = getenv("HSK_COMBINE_BUCKET") ? (u64)std::max(256, atoi(getenv("HSK_COMBINE_BUCKET"))) : 12288;

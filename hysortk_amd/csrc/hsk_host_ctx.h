@@ -103,6 +103,19 @@ struct HostPool {
 
 struct EvPair { hipEvent_t a, b; int kind; u64 keys; u64 bytes; };
 
+// What a call learns about its input BEFORE it commits to a plan (estimate_plan, hsk_api.hip): the k-mer spectrum of a small prefix of
+// the reads, counted by the instance path, extrapolated to the whole input -- distinct k-mers per k-mer instance is what the combining
+// extraction (pairs per k-mer), the first table of the LDS aggregation (distinct keys per prefix bin) and the decision to aggregate at
+// all depend on.  Valid for the call that made it; the adaptive fields of the context are only the fallback where no estimate is made.
+struct PlanEstimate {
+    bool valid = false;
+    double distinct_per_kmer = 0;      // estimated (distinct canonical k-mers) / (k-mer instances) of the WHOLE input
+    double lambda_sample = 0;          // mean copies per genomic k-mer inside the sample
+    double fraction = 0;               // sample bytes / input bytes
+    u64 sample_kmers = 0, n1 = 0, n2 = 0, n3 = 0, distinct_sample = 0;
+    double ms = 0;                     // host wall clock of the estimate
+};
+
 struct hsk_ctx {
     hsk_config cfg;
     int nw = 1;
@@ -147,11 +160,17 @@ struct hsk_ctx {
     // ... another look after combine_off_period calls: 8, and twice as many every time the look finds the same kind of input again (up
     // to 64: a look costs the call ~2 x, reads with errors should not pay that every eighth call); back to 8 once a call has gone through
     int combine_off_period = 8, combine_good_calls = 0;
-    void leave_combine() { combine_off_period = combine_good_calls ? 8 : std::min(combine_off_period * 2, 64); combine_good_calls = 0; combine_off = true; combine_off_calls = 0; }
+    bool combine_left_now = false;     // ... during THIS call (binding for the attempts that follow, whatever the estimate said)
+    void leave_combine() { combine_left_now = true; combine_off_period = combine_good_calls ? 8 : std::min(combine_off_period * 2, 64); combine_good_calls = 0; combine_off = true; combine_off_calls = 0; }
     u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)
     int combine_prefix_floor = 0;      // ... never below this again (set when a bin beat the last table with fewer bits)
     int combine_prefix = 0;            // key bits of the weighted finish's bins the next batch is planned with (0: the default; follows the pairs per task)
     bool combine_veto = false;         // this call's store turned out to be no use to the combining extraction (too few tasks for a batch ...): the call again, without it
+    PlanEstimate est;                  // this call's estimate (estimate_plan); est.valid decides instead of combine_off / agg_off / agg_first_cap
+    double est_bias = 1.0;             // pairs per k-mer the combining extraction really produced / what the estimate promised, when a call had to leave the plan after all
+    // a call that followed its estimate into the combining extraction and had to start again: estimates like this one are not believed again on this context
+    void distrust_estimate(double ratio) { if (est.valid && est.distinct_per_kmer > 0) est_bias = std::max(est_bias, 1.05 / (est.distinct_per_kmer * ratio)); }
+    int plan_attempt = 0;              // dispatch_pipeline: how often this call has been started again (HSK_RETRY_PLAN); bounded there
     bool forbid_long_way = false;      // heavy-hitter pre-aggregation: a task the aggregating finish cannot handle is reported, not redone
 };
 

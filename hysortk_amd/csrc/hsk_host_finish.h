@@ -233,7 +233,7 @@ static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u
 {
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     const AggArgs &a = p.a;
-    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = records; ep.bytes = records * NW * 8; (void)hipEventRecord(ep.a, c->stream); }
+    EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 2; ep.keys = records; ep.bytes = records * (NW * 8 + (p.weighted ? 8 : 0)); (void)hipEventRecord(ep.a, c->stream); }      // (record bytes READ: keys, and the counts of {k-mer, count} pairs)
     if (NW == 3) {
         if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);

@@ -273,6 +273,9 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
+        // (hsk_count derives the read index only for the fast parse; should a derived index ever arrive here with its verdict still open, a
+        //  wrong guess must not be counted: the call fails instead of trusting lengths and offsets nobody has confirmed)
+        if (c->roff_check.valid() && !c->roff_check.get()) { c->pool.release(d_task_tot); return fail(c, HSK_ERR_INTERNAL, "derived read index reached the general parse unverified and does not match the caller's"); }
         if (c->index_unchecked) {
             c->index_unchecked = false;
             if (h_ovf[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }

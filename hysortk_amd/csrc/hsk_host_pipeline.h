@@ -289,6 +289,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     u64 max_task = 0, total_kmers = 0;
     for (u32 t = 0; t < ntasks; ++t) { finalize_segs(segs[t]); max_task = std::max(max_task, segs[t].nkmers); total_kmers += segs[t].nkmers; }
     out->total_kmers = total_kmers;
+    if (c->est.valid && NW == 1 && !ext && !c->forbid_long_way && max_task) {
+        // distinct keys per 16-bit prefix bin of the largest task, from this call's estimate: the first table of the ladder, or no tables at all
+        // (most bins beyond 2048 slots: four prefix passes + the tile finish; what a batch used to find out the hard way, agg_stage2)
+        const double d = c->est.distinct_per_kmer * (double)max_task / 65536.0;
+        c->agg_first_cap = d <= 600.0 ? AG_LOG2CAP_SMALL : d <= 1250.0 ? AG_LOG2CAP_MEDIUM : AG_LOG2CAP_LARGE;
+        if (d > 1450.0 && !(ex && ex->vt_shift) && !x_src.item) { c->agg_off = true; c->agg_off_calls = 0; }
+    }
 
     // ---- per task: expand, sort, count ---------------------------------------------------------------
     const u32 histo_len = (u32)std::min<int64_t>((int64_t)c->cfg.upper_freq + 1, 65536);    // (U <= 65535 except in the unfiltered pre-aggregation)
@@ -571,6 +578,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 if (combine) {
                     if (!combine_prefix_forced() && slot_prefix[sl] < COMBINE_PREFIX_MAX) c->combine_prefix = c->combine_prefix_floor = COMBINE_PREFIX_MAX;      // once more with the narrowest bins
                     else if (!c->combine_off) c->leave_combine();
+                    c->distrust_estimate((double)combine_ratio());
                     return HSK_RETRY_PLAN;
                 }
             }
@@ -614,8 +622,11 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             // one pair per 25.6 k-mers 102 against 126 ms, one per 6.6 -- reads with 0.3 % errors -- 171 against 138: the tables overflow inside
             // the buckets and the parse side's extra 20 ms buy nothing; at one per sixteen a bucket's table is already 37 % full); the batches of this call finish on the pairs, the next calls take the
             // instance path
-            static const u64 ratio_env = getenv("HSK_COMBINE_RATIO") ? (u64)std::max(1, atoi(getenv("HSK_COMBINE_RATIO"))) : 16;      // (measurements: 1 = never leave)
-            if (bk && bp * ratio_env > bk && !c->combine_off) c->leave_combine();
+            const u64 ratio_env = combine_ratio();
+            if (bk && bp * ratio_env > bk && !c->combine_off) {
+                c->leave_combine();
+                if (c->est.valid) c->est_bias = std::min(8.0, std::max(1.0, ((double)bp / (double)bk) / c->est.distinct_per_kmer));      // (the estimate promised fewer pairs: later estimates on this context are scaled)
+            }
         }
         pt.begin(PH_SORT);
         if (sbatch[sl].active) { if constexpr (NW <= 2) { int rc = sort_batch_prescattered<NW>(c, bt, xs_plan, d_ghist_slot[sl], sbatch[sl]); if (rc) return rc; } }
@@ -834,11 +845,15 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     ResultPriv *rp = new ResultPriv();
     out->priv = rp; out->nw = NW;
     if ((c->agg_off || c->agg_off_wide) && ++c->agg_off_calls >= 8) { c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0; }      // (another look every eighth call: the input may have changed)
-    if (c->combine_off && ++c->combine_off_calls >= c->combine_off_period) { c->combine_off = false; c->combine_off_calls = 0; }
+    if (c->combine_off && ++c->combine_off_calls >= c->combine_off_period) { c->combine_off = false; c->combine_off_calls = 0; c->combine_prefix_floor = 0; }      // (another look: the bin width starts from the default again as well)
     // the combining extraction pays from a few hundred million k-mers on (a bucket order of the supermers comes first); HSK_COMBINE_MIN_BYTES
     // moves the limit (tests: 0)
     static const u64 combine_min = getenv("HSK_COMBINE_MIN_BYTES") ? (u64)atoll(getenv("HSK_COMBINE_MIN_BYTES")) : (64ULL << 20);
-    c->combine_now = NW == 1 && nranks == 1 && !ext && !c->combine_off && !c->combine_veto && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
+    // this call's own estimate of the input (estimate_plan) decides where there is one; the context's memory of earlier calls (combine_off, agg_off) where there is none
+    const bool est = c->est.valid;
+    const bool combine_pays = !c->combine_left_now && (est ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off);
+    if (est && c->agg_off && c->plan_attempt == 0) { c->agg_off = false; c->agg_off_calls = 0; }      // (process_rank decides again, from the estimate and the task sizes)
+    c->combine_now = NW == 1 && nranks == 1 && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
                      c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok;
     c->combine_veto = false;
     // the combining extraction wants buckets of ~12 k k-mers: the parse itself splits every task by the top minimizer bits (virtual
@@ -857,6 +872,13 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records; more real tasks than that: the instance path)
     if (ntasks > 768) c->combine_now = false;
     if (c->combine_now) { u32 sh = 0; while (sh < 4 && ((u64)ntasks << (sh + 1)) <= 768) ++sh; c->vt_shift = sh; }
+    if (c->combine_now && est) {
+        // a task has at most 2^14 buckets (CS_MAX_LOG2NB; 2^(10 + virtual-task bits)): few, large tasks make buckets whose distinct k-mers overflow the
+        // 2048-slot tables again and again (partial pairs: the detour stops paying) -- predicted from the estimate instead of found out by a batch
+        const u32 lg = (u32)std::min<int>(CS_MAX_LOG2NB, CS_MAX_LOCAL + (int)c->vt_shift);
+        const double per_bucket = (double)packed_bytes * 4.0 / (double)ntasks / (double)(1u << lg);
+        if (per_bucket > (double)combine_bucket_kmers() && c->est.distinct_per_kmer * per_bucket > 1400.0) { c->combine_now = false; c->vt_shift = 0; }
+    }
     const u32 vts = c->vt_shift, nvt = ntasks << vts;       // what the parse calls tasks
     std::vector<int32_t> owner(ntasks, 0);
     std::vector<u32> order(ntasks);

@@ -1113,6 +1113,14 @@ __global__ void resolve_pos_rid_kernel(const u64 *sm_gpos, u64 n, const u64 *rof
     }
 }
 
+// the reads that lie completely inside the first `bytes` bytes of the packed buffer: out[0] = their number r, out[1] = roff[r] (plan estimate, hsk_api.hip)
+__global__ void prefix_reads_kernel(const u64 *roff, u64 nreads, u64 bytes, u64 *out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const u64 r = nreads ? find_read(roff, 0, nreads - 1, bytes) : 0;      // the read that holds byte `bytes` (or the last one that starts at or before it)
+    out[0] = r; out[1] = nreads ? roff[r] : 0;
+}
+
 // hsk_count(): the caller's read index must be ascending, non-overlapping and inside the packed buffer (error bit 32)
 __global__ void index_check_kernel(const u64 *roff, const u32 *rlen, u64 nreads, u64 packed_bytes, u32 *err)
 {

@@ -124,3 +124,52 @@ def test_host_paths_through_the_combining_extraction(instance):
     ref = run(dict(spec, calls=["device"]), {"HSK_COMBINE": "0"})[0]
     assert all(r["combine_launches"] > 0 for r in rs)
     assert {r["digest"] for r in rs} == {ref["digest"]}
+
+
+# ---- the plan is chosen inside the call (estimate_plan, hsk_api.hip): ONE call on a fresh context, library defaults (no HSK_COMBINE_MIN_BYTES) ----
+BIG = dict(BASE, ntasks=0, L=1, U=65535, genome=8000000, nreads=1800000, seed=91)            # 68 MB of packed reads, 32x: the combining extraction's own limit is 64 MB
+
+
+@pytest.mark.parametrize("how", ["device", "pinned", "host"])
+def test_first_call_on_clean_deep_reads_takes_the_combining_extraction(how):
+    r = run(dict(BIG, calls=[how]), {})[0]
+    ref = run(dict(BIG, calls=["device"]), {"HSK_COMBINE": "0"})[0]
+    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    assert r["combine_pairs"] * 16 < r["combine_kmers"]
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+
+
+@pytest.mark.parametrize("spec,why", [
+    (dict(error_rate=0.003), "0.3 % substitution errors: one k-mer in eleven is an error k-mer that occurs once"),
+    (dict(error_rate=0.01), "1 % substitution errors"),
+    (dict(error_rate=0.75), "uniform random reads: every k-mer once"),
+    (dict(genome=64000000), "coverage 4: a k-mer has four copies"),
+])
+@pytest.mark.parametrize("how", ["device", "pinned"])
+def test_first_call_never_starts_a_plan_the_input_does_not_pay_for(spec, why, how):
+    """A real client calls kmer_count() once (reference src/hysortk.cpp:36-96): the FIRST call on a fresh context must already take the
+    instance path for inputs with too few copies per k-mer -- combine_kernel is never launched -- and give the same list."""
+    sp = dict(BIG, calls=[how], **spec)
+    r = run(sp, {})[0]
+    ref = run(dict(sp, calls=["device"]), {"HSK_COMBINE": "0", "HSK_PLAN_SAMPLE": "0"})[0]
+    assert r["combine_launches"] == 0 and r["instance_extractions"] > 0, why
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"]), why
+
+
+def test_alternating_inputs_on_one_context_choose_per_call():
+    """clean, noisy, clean on ONE context: every call chooses for its own input (the context's memory of the previous call does not decide)"""
+    import hysortk_amd as H
+    with H.Context(K=31, M=17, L=1, U=65535, profile=True) as ctx:
+        clean = ctx.synth_reads(8000000, 150, 1800000, 5)
+        noisy = ctx.synth_reads(8000000, 150, 1800000, 6, error_rate=0.01)
+        seen = []
+        for dp, nb, do, dl in (clean, noisy, clean, noisy):
+            ctx.stats(reset=True)
+            r = ctx.count_device(dp, nb, do, dl, 1800000)
+            st = ctx.stats(reset=True)
+            seen.append((int(st["combine_launches"]) > 0, len(r)))
+            del r
+        for d in (clean, noisy):
+            ctx.synth_free(d[0], d[2], d[3])
+    assert [s[0] for s in seen] == [True, False, True, False], seen
+    assert seen[0][1] == seen[2][1] and seen[1][1] == seen[3][1]

@@ -209,3 +209,31 @@ def test_pipelined_ingest_with_few_tasks(ntasks):
         H.pinned_free(y)
     assert len(ref) > 100000
     assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off) and np.array_equal(ref.histo, a.histo)
+
+
+def test_pinned_mixed_lengths_with_the_general_parse_k51_m35():
+    """M = 35 (> SCAN_MAX_M) takes the general parse kernels from the start, which never read the host threads' verdict on a derived
+    read index: hsk_count() must not derive the index there.  Pinned reads whose first, middle and last lengths agree while 1 % of the
+    others are shorter (the sample says 'fixed length', which is wrong): same list as from pageable memory."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    n = (1 << 20) + 777
+    packed, off, lens0 = synth.packed_reads(2000000, 150, n, 35)
+    rng = np.random.default_rng(5)
+    lens = lens0.copy()
+    short = rng.choice(np.arange(1, n - 1), n // 100, replace=False)
+    short = short[short != n // 2]
+    lens[short] = 111
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
+    with H.Context(K=51, M=35, L=2, U=200, ntasks=16) as c:
+        a = c.count((pp, po, pl))
+        ref = c.count((packed, off, lens))
+        pl[:] = lens0
+        b = c.count((pp, po, pl))
+        ref_b = c.count((packed, off, lens0))
+    for y in (pp, po, pl):
+        H.pinned_free(y)
+    assert len(ref) > 100000 and int(ref.cnt.sum()) < int(ref_b.cnt.sum())
+    assert np.array_equal(ref.kmers, a.kmers) and np.array_equal(ref.cnt, a.cnt) and np.array_equal(ref.task_off, a.task_off)
+    assert np.array_equal(ref_b.kmers, b.kmers) and np.array_equal(ref_b.cnt, b.cnt)
