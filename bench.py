@@ -304,6 +304,48 @@ def first_call_leg(H, local, genome_len, nreads, seed):
     return out
 
 
+def multi_rank_leg(H, local, name, KK, ext, R, per_rank_bp, ntasks, seed, steps=2):
+    """The N > 1 data path on ONE GPU at scale (hsk_count_loopback_device): R virtual ranks, each holding per_rank_bp of reads sampled from one
+    genome of R x per_rank_bp / 32 bases (the 8-GPU workload's shape: (R-1)/R of the supermers change ranks), the 8-GPU bench's task count;
+    task-size probe, dispatcher, owner-grouped byte-store placement, grouped exchange overlapped with the sort (device copies stand in for RCCL
+    send / recv over xGMI), multi-segment extraction.  The virtual ranks run one after the other, so a rank's device ms IS what one GPU of the
+    8-GPU job spends outside the wire: the per-GPU cost of leaving the single-GPU plan, driver-timed."""
+    G = R * per_rank_bp // COVERAGE
+    NR = per_rank_bp // READ_LEN
+    ctx = H.Context(K=KK, M=M, L=L, U=U, EXT=ext, ntasks=ntasks, device=local, profile=True, keep_device=True)
+    reads = []
+    for r in range(R):
+        dp, nb, do, dl = ctx.synth_reads(G, READ_LEN, NR, seed, first_read=r * NR)
+        reads.append((dp, nb, do, dl, NR))
+    res, owner = ctx.count_loopback_device(reads)          # warm-up: pools
+    del res
+    ctx.stats(reset=True)
+    walls, ranks = [], None
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        res, owner = ctx.count_loopback_device(reads)
+        walls.append(time.perf_counter() - t0)
+        ranks = [dict(r_.info) for r_ in res]
+        del res
+    st = ctx.stats(reset=True)
+    for x in reads:
+        ctx.synth_free(x[0], x[2], x[3])
+    ctx.close()
+    wall = sum(walls) / len(walls)
+    nk_rank = NR * (READ_LEN - KK + 1)
+    per = [{"rank": i, "owned_kmers": r_["total_kmers"], "owned_tasks": int((owner == i).sum()),
+            "ms": {k_[3:]: round(v, 2) for k_, v in r_.items() if k_.startswith("ms_") and k_ != "ms_d2h"}} for i, r_ in enumerate(ranks)]
+    ms_rank = [p_["ms"]["total"] for p_ in per]
+    mean_ms = sum(ms_rank) / R
+    return {"name": name, "K": KK, "EXT": ext, "virtual_ranks": R, "bp_per_rank": per_rank_bp, "kmers_per_rank": nk_rank, "ntasks": len(owner), "steps": steps,
+            "wall_ms_all_ranks": wall * 1e3, "value": R * nk_rank / wall, "unit": "k-mers/s (all virtual ranks on one GPU, one after the other)",
+            "per_rank_device_ms": {"mean": mean_ms, "max": max(ms_rank), "min": min(ms_rank)},
+            "per_gpu_rate_from_device_ms": nk_rank / (max(ms_rank) * 1e-3),
+            "per_gpu_rate_note": "k-mers of one rank's reads / the slowest rank's device ms: what one GPU of the 8-GPU job would sustain if the wire were free "
+                                 "(the exchange here is device copies inside one HBM; over xGMI a rank moves ~1.55 B per k-mer x 7/8 to its peers on seven links)",
+            "ranks": per, "combine_launches": int(st.get("combine_launches", 0)), "exchange": "device-to-device copies in place of ncclSend / ncclRecv (hsk_comm.h plans, unchanged)"}
+
+
 def e2e_host_leg(H, KK, ext, ntasks, local, genome_len, nreads, seed, steps):
     """hsk_count() from a DnaBuffer in pinned host RAM to KmerListS entries in pinned host RAM (what the reference times as
     'Overall kmer counting (Excluding I/O)', src/hysortk.cpp:58,91), L=15 U=40."""
@@ -575,6 +617,13 @@ def main():
                     out["variants"].append(run_variant(H, local, name, note, vk, vext, plan, Lv, Uv, vg, vn, seed, er, 3, refb))
                 except Exception as e:
                     out["variants"].append({"name": name, "error": str(e)[:300]})
+        if world == 1 and not a.no_variants:
+            out["multi_rank_path"] = []
+            for (mname, mk, mext, mbp) in (("k31_8x5Gbp", 31, 0, 5_000_000_000), ("k51_8x2.5Gbp", 51, 0, 2_500_000_000), ("ext_8x1.25Gbp", 31, 1, 1_250_000_000)):
+                try:
+                    out["multi_rank_path"].append(multi_rank_leg(H, local, mname, mk, mext, 8, int(mbp * a.scale), 320, seed + 7))
+                except Exception as e:
+                    out["multi_rank_path"].append({"name": mname, "error": str(e)[:300]})
         if world == 1 and not a.no_variants:
             try:
                 out["first_calls"] = first_call_leg(H, local, int(GENOME_PER_GPU * a.scale) // 2, nreads // 2, seed + 100)

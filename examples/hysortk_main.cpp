@@ -16,7 +16,10 @@ int main(int argc, char **argv)
     std::cout << "KMER_SIZE: " << KMER_SIZE << " MINIMIZER_SIZE: " << MINIMIZER_SIZE << " LOWER_KMER_FREQ: " << LOWER_KMER_FREQ
               << " UPPER_KMER_FREQ: " << UPPER_KMER_FREQ << " EXTENSION: " << EXTENSION << std::endl;
     try {
+        const auto tr = std::chrono::steady_clock::now();
         auto dna = hysortk::read_dna_buffer(fasta, MPI_COMM_WORLD);
+        const double sr = std::chrono::duration<double>(std::chrono::steady_clock::now() - tr).count();
+        std::cout << "read_dna_buffer: " << sr << " s, " << dna->size() << " reads, " << dna->getbufsize() << " packed bytes" << std::endl;
         const auto t0 = std::chrono::steady_clock::now();
         auto list = hysortk::kmer_count(*dna, MPI_COMM_WORLD);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -58,7 +58,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/hsk.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
     "hsk_abi_version", "hsk_device_count", "hsk_host_alloc", "hsk_host_free", "hsk_init", "hsk_destroy", "hsk_strerror", "hsk_last_error", "hsk_config_default",
-    "hsk_count", "hsk_count_device", "hsk_count_loopback", "hsk_result_free", "hsk_result_device_task", "hsk_format_entries", "hsk_get_stats",
+    "hsk_count", "hsk_count_device", "hsk_count_loopback", "hsk_count_loopback_device", "hsk_result_free", "hsk_result_device_task", "hsk_format_entries", "hsk_get_stats",
     "hsk_stage_destinations", "hsk_stage_task_kmers", "hsk_stage_sort", "hsk_stage_count_sorted",
     "hsk_plan_tot_tasks", "hsk_plan_classify", "hsk_plan_dispatch", "hsk_plan_partition_reads", "hsk_plan_exchange",
     "hsk_comm_get_unique_id", "hsk_comm_init", "hsk_comm_destroy", "hsk_comm_selftest",
@@ -105,6 +105,7 @@ def load():
     L.hsk_count.argtypes = [vp, vp, C.c_uint64, u64p, vp, C.c_uint64, C.c_int64, C.POINTER(Result)]
     L.hsk_count_device.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_int64, C.POINTER(Result)]
     L.hsk_count_loopback.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(Result), vp, C.c_int32]
+    L.hsk_count_loopback_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(Result), vp, C.c_int32]
     L.hsk_result_free.argtypes = [vp, C.POINTER(Result)]
     L.hsk_result_free.restype = None
     L.hsk_result_device_task.argtypes = [C.POINTER(Result), C.c_int32] + [vp] * 7

@@ -385,6 +385,18 @@ class Context:
         res = [self._wrap(outs[r]) for r in range(R)]
         return res, owner[:nt].copy()
 
+    def count_loopback_device(self, reads, wrap=True):
+        """The same with every virtual rank's reads resident in HBM: reads = [(d_packed, packed_bytes, d_off, d_len, nreads)] as synth_reads
+        returns them.  Returns ([KmerList (or DeviceResult with keep_device) per rank], owner table)."""
+        R = len(reads)
+        PP = (C.c_void_p * R)(*[r[0] for r in reads]); OP = (C.c_void_p * R)(*[r[2] for r in reads]); LP = (C.c_void_p * R)(*[r[3] for r in reads])
+        nb = np.array([r[1] for r in reads], dtype=np.uint64); nr = np.array([r[4] for r in reads], dtype=np.uint64)
+        outs = (_lib.Result * R)()
+        owner = np.zeros(1024, dtype=np.int32)
+        self._check(self.lib.hsk_count_loopback_device(self.h, R, PP, _p(nb), OP, LP, _p(nr), outs, _p(owner), owner.size))
+        nt = int(outs[0].ntasks)
+        return [self._wrap(outs[r]) for r in range(R)], owner[:nt].copy()
+
     def stats(self, reset=True):
         s = _lib.Stats()
         self._check(self.lib.hsk_get_stats(self.h, C.byref(s), 1 if reset else 0))

@@ -36,6 +36,7 @@
 #include "hsk_agg.h"
 #include "hsk_combine.h"
 #include "hsk_heavy.h"
+#include "hsk_estimate.h"
 #include "hsk_synth.h"
 #include "hsk_plan.h"
 #include "hsk_comm.h"
@@ -221,17 +222,19 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 
 // ------------------------------------------------------------------------------------------------
 // The plan is chosen INSIDE the call (hysortk::kmer_count() is called once per process, reference src/hysortk.cpp:36-96: there is
-// no "next call" that could profit from what this one learned).  Before anything is parsed, the reads that lie inside the first
-// 1/64 of the packed buffer (4 - 64 MB) are counted by the instance path with L = 1: a complete, small hsk_count_device() whose
-// histogram gives the sample's k-mer spectrum.  Two components explain it: genomic k-mers, Poisson with mean lambda_s copies inside
-// the sample (lambda_s = 3 n3 / n2, their number G = 2 n2 exp(lambda_s) / lambda_s^2 -- doubletons and tripletons are nearly free of
-// sequencing errors), and k-mers that occur once whatever the depth (errors, a uniform input): E_s = n1 - G lambda_s exp(-lambda_s).
-// In the whole input (1 / f times the sample) the first kind is seen at least once with probability 1 - exp(-lambda_s / f), the
-// second kind grows with the input:   distinct per k-mer = (f G (1 - exp(-lambda_s / f)) + E_s) / N_s.
-// Error-free 32x reads: 1 / 25.8 (the combining extraction then writes one pair per 25.6 k-mers); 0.3 % substitution errors: ~0.13;
-// uniform reads: 1.  Reads in genome order (a sorted alignment turned back into reads) make the prefix deeper than the model thinks and
-// the first term smaller than it is; the second term, which is what moves the decision for deep data, is unaffected.
-// HSK_PLAN_SAMPLE=0 turns the estimate off (the context's memory of earlier calls decides, as in rounds 2-3).
+// no "next call" that could profit from what this one learned).  Before anything is parsed, a sketch of the input is counted
+// (hsk_estimate.h: the reads inside the first 1/64 of the packed buffer, 1/32 of their canonical k-mers by hash, a global table):
+// n1, n2, n3 = chosen k-mers seen once, twice, three times in the sample.  Two components explain them: genomic k-mers, Poisson with
+// mean lambda_s copies inside the sample (lambda_s = 3 n3 / n2, their number G = 2 n2 exp(lambda_s) / lambda_s^2 -- doubletons and
+// tripletons are nearly free of sequencing errors), and k-mers that occur once whatever the depth (errors, a uniform input):
+// E_s = n1 - G lambda_s exp(-lambda_s).  In the whole input (1 / f times the sample) the first kind is seen at least once with
+// probability 1 - exp(-lambda_s / f), the second kind grows with the input:
+//     distinct per k-mer = (f G (1 - exp(-lambda_s / f)) + E_s) / N_s.
+// Measured on the 10 Gbp workload: error-free 32x reads 0.039 (the combining extraction then writes one pair per 25.6 k-mers), 0.3 %
+// substitution errors 0.13, 1 % 0.31, uniform reads 1.0.  Reads in genome order (a sorted alignment turned back into reads) make the
+// prefix deeper than the model thinks and the first term smaller than it is; the second term, which is what moves the decision for
+// deep data, is unaffected.  Cost: two small kernels and one wait.  HSK_PLAN_SAMPLE=0 turns the estimate off (the context's memory of
+// earlier calls decides, as in rounds 2-3).
 // ------------------------------------------------------------------------------------------------
 static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads)
 {
@@ -242,60 +245,40 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     if (!enabled || c->comm.active() || c->nw != 1 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;
     if (c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT)) return HSK_OK;         // nothing to choose
     const auto t0 = std::chrono::steady_clock::now();
-    if (c->index_unchecked) {
-        // the sample goes through the whole pipeline: the device-side verdict on the caller's read index first (parse_count would read it after the scan)
-        u32 *h = (u32 *)((char *)c->pinned + c->pinned_bytes - 320);
-        HIPCHK(c, hipMemcpyAsync(h + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hsk_sync(c, c->stream));
-        c->index_unchecked = false;
-        if (h[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }
-    }
     const u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);
-    u64 *d_pr; DALLOC(c, d_pr, u64 *, 256);
-    u64 *h_pr = (u64 *)((char *)c->pinned + c->pinned_bytes - 512);
-    hipLaunchKernelGGL(prefix_reads_kernel, dim3(1), dim3(64), 0, c->stream, d_roff, nreads, want, d_pr);
-    HIPCHK(c, hipMemcpyAsync(h_pr, d_pr, 16, hipMemcpyDeviceToHost, c->stream));
+    const u64 exp_ins = want * 4 / (1ULL << EST_SELECT_BITS) + 1024;
+    u64 cap = 1ULL << 16; while (cap < exp_ins * 4) cap <<= 1;
+    unsigned long long *d_keys, *d_out; u32 *d_cnts;
+    DALLOC(c, d_keys, unsigned long long *, cap * 8); DALLOC(c, d_cnts, u32 *, cap * 4); DALLOC(c, d_out, unsigned long long *, 256);
+    auto release = [&]() { c->pool.release(d_keys); c->pool.release(d_cnts); c->pool.release(d_out); };
+    HIPCHK(c, hipMemsetAsync(d_keys, 0, cap * 8, c->stream)); HIPCHK(c, hipMemsetAsync(d_cnts, 0, cap * 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_out, 0, 256, c->stream));
+    // the reads that lie completely inside the first `want` bytes (found on the device: the read index of a device-resident input is not on the host)
+    unsigned long long *h_out = (unsigned long long *)((char *)c->pinned + c->pinned_bytes - 512);
+    hipLaunchKernelGGL(prefix_reads_kernel, dim3(1), dim3(64), 0, c->stream, d_roff, nreads, want, (u64 *)(d_out + 8));
+    HIPCHK(c, hipMemcpyAsync(h_out + 8, d_out + 8, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hsk_sync(c, c->stream));
-    c->pool.release(d_pr);
-    const u64 s_reads = h_pr[0], s_bytes = h_pr[1];
-    if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes) return HSK_OK;      // (long reads, a strange index: no estimate, the context's memory decides)
+    const u64 s_reads = h_out[8], s_bytes = h_out[9];
+    if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes || s_bytes > want + (1u << 20)) { release(); return HSK_OK; }      // (very long reads, a strange index: no estimate, the context's memory decides)
     // host input: the sample's bytes first (the main run copies them again with its first slab)
-    const u8 *zc = c->zc_src, *h2d = c->h2d_src;
-    if (h2d || zc) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), h2d ? h2d : zc, s_bytes, hipMemcpyDefault, c->stream));
-    // the sample's count must leave no trace in the context: configuration, plan memory, statistics, the host path's pending verdicts
-    const hsk_config cfg0 = c->cfg; const hsk_stats st0 = c->stats; const int flags0 = g_plan_flags;
-    const int a_cap = c->agg_first_cap, a_clean = c->agg_clean_batches, a_calls = c->agg_off_calls; const bool a_off = c->agg_off, a_offw = c->agg_off_wide;
-    const bool cb_off = c->combine_off, cb_veto = c->combine_veto; const int cb_calls = c->combine_off_calls, cb_period = c->combine_off_period, cb_good = c->combine_good_calls, cb_pf = c->combine_prefix_floor, cb_p = c->combine_prefix;
-    const double epk = c->entries_per_kmer;
-    std::future<bool> verdict = std::move(c->roff_check);
-    const bool r_bad = c->roff_bad; const uint32_t *rl_h = c->rlen_host; const uint64_t *ro_h = c->roff_host; u64 *ro_g = c->roff_given;
-    c->zc_src = nullptr; c->h2d_src = nullptr; c->roff_bad = false; c->rlen_host = nullptr; c->roff_host = nullptr; c->roff_given = nullptr;
-    c->cfg.lower_freq = 1; c->cfg.upper_freq = 65535; c->cfg.ntasks = 0;
-    c->cfg.flags = (cfg0.flags | HSK_FLAG_KEEP_DEVICE | HSK_FLAG_NO_COMBINE) & ~HSK_FLAG_PROFILE;
-    g_plan_flags = c->cfg.flags;
-    c->agg_first_cap = 10; c->agg_off = c->agg_off_wide = false; c->agg_off_calls = 0;
-    const std::vector<void *> before = c->pool.snapshot();
-    hsk_result tmp; memset(&tmp, 0, sizeof tmp);
-    int rc = run_pipeline<1>(c, d_packed, s_bytes, d_roff, d_rlen, s_reads, 0, &tmp);
-    u64 n1 = 0, n2 = 0, n3 = 0, ds = 0; const u64 ns = tmp.total_kmers;
-    if (rc == HSK_OK && tmp.histo && tmp.histo_len > 3) { n1 = tmp.histo[1]; n2 = tmp.histo[2]; n3 = tmp.histo[3]; ds = tmp.n; }
-    if (rc != HSK_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream); (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); }
-    hsk_result_free(c, &tmp);
-    if (rc != HSK_OK) c->pool.release_all_but(before);
-    c->cfg = cfg0; c->stats = st0; g_plan_flags = flags0;
-    c->agg_first_cap = a_cap; c->agg_clean_batches = a_clean; c->agg_off_calls = a_calls; c->agg_off = a_off; c->agg_off_wide = a_offw;
-    c->combine_off = cb_off; c->combine_veto = cb_veto; c->combine_off_calls = cb_calls; c->combine_off_period = cb_period; c->combine_good_calls = cb_good; c->combine_prefix_floor = cb_pf; c->combine_prefix = cb_p;
-    c->entries_per_kmer = epk; c->vt_shift = 0; c->combine_now = false;
-    c->zc_src = zc; c->h2d_src = h2d; c->roff_check = std::move(verdict); c->roff_bad = r_bad; c->rlen_host = rl_h; c->roff_host = ro_h; c->roff_given = ro_g;
-    { drain_profile_events(c); c->stats = st0; }
-    if (rc != HSK_OK || ns < (1u << 16)) return HSK_OK;                    // (no estimate; an input that breaks the small count will break the real one and report there)
+    if (c->h2d_src || c->zc_src) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), c->h2d_src ? c->h2d_src : c->zc_src, s_bytes, hipMemcpyDefault, c->stream));
+    EstimateArgs ea; memset(&ea, 0, sizeof ea);
+    ea.packed = d_packed; ea.roff = d_roff; ea.rlen = d_rlen; ea.nreads = s_reads; ea.positions = s_bytes * 4; ea.k = c->cfg.kmer_size;
+    ea.keys = d_keys; ea.cnts = d_cnts; ea.cap_mask = cap - 1; ea.out = d_out;
+    const u64 nthreads = (ea.positions + EST_SPAN - 1) / EST_SPAN;
+    hipLaunchKernelGGL(estimate_insert_kernel, dim3((u32)((nthreads + EST_THREADS - 1) / EST_THREADS)), dim3(EST_THREADS), 0, c->stream, ea);
+    hipLaunchKernelGGL(estimate_hist_kernel, dim3((u32)std::min<u64>(cap / EST_THREADS, 4096)), dim3(EST_THREADS), 0, c->stream, ea);
+    HIPCHK(c, hipMemcpyAsync(h_out, d_out, 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
+    release();                                                              // (stream-ordered reuse: the kernels above are done)
+    const u64 lost = h_out[0], n1 = h_out[1], n2 = h_out[2], n3 = h_out[3], ds = h_out[4], ns = h_out[5];
+    if (lost || ns < (1u << 14)) return HSK_OK;                            // (no estimate)
     PlanEstimate &e = c->est;
     e.fraction = (double)s_bytes / (double)packed_bytes; e.sample_kmers = ns; e.n1 = n1; e.n2 = n2; e.n3 = n3; e.distinct_sample = ds;
     double G = 0, lam = 0, Es = (double)n1;
     if (n2 >= 64 && n3 >= 16 && (double)n2 * 2000.0 > (double)n1) {       // (a genomic component exists: more than one doubleton per 2000 singletons)
         lam = std::min(30.0, std::max(1e-3, 3.0 * (double)n3 / (double)n2));
         G = 2.0 * (double)n2 * std::exp(lam) / (lam * lam);
-        G = std::min(G, (double)ds + (double)ds * std::exp(-lam) / std::max(1e-9, 1.0 - std::exp(-lam)));      // (never more genomic k-mers than the sample's distinct ones can stand for)
+        G = std::min(G, (double)ds / std::max(1e-9, 1.0 - std::exp(-lam)));      // (never more genomic k-mers than the sample's distinct ones can stand for)
         Es = std::max(0.0, (double)n1 - G * lam * std::exp(-lam));
     }
     e.lambda_sample = lam;
@@ -303,8 +286,8 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     e.distinct_per_kmer = std::min(1.0, std::max(D / (double)ns, 1.0 / 65536.0));
     e.valid = true;
     e.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (timing_enabled()) fprintf(stderr, "[hsk] plan estimate: sample %.1f MB (%llu k-mers, 1/%.0f of the input), n1 %llu n2 %llu n3 %llu distinct %llu: lambda_s %.3f, %.4f distinct per k-mer (one in %.1f), %.2f ms\n",
-                                  s_bytes / 1048576.0, (unsigned long long)ns, 1.0 / e.fraction, (unsigned long long)n1, (unsigned long long)n2, (unsigned long long)n3, (unsigned long long)ds, lam, e.distinct_per_kmer, 1.0 / e.distinct_per_kmer, e.ms);
+    if (timing_enabled()) fprintf(stderr, "[hsk] plan estimate: sample %.1f MB (1/%.0f of the input), %llu chosen k-mer instances, n1 %llu n2 %llu n3 %llu distinct %llu: lambda_s %.3f, %.4f distinct per k-mer (one in %.1f), %.2f ms\n",
+                                  s_bytes / 1048576.0, 1.0 / e.fraction, (unsigned long long)ns, (unsigned long long)n1, (unsigned long long)n2, (unsigned long long)n3, (unsigned long long)ds, lam, e.distinct_per_kmer, 1.0 / e.distinct_per_kmer, e.ms);
     return HSK_OK;
 }
 
@@ -575,6 +558,49 @@ extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *
         c->pool.release_all_but(before);
         (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
     }
+    return rc;
+}
+
+// the same with every virtual rank's reads already resident in HBM (full-size runs of the multi-rank data path: tests/test_gpu_multirank.py,
+// bench.py variants[multi_rank_path]); d_off[r] has nreads[r] entries
+extern "C" int hsk_count_loopback_device(hsk_ctx *c, int nranks, const void *const *d_packed, const uint64_t *packed_bytes, const void *const *d_off,
+                                         const void *const *d_len, const uint64_t *nreads, hsk_result *outs, int32_t *owner_out, int32_t owner_capacity)
+{
+    if (!c || nranks < 1 || nranks > 64 || !d_packed || !packed_bytes || !d_off || !d_len || !nreads || !outs) return HSK_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    g_plan_flags = c->cfg.flags;
+    std::vector<DevInput> in(nranks);
+    std::vector<u64 *> roffs(nranks, nullptr);
+    u64 *stage = (u64 *)((char *)c->pinned + (256u << 10));                   // (pinned staging: one end offset per rank)
+    int rc = HSK_OK;
+    for (int r = 0; r < nranks && rc == HSK_OK; ++r) {
+        if (((uintptr_t)d_packed[r] & 3) != 0) { rc = fail(c, HSK_ERR_INVALID_ARG, "d_packed must be 4-byte aligned"); break; }
+        roffs[r] = (u64 *)c->pool.alloc((nreads[r] + 1) * 8);
+        if (!roffs[r]) { rc = fail(c, HSK_ERR_OOM, "read offsets of rank %d", r); break; }
+        if (nreads[r]) HIPCHK(c, hipMemcpyAsync(roffs[r], d_off[r], nreads[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+        stage[r] = packed_bytes[r];
+        HIPCHK(c, hipMemcpyAsync(roffs[r] + nreads[r], stage + r, 8, hipMemcpyHostToDevice, c->stream));
+        in[r].packed = (u8 *)const_cast<void *>(d_packed[r]); in[r].roff = roffs[r]; in[r].rlen = (u32 *)const_cast<void *>(d_len[r]);
+    }
+    u32 ntasks = 0;
+    std::vector<int32_t> owner(HSK_MAX_TASKS, 0);
+    const std::vector<void *> before = c->pool.snapshot();
+    if (rc == HSK_OK) {
+        switch (c->nw) {
+        case 1: rc = run_loopback<1>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        case 2: rc = run_loopback<2>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        default: rc = run_loopback<3>(c, nranks, in.data(), packed_bytes, nreads, outs, owner.data(), &ntasks); break;
+        }
+    }
+    if (rc == HSK_OK && owner_out) { if ((u32)owner_capacity < ntasks) rc = HSK_ERR_INVALID_ARG; else memcpy(owner_out, owner.data(), sizeof(int32_t) * ntasks); }
+    if (rc != HSK_OK) {
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamSynchronize(c->d2h_stream);
+        for (int r = 0; r < nranks; ++r) hsk_result_free(c, &outs[r]);
+        c->pool.release_all_but(before);
+        (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    for (u64 *p : roffs) c->pool.release(p);
     return rc;
 }
 

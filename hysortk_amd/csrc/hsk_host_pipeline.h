@@ -1119,8 +1119,15 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<u64> bytes(ntasks, 0);
     std::vector<ParseJob> jobs(R);
     auto release_jobs = [&]() { for (auto &j : jobs) parse_release(c, j); };
+    // per-rank device time of the parse (hash + count, then placement + byte store): outs[r].ms_parse
+    EvList tev(c);
+    std::vector<hipEvent_t> e0(R), e1(R), e2(R), e3(R);
+    for (int r = 0; r < R; ++r) { e0[r] = tev.get(); e1[r] = tev.get(); e2[r] = tev.get(); e3[r] = tev.get(); }
+    auto parse_ms = [&](int r) { float a = 0, b = 0; (void)hipEventElapsedTime(&a, e0[r], e1[r]); (void)hipEventElapsedTime(&b, e2[r], e3[r]); return (double)a + (double)b; };
     for (int r = 0; r < R; ++r) {
+        (void)hipEventRecord(e0[r], c->stream);
         int rc = parse_count(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, jobs[r]);
+        (void)hipEventRecord(e1[r], c->stream);
         if (rc) { release_jobs(); return rc; }
         for (u32 t = 0; t < ntasks; ++t) bytes[t] += jobs[r].task_tot[3 * t + 1] + jobs[r].task_tot[3 * t] * (ext ? 9 : 1);
     }
@@ -1163,10 +1170,12 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<SupermerStore> st(R);
     std::vector<u64> M((size_t)R * ntasks * 3, 0);
     for (int r = 0; r < R; ++r) {
+        (void)hipEventRecord(e2[r], c->stream);
         int rc = parse_place(c, jobs[r], order, st[r], any_heavy ? &is_heavy : nullptr, R > 1);
         parse_release(c, jobs[r]);
         if (rc) { release_jobs(); return rc; }
         rc = pack_store_bytes(c, st[r], source_from_packed(in[r].packed, packed_bytes[r], st[r].sm_gpos), !overlap_enabled()); if (rc) { release_jobs(); return rc; }
+        (void)hipEventRecord(e3[r], c->stream);
         for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)r * ntasks * 3 + i] = st[r].task_tot[i];
     }
     // 2b. the k-mer lists of the heavy tasks go to their owners (device copies here, send/recv in run_pipeline)
@@ -1206,6 +1215,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             PhaseTimer pt(c);
             ProcExtra ex; ex.heavy_in = &hin[r];
             rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r], &ex);
+            if (rc_all == HSK_OK) { outs[r].ms_parse = parse_ms(r); outs[r].ms_total = outs[r].ms_parse + outs[r].ms_exchange + outs[r].ms_extract + outs[r].ms_sort + outs[r].ms_count + outs[r].ms_d2h; }
         }
         for (int r = 0; r < R; ++r) free_store(c, st[r]);
         free_hin();
@@ -1243,6 +1253,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         int rc = process_rank<NW>(c, ntasks, owner, r, segs[r], xb[r].len, source_from_bytes(xb[r].bytes, xb[r].nbytes), xb[r].pos, xb[r].rid, &outs[r], rp, pt, false, nullptr, &ex);
         xb[r].release(c->pool);
         if (rc) { free_hin(); return rc; }
+        outs[r].ms_parse = parse_ms(r); outs[r].ms_total = outs[r].ms_parse + outs[r].ms_exchange + outs[r].ms_extract + outs[r].ms_sort + outs[r].ms_count + outs[r].ms_d2h;
     }
     free_hin();
     return HSK_OK;

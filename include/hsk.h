@@ -197,6 +197,13 @@ int hsk_count_loopback(hsk_ctx *ctx, int nranks, const uint8_t *const *packed, c
                        const uint64_t *const *read_byte_off, const uint32_t *const *read_len, const uint64_t *nreads,
                        hsk_result *outs, int32_t *owner_out, int32_t owner_capacity);
 
+/* The same with every virtual rank's reads already resident in HBM (d_read_byte_off[r] has nreads[r] entries): full-size runs of the
+ * multi-rank data path on one GPU.  outs[r].ms_parse / ms_exchange / ms_extract / ms_sort / ms_count / ms_total are rank r's device
+ * times (the virtual ranks run one after the other). */
+int hsk_count_loopback_device(hsk_ctx *ctx, int nranks, const void *const *d_packed, const uint64_t *packed_bytes,
+                              const void *const *d_read_byte_off, const void *const *d_read_len, const uint64_t *nreads,
+                              hsk_result *outs, int32_t *owner_out, int32_t owner_capacity);
+
 /* ctx == NULL is allowed when the context is already destroyed: a result outlives its context (its pinned host blocks belong to the
  * result; hsk_destroy frees only the context's cache of released blocks). */
 void hsk_result_free(hsk_ctx *ctx, hsk_result *res);

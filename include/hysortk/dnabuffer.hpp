@@ -11,6 +11,7 @@
 #include <cassert>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <vector>
 #include "../hsk.h"
 #include "dnaseq.hpp"
@@ -28,6 +29,17 @@ public:
             seqs_.emplace_back(readlens[i], buf_ + head_);
             head_ += DnaSeq::bytesneeded(readlens[i]);
         }
+    }
+
+    // a buffer of `bufsize` bytes whose packed bytes `fill(uint8_t *)` writes in one go (read_dna_buffer: one device-to-host copy of the
+    // reads hsk_pack_fasta packed on the GPU); the reads' views follow from their lengths (back to back, every read on a byte boundary)
+    template <class Fill>
+    DnaBuffer(size_t bufsize, const std::vector<size_t> &readlens, Fill &&fill) : head_(0), cap_(bufsize), buf_(allocate(bufsize, pinned_))
+    {
+        fill(buf_);
+        seqs_.reserve(readlens.size());
+        for (size_t l : readlens) { seqs_.emplace_back(l, buf_ + head_); head_ += DnaSeq::bytesneeded(l); }
+        assert(head_ <= cap_);
     }
 
     DnaBuffer(const DnaBuffer &o) : head_(o.head_), cap_(o.cap_), buf_(allocate(o.cap_, pinned_))
@@ -60,6 +72,17 @@ public:
         if (count == 0) return 0;
         const DnaSeq &last = seqs_[start + count - 1];
         return static_cast<size_t>((last.data() + last.numbytes()) - seqs_[start].data());
+    }
+
+    // every read as ASCII, one per line (reference src/dnabuffer.cpp:42-52)
+    std::string getasciifilecontents() const
+    {
+        std::string out;
+        size_t total = 0;
+        for (const DnaSeq &s : seqs_) total += s.size() + 1;
+        out.reserve(total);
+        for (const DnaSeq &s : seqs_) { out += s.ascii(); out.push_back('\n'); }
+        return out;
     }
 
     static size_t computebufsize(const std::vector<size_t> &seqlens)

@@ -20,6 +20,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include "../hsk.h"
 #include "compiletime.h"
 #include "dnabuffer.hpp"
@@ -98,8 +101,27 @@ inline hsk_ctx *context(MPI_Comm comm)
     return ctx;
 }
 
-struct FaiRecord { size_t len, pos, bases; };
+struct FaiRecord { size_t len, pos, bases, width; };            // .fai columns 2-5 (width = bytes per line incl. the line break; 0: not given, bases + 1 as the reference assumes)
 
+} // namespace detail
+
+namespace detail {
+// read-only mapping of the byte range [a, b) of a file (the FASTA records of this rank)
+struct MappedFile {
+    void *base = nullptr; size_t maplen = 0, skip = 0; int fd = -1;
+    MappedFile(const std::string &path, size_t a, size_t b)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE), a0 = a / page * page;
+        skip = a - a0; maplen = b - a0;
+        base = ::mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)a0);
+        if (base == MAP_FAILED) { ::close(fd); base = nullptr; throw std::runtime_error("cannot map " + path); }
+    }
+    const char *text() const { return static_cast<const char *>(base) + skip; }
+    ~MappedFile() { if (base) ::munmap(base, maplen); if (fd >= 0) ::close(fd); }
+    MappedFile(const MappedFile &) = delete; MappedFile &operator=(const MappedFile &) = delete;
+};
 } // namespace detail
 
 // FASTA + .fai -> the calling rank's DnaBuffer (contiguous run of records balanced by bases).
@@ -114,7 +136,7 @@ inline std::shared_ptr<DnaBuffer> read_dna_buffer(const std::string &fasta_fname
         while (std::getline(fai, line)) {
             std::istringstream is(line);
             std::string name; detail::FaiRecord rec{};
-            if (is >> name >> rec.len >> rec.pos >> rec.bases) recs.push_back(rec);
+            if (is >> name >> rec.len >> rec.pos >> rec.bases) { if (!(is >> rec.width)) rec.width = rec.bases + 1; recs.push_back(rec); }
         }
     }
     std::vector<uint64_t> lens(recs.size()), counts(r.size, 0);
@@ -126,6 +148,30 @@ inline std::shared_ptr<DnaBuffer> read_dna_buffer(const std::string &fasta_fname
     const size_t mine = counts[r.rank];
     std::vector<size_t> mylens(mine);
     for (size_t i = 0; i < mine; ++i) mylens[i] = recs[first + i].len;
+    // Files of some size are packed on the GPU (hsk_pack_fasta: the records' text is mapped and uploaded once, one lane per packed byte
+    // gathers its four bases across the line breaks, same bytes as DnaSeq's packer incl. the code-4 spill) and come back as ONE copy into
+    // the (pinned) DnaBuffer -- the host loop below packs ~50 Mbp/s, the path it feeds counts 60 Gbp/s.  HSK_HOST_INGEST=1 keeps the host loop.
+    if (mine > 0) {
+        const detail::FaiRecord &l = recs[first + mine - 1];
+        const size_t nl = l.bases ? (l.len + l.bases - 1) / l.bases : 0;
+        const size_t span0 = recs[first].pos, span1 = l.len ? l.pos + (l.bases ? (nl - 1) * l.width + (l.len - (nl - 1) * l.bases) : l.len) : l.pos;
+        const char *hi = std::getenv("HSK_HOST_INGEST");
+        bool small_len = true; for (size_t i = 0; i < mine; ++i) if (mylens[i] >> 32) small_len = false;
+        if (span1 > span0 && span1 - span0 >= (size_t(16) << 20) && small_len && !(hi && atoi(hi) != 0) && hsk_device_count() > 0) {
+            hsk_ctx *ctx = detail::context(comm);
+            detail::MappedFile mf(fasta_fname, span0, span1);
+            std::vector<uint64_t> pos(mine); std::vector<uint32_t> rl(mine), lb(mine), lw(mine);
+            for (size_t i = 0; i < mine; ++i) { const detail::FaiRecord &q = recs[first + i]; pos[i] = q.pos - span0; rl[i] = (uint32_t)q.len; lb[i] = (uint32_t)q.bases; lw[i] = (uint32_t)q.width; }
+            void *dp = nullptr, *doff = nullptr, *dlen = nullptr; uint64_t pb = 0;
+            detail::check(hsk_pack_fasta(ctx, mf.text(), span1 - span0, pos.data(), rl.data(), lb.data(), lw.data(), mine, &dp, &pb, &doff, &dlen), ctx, "hsk_pack_fasta");
+            std::shared_ptr<DnaBuffer> dbuf;
+            try {
+                dbuf = std::make_shared<DnaBuffer>(DnaBuffer::computebufsize(mylens), mylens, [&](uint8_t *dst) { detail::check(hsk_memcpy_d2h(ctx, dst, dp, pb), ctx, "hsk_memcpy_d2h"); });
+            } catch (...) { hsk_synth_free(ctx, dp, doff, dlen); throw; }
+            hsk_synth_free(ctx, dp, doff, dlen);
+            return dbuf;
+        }
+    }
     auto buf = std::make_shared<DnaBuffer>(DnaBuffer::computebufsize(mylens));
     std::ifstream fa(fasta_fname, std::ios::binary);
     if (!fa) throw std::runtime_error("cannot open " + fasta_fname);

@@ -142,4 +142,5 @@ typedef std::vector<KmerListEntryS> KmerListS;
 
 namespace std {
 template <int N> struct hash<hysortk::Kmer<N>> { size_t operator()(const hysortk::Kmer<N> &k) const { return k.GetHash(); } };
+template <int N> struct less<hysortk::Kmer<N>> { bool operator()(const hysortk::Kmer<N> &a, const hysortk::Kmer<N> &b) const { return a < b; } };      // reference include/kmer.hpp:96-102
 } // namespace std

@@ -160,3 +160,94 @@ def test_loopback_heavy_hitter_tasks(R, ntasks, K):
         assert H.histogram_text(kl.histo) == O.histogram_text(ores.cnt)
         total += len(kl)
     assert total > 1000 and max(int(kl.cnt.max()) for kl in res if len(kl)) > 1000    # the repeat's k-mers made it through the merge
+
+
+# ---- the 8-GPU configurations' per-GPU share through the multi-rank data path at full size, on one GPU ---------------------------
+def _loopback_full(H, K, EXT, R, G, NR, ntasks, seed=20251003):
+    """R virtual ranks, each holding NR reads sampled from ONE genome of G bases (bench.py's N > 1 workload): per-rank results in
+    host memory + the owner table + per-task oracle digests over ALL reads (global read ids)."""
+    from oracle import hsk_oracle as O
+    RL = 150
+    want_n = np.zeros(ntasks, np.uint64); want_mix = np.zeros(ntasks, np.uint64)
+    with H.Context(K=K, M=17, L=1, U=65535, EXT=EXT, ntasks=ntasks, profile=True) as c:
+        reads = []
+        for r in range(R):
+            dp, nb, do, dl = c.synth_reads(G, RL, NR, seed, first_read=r * NR)
+            reads.append((dp, nb, do, dl, NR))
+        res, owner = c.count_loopback_device(reads)
+        st = c.stats()
+        off = np.arange(NR, dtype=np.uint64) * np.uint64((RL + 3) // 4)
+        lens = np.full(NR, RL, dtype=np.uint32)
+        for r in range(R):
+            packed = c.d2h(reads[r][0], reads[r][1])
+            n, mix = O.task_digests(packed, off, lens, k=K, m=17, ext=EXT, ntasks=ntasks, rid_base=r * NR)
+            with np.errstate(over="ignore"):
+                want_n += n; want_mix += mix
+            del packed
+        for x in reads:
+            c.synth_free(x[0], x[2], x[3])
+    return res, owner, want_n, want_mix, st
+
+
+def _check_ranks_against_digests(res, owner, want_n, want_mix, R, nw, ext):
+    from oracle import hsk_oracle as O
+    ntasks = len(owner)
+    seen = np.zeros(ntasks, bool)
+    for r, kl in enumerate(res):
+        pay = (kl.payload_off, kl.pos, kl.rid) if ext else None
+        got_n, got_mix = O.entries_digests(kl.kmers, kl.cnt, kl.task_off, payload=pay)
+        mine = owner == r
+        assert not np.any(got_n[~mine]), "a rank returned entries of a task it does not own"
+        assert np.array_equal(got_n[mine], want_n[mine]), (r, got_n[mine], want_n[mine])
+        assert np.array_equal(got_mix[mine], want_mix[mine]), r
+        seen |= mine
+        # every task strictly ascending as a little-endian multi-word integer
+        k = kl.kmers
+        up = k[1:, nw - 1] > k[:-1, nw - 1]
+        for w in range(nw - 2, -1, -1):
+            eq = np.ones(len(up), bool)
+            for w2 in range(nw - 1, w, -1):
+                eq &= k[1:, w2] == k[:-1, w2]
+            up |= eq & (k[1:, w] > k[:-1, w])
+        starts = kl.task_off[1:-1].astype(np.int64)
+        up[starts[(starts > 0) & (starts < len(k))] - 1] = True
+        assert bool(up.all()), r
+    assert seen.all() and set(owner.tolist()) == set(range(R))
+
+
+@pytest.mark.parametrize("K,EXT", [(31, 0), (51, 0), (31, 1)])
+def test_full_size_multirank_path_eight_virtual_ranks(K, EXT):
+    """BASELINE configs[2] / [3] / [4] need 8 GPUs; what ONE GPU can prove of them: 8 virtual ranks x 1.25 Gbp of reads sampled from one
+    genome (10 Gbp, the oracle's streaming budget), the 8-GPU bench's 320 tasks (40 per rank = 5 task groups each), dispatcher, byte-store
+    placement, grouped exchange overlapped with the sort (device copies in place of RCCL send / recv), multi-segment extraction from
+    eight source ranks per task: every rank's list equals the CPU oracle's per-task digests of ALL reads (count and multiset digest,
+    with EXTENSION every (k-mer, pos, global read id)), every task strictly ascending, key arrays beyond 2^32 bytes."""
+    import hysortk_amd as H
+    R, G, RL = 8, (312_500_000 if not EXT else 39_062_500), 150          # (EXTENSION: 1.0e9 payloads of 8 bytes come back to the host; 1.25 Gbp)
+    NR = G * 32 // RL // R
+    res, owner, want_n, want_mix, st = _loopback_full(H, K, EXT, R, G, NR, 320)
+    assert int(want_n.sum()) == R * NR * (RL - K + 1) == sum(kl.info["total_kmers"] for kl in res)
+    _check_ranks_against_digests(res, owner, want_n, want_mix, R, (K + 31) // 32, EXT)
+    assert np.bincount(owner, minlength=R).min() >= 30                  # (balanced dispatch: ~40 tasks per rank)
+    assert st["combine_launches"] == 0 or K == 31                       # (two-word keys and payloads never take the combining extraction)
+
+
+def test_full_size_multirank_path_byte_store_beyond_4gb():
+    """Two virtual ranks x 12 Gbp: each rank's byte store (the exchange's wire format) and receive buffers pass 2^32 bytes, a task's
+    segments from both source ranks lie beyond 32-bit offsets; 96 tasks = 6 task groups per rank."""
+    import hysortk_amd as H
+    R, G, RL = 2, 750_000_000, 150
+    NR = 12_000_000_000 // RL
+    res, owner, want_n, want_mix, st = _loopback_full(H, 31, 0, R, G, NR, 96)
+    assert sum(kl.info["total_kmers"] for kl in res) == R * NR * (RL - 31 + 1)
+    _check_ranks_against_digests(res, owner, want_n, want_mix, R, 1, 0)
+
+
+def test_multirank_path_with_more_than_eight_task_groups_per_rank():
+    """704 tasks on 8 virtual ranks = 88 per rank = 11 task groups each (the group feeder keeps two in flight): lists equal the oracle's."""
+    import hysortk_amd as H
+    R, G, RL = 8, 40_000_000, 150
+    NR = G * 32 // RL // R
+    res, owner, want_n, want_mix, st = _loopback_full(H, 31, 0, R, G, NR, 704)
+    _check_ranks_against_digests(res, owner, want_n, want_mix, R, 1, 0)
+    assert np.bincount(owner, minlength=R).min() > 64
