@@ -16,7 +16,7 @@ class Config(C.Structure):
         ("kmer_size", C.c_int32), ("minimizer_size", C.c_int32), ("lower_freq", C.c_int32), ("upper_freq", C.c_int32),
         ("extension", C.c_int32), ("ntasks", C.c_int32), ("device", C.c_int32), ("plain_dispatcher", C.c_int32),
         ("dispatch_upper_coe", C.c_double), ("dispatch_step", C.c_double),
-        ("radix_bits", C.c_int32), ("flags", C.c_int32), ("unbalanced_ratio", C.c_double), ("reserved", C.c_int64 * 3),
+        ("radix_bits", C.c_int32), ("flags", C.c_int32), ("unbalanced_ratio", C.c_double), ("tuning", C.c_char_p), ("reserved", C.c_int64 * 2),
     ]
 
 

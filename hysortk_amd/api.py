@@ -236,7 +236,7 @@ class Context:
     """One hsk_ctx (one process, one GPU)."""
 
     def __init__(self, K=31, M=17, L=15, U=40, EXT=0, ntasks=0, device=0, plain_dispatcher=0, radix_bits=8, profile=False, keep_device=False,
-                 plan=None):
+                 plan=None, tuning=None):
         """plan: None (two prefix passes + LDS aggregation, the library's choice), "no_aggregation" (HSK_FLAG_NO_AGGREGATION) or
         "full_sort" (HSK_FLAG_FULL_SORT: the reference's algorithm, LSD over all key bytes + merge-count over the sorted array)."""
         self.lib = _lib.load()
@@ -246,6 +246,10 @@ class Context:
         cfg.extension, cfg.ntasks, cfg.device, cfg.plain_dispatcher, cfg.radix_bits = EXT, ntasks, device, plain_dispatcher, radix_bits
         cfg.flags = (_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_KEEP_DEVICE if keep_device else 0) | \
             {None: 0, "no_aggregation": _lib.FLAG_NO_AGGREGATION, "full_sort": _lib.FLAG_FULL_SORT, "no_combine": _lib.FLAG_NO_COMBINE}[plan]
+        # tuning: dict or "name=value,..." (hsk_config::tuning): forced paths for tests and a few measured thresholds, per context
+        if isinstance(tuning, dict):
+            tuning = ",".join("%s=%d" % (k, int(v)) for k, v in tuning.items())
+        cfg.tuning = tuning.encode() if tuning else None
         self.keep_device = bool(keep_device)
         self.cfg = cfg
         self.K, self.EXT = K, EXT

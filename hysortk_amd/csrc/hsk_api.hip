@@ -137,6 +137,10 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
     if (c->cfg.dispatch_step <= 0) c->cfg.dispatch_step = 0.05;
     if (!(c->cfg.unbalanced_ratio > 0)) c->cfg.unbalanced_ratio = 2.3;
     c->nw = (cfg->kmer_size + 31) / 32;
+    c->tune.parse(cfg->tuning);                                   // the client's string first, then the environment's (a name already set stays)
+    c->tune.parse(getenv("HSK_TUNING"));
+    c->cfg.tuning = nullptr;                                      // (the caller's string is not kept)
+    g_tune = &c->tune;
     memset(&c->stats, 0, sizeof c->stats);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -159,7 +163,7 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
         for (int i = 8; i < 16; ++i) if (h_cnt[i]) seen = -100;
         // every XCD must get a fair share of a round-robin launch (4096 workgroups: 512 each)
         c->xcd_batch_ok = seen == 8 && lo >= 256;
-        if (getenv("HSK_FORCE_NO_XCD") && atoi(getenv("HSK_FORCE_NO_XCD")) != 0) c->xcd_batch_ok = false;      // test hook
+        if (c->tune.get("force_no_xcd", 0)) c->xcd_batch_ok = false;      // test hook
     }
     *out = c;
     return HSK_OK;
@@ -223,7 +227,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 // ------------------------------------------------------------------------------------------------
 // The plan is chosen INSIDE the call (hysortk::kmer_count() is called once per process, reference src/hysortk.cpp:36-96: there is
 // no "next call" that could profit from what this one learned).  Before anything is parsed, a sketch of the input is counted
-// (hsk_estimate.h: the reads inside the first 1/64 of the packed buffer, 1/32 of their canonical k-mers by hash, a global table):
+// (hsk_estimate.h: the reads inside the first 1/256 of the packed buffer (4 - 32 MB), 1/32 of their canonical k-mers by hash, a global table):
 // n1, n2, n3 = chosen k-mers seen once, twice, three times in the sample.  Two components explain them: genomic k-mers, Poisson with
 // mean lambda_s copies inside the sample (lambda_s = 3 n3 / n2, their number G = 2 n2 exp(lambda_s) / lambda_s^2 -- doubletons and
 // tripletons are nearly free of sequencing errors), and k-mers that occur once whatever the depth (errors, a uniform input):
@@ -233,44 +237,50 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 // Measured on the 10 Gbp workload: error-free 32x reads 0.039 (the combining extraction then writes one pair per 25.6 k-mers), 0.3 %
 // substitution errors 0.13, 1 % 0.31, uniform reads 1.0.  Reads in genome order (a sorted alignment turned back into reads) make the
 // prefix deeper than the model thinks and the first term smaller than it is; the second term, which is what moves the decision for
-// deep data, is unaffected.  Cost: two small kernels and one wait.  HSK_PLAN_SAMPLE=0 turns the estimate off (the context's memory of
+// deep data, is unaffected.  Cost: two small kernels and one wait.  tuning "plan_sample=0" turns the estimate off (the context's memory of
 // earlier calls decides, as in rounds 2-3).
 // ------------------------------------------------------------------------------------------------
 static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads)
 {
     c->est = PlanEstimate();
-    static const bool enabled = !(getenv("HSK_PLAN_SAMPLE") && atoi(getenv("HSK_PLAN_SAMPLE")) == 0);
-    constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 64ULL << 20;
+    const bool enabled = tune("plan_sample", 1) != 0;
+    constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 32ULL << 20;
     // who would use it: one-word keys without payload on one GPU (combining extraction or not, first table, aggregation or not)
-    if (!enabled || c->comm.active() || c->nw != 1 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;
+    if (!enabled || c->nw != 1 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
     if (c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT)) return HSK_OK;         // nothing to choose
     const auto t0 = std::chrono::steady_clock::now();
-    const u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);
-    const u64 exp_ins = want * 4 / (1ULL << EST_SELECT_BITS) + 1024;
-    u64 cap = 1ULL << 16; while (cap < exp_ins * 4) cap <<= 1;
-    unsigned long long *d_keys, *d_out; u32 *d_cnts;
-    DALLOC(c, d_keys, unsigned long long *, cap * 8); DALLOC(c, d_cnts, u32 *, cap * 4); DALLOC(c, d_out, unsigned long long *, 256);
-    auto release = [&]() { c->pool.release(d_keys); c->pool.release(d_cnts); c->pool.release(d_out); };
-    HIPCHK(c, hipMemsetAsync(d_keys, 0, cap * 8, c->stream)); HIPCHK(c, hipMemsetAsync(d_cnts, 0, cap * 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_out, 0, 256, c->stream));
-    // the reads that lie completely inside the first `want` bytes (found on the device: the read index of a device-resident input is not on the host)
+    u64 want = std::min<u64>(std::max<u64>(packed_bytes / 256, MIN_SAMPLE), MAX_SAMPLE);      // (10 Gbp: 10 MB of reads, ~1.2 M chosen k-mer instances: 0.4 ms)
+    u64 lost = 0, n1 = 0, n2 = 0, n3 = 0, ds = 0, ns = 0, s_bytes = 0;
     unsigned long long *h_out = (unsigned long long *)((char *)c->pinned + c->pinned_bytes - 512);
-    hipLaunchKernelGGL(prefix_reads_kernel, dim3(1), dim3(64), 0, c->stream, d_roff, nreads, want, (u64 *)(d_out + 8));
-    HIPCHK(c, hipMemcpyAsync(h_out + 8, d_out + 8, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));
-    const u64 s_reads = h_out[8], s_bytes = h_out[9];
-    if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes || s_bytes > want + (1u << 20)) { release(); return HSK_OK; }      // (very long reads, a strange index: no estimate, the context's memory decides)
-    // host input: the sample's bytes first (the main run copies them again with its first slab)
-    if (c->h2d_src || c->zc_src) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), c->h2d_src ? c->h2d_src : c->zc_src, s_bytes, hipMemcpyDefault, c->stream));
-    EstimateArgs ea; memset(&ea, 0, sizeof ea);
-    ea.packed = d_packed; ea.roff = d_roff; ea.rlen = d_rlen; ea.nreads = s_reads; ea.positions = s_bytes * 4; ea.k = c->cfg.kmer_size;
-    ea.keys = d_keys; ea.cnts = d_cnts; ea.cap_mask = cap - 1; ea.out = d_out;
-    const u64 nthreads = (ea.positions + EST_SPAN - 1) / EST_SPAN;
-    hipLaunchKernelGGL(estimate_insert_kernel, dim3((u32)((nthreads + EST_THREADS - 1) / EST_THREADS)), dim3(EST_THREADS), 0, c->stream, ea);
-    hipLaunchKernelGGL(estimate_hist_kernel, dim3((u32)std::min<u64>(cap / EST_THREADS, 4096)), dim3(EST_THREADS), 0, c->stream, ea);
-    HIPCHK(c, hipMemcpyAsync(h_out, d_out, 48, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));
-    release();                                                              // (stream-ordered reuse: the kernels above are done)
-    const u64 lost = h_out[0], n1 = h_out[1], n2 = h_out[2], n3 = h_out[3], ds = h_out[4], ns = h_out[5];
+    for (int round = 0; round < 2; ++round) {
+        const u64 exp_ins = want * 4 / (1ULL << EST_SELECT_BITS) + 1024;
+        u64 cap = 1ULL << 16; while (cap < exp_ins * 4) cap <<= 1;
+        unsigned long long *d_keys, *d_out; u32 *d_cnts;
+        DALLOC(c, d_keys, unsigned long long *, cap * 8); DALLOC(c, d_cnts, u32 *, cap * 4); DALLOC(c, d_out, unsigned long long *, 256);
+        auto release = [&]() { c->pool.release(d_keys); c->pool.release(d_cnts); c->pool.release(d_out); };
+        HIPCHK(c, hipMemsetAsync(d_keys, 0, cap * 8, c->stream)); HIPCHK(c, hipMemsetAsync(d_cnts, 0, cap * 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_out, 0, 256, c->stream));
+        // the reads that lie completely inside the first `want` bytes (found on the device: the read index of a device-resident input is not on the host)
+        hipLaunchKernelGGL(prefix_reads_kernel, dim3(1), dim3(64), 0, c->stream, d_roff, nreads, want, (u64 *)(d_out + 8));
+        HIPCHK(c, hipMemcpyAsync(h_out + 8, d_out + 8, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
+        const u64 s_reads = h_out[8]; s_bytes = h_out[9];
+        if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes || s_bytes > want + (1u << 20)) { release(); return HSK_OK; }      // (very long reads, a strange index: no estimate, the context's memory decides)
+        // host input: the sample's bytes first (the main run copies them again with its first slab)
+        if (c->h2d_src || c->zc_src) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), c->h2d_src ? c->h2d_src : c->zc_src, s_bytes, hipMemcpyDefault, c->stream));
+        EstimateArgs ea; memset(&ea, 0, sizeof ea);
+        ea.packed = d_packed; ea.roff = d_roff; ea.rlen = d_rlen; ea.nreads = s_reads; ea.positions = s_bytes * 4; ea.k = c->cfg.kmer_size;
+        ea.keys = d_keys; ea.cnts = d_cnts; ea.cap_mask = cap - 1; ea.out = d_out;
+        const u64 nthreads = (ea.positions + EST_SPAN - 1) / EST_SPAN;
+        hipLaunchKernelGGL(estimate_insert_kernel, dim3((u32)((nthreads + EST_THREADS - 1) / EST_THREADS)), dim3(EST_THREADS), 0, c->stream, ea);
+        hipLaunchKernelGGL(estimate_hist_kernel, dim3((u32)std::min<u64>(cap / EST_THREADS, 4096)), dim3(EST_THREADS), 0, c->stream, ea);
+        HIPCHK(c, hipMemcpyAsync(h_out, d_out, 48, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hsk_sync(c, c->stream));
+        release();                                                          // (stream-ordered reuse: the kernels above are done)
+        lost = h_out[0]; n1 = h_out[1]; n2 = h_out[2]; n3 = h_out[3]; ds = h_out[4]; ns = h_out[5];
+        // shallow data (coverage below ~10): too few tripletons in 1/256 of the reads to tell the depth -- once more on sixteen times as many
+        if (round == 0 && !lost && n2 >= 16 && n3 < 256 && want * 16 <= packed_bytes / 2 && want * 16 <= (512ULL << 20)) { want *= 16; continue; }
+        break;
+    }
     if (lost || ns < (1u << 14)) return HSK_OK;                            // (no estimate)
     PlanEstimate &e = c->est;
     e.fraction = (double)s_bytes / (double)packed_bytes; e.sample_kmers = ns; e.n1 = n1; e.n2 = n2; e.n3 = n3; e.distinct_sample = ds;
@@ -428,8 +438,7 @@ static bool offsets_back_to_back(const uint64_t *off, const uint32_t *len, uint6
 // take staged copies.  HSK_ZERO_COPY=0 always copies.
 static bool zero_copy_enabled()
 {
-    static const bool on = !(getenv("HSK_ZERO_COPY") && atoi(getenv("HSK_ZERO_COPY")) == 0);
-    return on;
+    return tune("zero_copy", 1) != 0;
 }
 
 // hsk_count() with a pinned DnaBuffer: only the read lengths travel ahead of the scan, the byte offsets are their prefix sums
@@ -448,7 +457,7 @@ static int derive_input(hsk_ctx *c, uint64_t packed_bytes, const uint64_t *off, 
     // Fixed-length reads (sequencer output): three samples say so, the device fills in the lengths, and the host threads that
     // compare the offsets anyway verify EVERY length while the GPU scans -- 4 bytes per read less on the link (267 MB of 2.8 GB at
     // 10 Gbp of 150-bp reads).  A single read of another length sends the call down the same road as a buffer with gaps.
-    static const bool uniform_enabled = !(getenv("HSK_UNIFORM_LEN") && atoi(getenv("HSK_UNIFORM_LEN")) == 0);
+    const bool uniform_enabled = tune("uniform_len", 1) != 0;
     const uint32_t ulen = (uniform_enabled && len[0] != 0 && len[0] == len[nreads / 2] && len[0] == len[nreads - 1]) ? len[0] : 0;
     if (ulen) { hipLaunchKernelGGL(rlen_fill_kernel, dim3(2048), dim3(256), 0, c->stream, d.rlen, nreads, ulen); c->rlen_host = len; c->stats.h2d_bytes -= nreads * 4; }
     else HIPCHK(c, hipMemcpyAsync(d.rlen, len, nreads * 4, hipMemcpyHostToDevice, c->stream));
@@ -467,7 +476,7 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
 {
     if (!c || !out || (nreads && (!off || !len)) || (packed_bytes && !packed)) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     tmark(nullptr); tmark("hsk_count enter");
     const bool device_check = nreads >= (1u << 20);          // a serial host loop over 10^8 reads costs more than the whole count
     int rc = device_check ? HSK_OK : check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
@@ -479,10 +488,10 @@ extern "C" int hsk_count(hsk_ctx *c, const uint8_t *packed, uint64_t packed_byte
     }
     // pinned input of some size: slab ingest (DMA copies pipelined with the scan, parse_count) instead of reads over PCIe in place;
     // HSK_H2D_SLABS=0: in place as in round 2, =n: n slabs
-    static const int slabs_env = getenv("HSK_H2D_SLABS") ? atoi(getenv("HSK_H2D_SLABS")) : 16;
+    const int slabs_env = (int)tune("h2d_slabs", 16);
     const bool slab_ingest = zc != nullptr && slabs_env > 1 && packed_bytes >= (32u << 20);
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
-    static const bool derive_enabled = !(getenv("HSK_DERIVE_OFFSETS") && atoi(getenv("HSK_DERIVE_OFFSETS")) == 0);
+    const bool derive_enabled = tune("derive_offsets", 1) != 0;
     // only the read lengths travel ahead of the scan (see roff_tilesum_kernel).  The host threads' verdict on the derived index is read by the
     // fast parse (parse_count's scan branch, parse_ingest_pipelined): with the general parse kernels from the start (M > SCAN_MAX_M, HSK_PARSE_FAST=0)
     // the caller's index travels and is checked on the device like a pageable one
@@ -516,7 +525,7 @@ extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packe
     if (!c || !out || (nreads && (!d_off || !d_len)) || (packed_bytes && !d_packed)) return HSK_ERR_INVALID_ARG;
     if (((uintptr_t)d_packed & 3) != 0) return fail(c, HSK_ERR_INVALID_ARG, "d_packed must be 4-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     // the kernels index roff[r+1]: build the (nreads+1)-entry offset array
     u64 *roff; DALLOC(c, roff, u64 *, (nreads + 1) * 8);
     if (nreads) HIPCHK(c, hipMemcpyAsync(roff, d_off, nreads * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -533,7 +542,7 @@ extern "C" int hsk_count_loopback(hsk_ctx *c, int nranks, const uint8_t *const *
 {
     if (!c || nranks < 1 || nranks > 64 || !packed || !packed_bytes || !off || !len || !nreads || !outs) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     std::vector<DevInput> in(nranks);
     int rc = HSK_OK;
     for (int r = 0; r < nranks && rc == HSK_OK; ++r) {
@@ -568,7 +577,7 @@ extern "C" int hsk_count_loopback_device(hsk_ctx *c, int nranks, const void *con
 {
     if (!c || nranks < 1 || nranks > 64 || !d_packed || !packed_bytes || !d_off || !d_len || !nreads || !outs) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     std::vector<DevInput> in(nranks);
     std::vector<u64 *> roffs(nranks, nullptr);
     u64 *stage = (u64 *)((char *)c->pinned + (256u << 10));                   // (pinned staging: one end offset per rank)
@@ -612,7 +621,7 @@ extern "C" int hsk_stage_destinations(hsk_ctx *c, const uint8_t *packed, uint64_
 {
     if (!c || !dest_off || (cap && !dest)) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
     const int K = c->cfg.kmer_size;
     uint64_t total = 0;
@@ -680,7 +689,7 @@ extern "C" int hsk_stage_task_kmers(hsk_ctx *c, const uint8_t *packed, uint64_t 
     if (!c || !n || (cap && !keys)) return HSK_ERR_INVALID_ARG;
     *n = 0;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     int rc = check_host_index(c, packed_bytes, off, len, nreads); if (rc) return rc;
     if (!nreads || !packed_bytes) return HSK_OK;
     DevInput d; rc = upload_input(c, packed, packed_bytes, off, len, nreads, d); if (rc) return rc;
@@ -721,7 +730,7 @@ extern "C" int hsk_stage_sort(hsk_ctx *c, uint64_t *keys, uint64_t *vals, uint64
     if (!c || (n && !keys) || nw < 1 || nw > 3) return HSK_ERR_INVALID_ARG;
     if (n == 0) return HSK_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     switch (nw) {
     case 1: return stage_sort_impl<1>(c, keys, vals, n);
     case 2: return stage_sort_impl<2>(c, keys, vals, n);
@@ -756,7 +765,7 @@ extern "C" int hsk_stage_count_sorted(hsk_ctx *c, const uint64_t *keys, uint64_t
     *n_out = 0;
     if (n == 0) return HSK_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     switch (nw) {
     case 1: return stage_count_impl<1>(c, keys, n, out_entries, cap, n_out);
     case 2: return stage_count_impl<2>(c, keys, n, out_entries, cap, n_out);
@@ -1086,7 +1095,7 @@ extern "C" int hsk_debug_parse_overlap(hsk_ctx *c, const void *d_packed, uint64_
 {
     if (!c || !out_ms) return HSK_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    g_plan_flags = c->cfg.flags;
+    enter_ctx(c);
     u64 *roff; DALLOC(c, roff, u64 *, (nreads + 1) * 8);
     HIPCHK(c, hipMemcpyAsync(roff, d_off, nreads * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(roff + nreads, &packed_bytes, 8, hipMemcpyHostToDevice, c->stream));

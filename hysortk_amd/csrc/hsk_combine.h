@@ -27,6 +27,7 @@
 // beyond the weighted finish's last table, no batch of eight tasks, a parse that left its fast path) starts again from the reads
 // in HBM (HSK_RETRY_PLAN, dispatch_pipeline).
 #pragma once
+#include "hsk_expand.h"
 #include "hsk_scatter.h"
 #include "hsk_agg.h"
 
@@ -166,6 +167,95 @@ __global__ __launch_bounds__(CS_THREADS) void bucket_scatter_kernel(BucketSortAr
         }
         __syncthreads();
         for (u32 i = tid; i < nt; i += CS_THREADS) out[s_gb[s_bk[i]] + i] = s_it[i];
+    }
+}
+
+// ---- 1b. several ranks: the items are built by the OWNER of a task (round 4) ------------------------------------------------------
+// The supermers travel as byte runs (hsk_comm.h: len[], bytes[] and, when the combining extraction is planned, the top 16 minimizer
+// bits sub16[] -- 2 bytes per supermer on the wire).  For a batch of eight owned tasks, whose segments come from every source rank:
+//   vt_hist_kernel     counts the supermers per (task, top four minimizer bits): the 16 VIRTUAL tasks the one-GPU parse makes itself
+//   vt_scan_kernel     lays the (task, virtual task) runs out back to back
+//   items_build_kernel a supermer's byte offset from the tile offsets of expand_scan_kernel + a scan of the tile's lengths, its first
+//                      64 bases as the 16-byte item place_items_kernel would have written, scattered into the 16 runs of its task (a
+//                      tile of 512 supermers: runs of ~32 items = 512 bytes)
+// What follows is the one-GPU path unchanged: bucket order inside the virtual tasks, combine_kernel, one radix pass, weighted finish.
+struct ItemBuildTask { const ExpSeg *segs; int nseg; const u8 *sm_len; const unsigned short *sub16; const u64 *src8; u64 src_words; const u64 *tile_off; u64 ntiles; };
+struct ItemBuildArgs {
+    ItemBuildTask t[8];
+    u32 *vt_cnt;               // [8][16] supermers per (task of the batch, virtual task)
+    u64 *vt_cur;               // [8][16] running slot cursors (vt_scan_kernel: the runs' first slots)
+    ulonglong2 *items; u32 *subs;
+    int k; u32 *err;
+};
+
+__global__ __launch_bounds__(EXP_THREADS) void vt_hist_kernel(ItemBuildArgs a)
+{
+    __shared__ u32 s_h[16];
+    const ItemBuildTask &t = a.t[blockIdx.y];
+    const u64 tile = blockIdx.x;
+    if (tile >= t.ntiles) return;
+    if (threadIdx.x < 16) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const ExpSeg seg = t.segs[seg_of_tile(t.segs, t.nseg, tile)];
+    const u64 first = (tile - seg.tile_start) * EXP_TILE;
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) {
+        const u64 s_ = first + (u64)i * EXP_THREADS + threadIdx.x;
+        if (s_ < seg.n_sup) atomicAdd(&s_h[t.sub16[seg.sup_off + s_] >> 12], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_h[threadIdx.x]) atomicAdd(&a.vt_cnt[blockIdx.y * 16 + threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(128) void vt_scan_kernel(ItemBuildArgs a)
+{
+    __shared__ u32 s_w[2];
+    const u32 c = a.vt_cnt[threadIdx.x];
+    const u32 inc = wave_incl_scan(c);
+    if (lane_id() == WAVE - 1) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    a.vt_cur[threadIdx.x] = (u64)((threadIdx.x >> 6) ? s_w[0] : 0u) + inc - c;      // (a batch's supermers: below 2^32, checked on the host)
+}
+
+__global__ __launch_bounds__(EXP_THREADS) void items_build_kernel(ItemBuildArgs a)
+{
+    __shared__ u32 s_scr[8];
+    __shared__ u32 s_h[16];
+    __shared__ u64 s_base[16];
+    const ItemBuildTask &t = a.t[blockIdx.y];
+    const u64 tile = blockIdx.x;
+    if (tile >= t.ntiles) return;
+    if (threadIdx.x < 16) s_h[threadIdx.x] = 0;
+    const ExpSeg seg = t.segs[seg_of_tile(t.segs, t.nseg, tile)];
+    const u64 first = (tile - seg.tile_start) * EXP_TILE;
+    u32 len[EXP_SPT], sub[EXP_SPT], off[EXP_SPT], rk[EXP_SPT]; bool ok[EXP_SPT];
+    u32 run = 0;
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) {
+        const u64 s_ = first + (u64)i * EXP_THREADS + threadIdx.x;
+        ok[i] = s_ < seg.n_sup;
+        len[i] = ok[i] ? t.sm_len[seg.sup_off + s_] : 0u;
+        sub[i] = ok[i] ? t.sub16[seg.sup_off + s_] : 0u;
+        u32 tot;
+        off[i] = run + block_excl_scan_256<u32>((len[i] + 3u) >> 2, s_scr, &tot);      // (supermer order inside the tile: the first 256, then the second)
+        run += tot;
+    }
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) rk[i] = ok[i] ? atomicAdd(&s_h[sub[i] >> 12], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < 16) s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd((unsigned long long *)&a.vt_cur[blockIdx.y * 16 + threadIdx.x], (unsigned long long)s_h[threadIdx.x]) : 0ULL;
+    __syncthreads();
+    const u64 byte0 = t.tile_off[2 * tile];
+#pragma unroll
+    for (int i = 0; i < EXP_SPT; ++i) {
+        if (!ok[i]) continue;
+        const u32 cnt = len[i] - (u32)a.k + 1u;
+        if (len[i] < (u32)a.k || cnt > 16u) { atomicOr(a.err, 4u); continue; }
+        const u64 bit = (byte0 + off[i]) * 8;
+        const u64 w0 = bits64_bytes_clamped(t.src8, bit, t.src_words), w1 = bits64_bytes_clamped(t.src8, bit + 64, t.src_words);
+        const u64 slot = s_base[sub[i] >> 12] + rk[i];
+        a.items[slot] = make_ulonglong2(w0, (w1 & ~0xFFULL) | (u64)cnt);
+        a.subs[slot] = sub[i] << 16;
     }
 }
 

@@ -158,10 +158,11 @@ struct Comm {
 
 struct ExchangeBuffers {
     uint8_t *len = nullptr; uint8_t *bytes = nullptr; uint32_t *pos = nullptr; int32_t *rid = nullptr; uint64_t nbytes = 0;
+    unsigned short *sub16 = nullptr;      // the supermers' top 16 minimizer bits (combining extraction on the owner's side), beside len
     template <typename Pool> void release(Pool &pool)
     {
-        pool.release(len); pool.release(bytes); pool.release(pos); pool.release(rid);
-        len = bytes = nullptr; pos = nullptr; rid = nullptr;
+        pool.release(len); pool.release(bytes); pool.release(pos); pool.release(rid); pool.release(sub16);
+        len = bytes = nullptr; pos = nullptr; rid = nullptr; sub16 = nullptr;
     }
 };
 
@@ -255,8 +256,9 @@ struct P2PGroup {
 // Every rank posts what the plan says, whether its own count has failed or not (GroupFeeder::drain_after_failure): a rank
 // that stopped taking part would leave its peers blocked in their receives.
 inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &pl, const uint8_t *sm_len, const uint8_t *sm_bytes,
-                         const uint32_t *sm_pos, const int32_t *sm_rid, ExchangeBuffers &xb)
+                         const uint32_t *sm_pos, const int32_t *sm_rid, ExchangeBuffers &xb, const unsigned short *sm_sub16 = nullptr)
 {
+    const bool sub = sm_sub16 != nullptr && xb.sub16 != nullptr;          // (every rank or none: agreed with the size matrix)
     const int nr = cm.nranks, me = cm.rank;
     {
         P2PGroup g(cm);
@@ -265,6 +267,7 @@ inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &
             if (pl.send_sup[q]) {
                 g.send(sm_len + pl.send_sup_off[q], pl.send_sup[q], q, s, "ncclSend(len)");
                 g.send(sm_bytes + pl.send_byte_off[q], pl.send_bytes[q], q, s, "ncclSend(bytes)");
+                if (sub) g.send(sm_sub16 + pl.send_sup_off[q], pl.send_sup[q] * 2, q, s, "ncclSend(minimizer bits)");
                 if (ext) {
                     g.send(sm_pos + pl.send_sup_off[q], pl.send_sup[q] * 4, q, s, "ncclSend(pos)");
                     g.send(sm_rid + pl.send_sup_off[q], pl.send_sup[q] * 4, q, s, "ncclSend(rid)");
@@ -273,6 +276,7 @@ inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &
             if (pl.recv_sup[q]) {
                 g.recv(xb.len + pl.recv_sup_off[q], pl.recv_sup[q], q, s, "ncclRecv(len)");
                 g.recv(xb.bytes + pl.recv_byte_off[q], pl.recv_bytes[q], q, s, "ncclRecv(bytes)");
+                if (sub) g.recv(xb.sub16 + pl.recv_sup_off[q], pl.recv_sup[q] * 2, q, s, "ncclRecv(minimizer bits)");
                 if (ext) {
                     g.recv(xb.pos + pl.recv_sup_off[q], pl.recv_sup[q] * 4, q, s, "ncclRecv(pos)");
                     g.recv(xb.rid + pl.recv_sup_off[q], pl.recv_sup[q] * 4, q, s, "ncclRecv(rid)");
@@ -285,6 +289,7 @@ inline int post_exchange(Comm &cm, hipStream_t s, bool ext, const ExchangePlan &
     if (pl.send_sup[me]) {
         if (hipMemcpyAsync(xb.len + pl.recv_sup_off[me], sm_len + pl.send_sup_off[me], pl.send_sup[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
         if (hipMemcpyAsync(xb.bytes + pl.recv_byte_off[me], sm_bytes + pl.send_byte_off[me], pl.send_bytes[me], hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+        if (sub && hipMemcpyAsync(xb.sub16 + pl.recv_sup_off[me], sm_sub16 + pl.send_sup_off[me], pl.send_sup[me] * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
         if (ext) {
             if (hipMemcpyAsync(xb.pos + pl.recv_sup_off[me], sm_pos + pl.send_sup_off[me], pl.send_sup[me] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
             if (hipMemcpyAsync(xb.rid + pl.recv_sup_off[me], sm_rid + pl.send_sup_off[me], pl.send_sup[me] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;

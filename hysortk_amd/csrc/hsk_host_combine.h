@@ -5,8 +5,7 @@
 // HSK_COMBINE=0: the instance path (expand_scatter2_kernel ...) always
 static bool combine_enabled()
 {
-    static const bool on = !(getenv("HSK_COMBINE") && atoi(getenv("HSK_COMBINE")) == 0);
-    return on && !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT | HSK_FLAG_NO_COMBINE));
+    return tune("combine", 1) != 0 && !(g_plan_flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT | HSK_FLAG_NO_COMBINE));
 }
 // k-mers per bucket the bucket order aims at (a table of CB_CAP slots takes the ~400 distinct k-mers of such a bucket at 32x coverage
 // with room to spare, and still most of them at 5x)
@@ -17,8 +16,8 @@ static bool combine_enabled()
 constexpr int COMBINE_PREFIX_DEFAULT = 14, COMBINE_PREFIX_MAX = 16;
 static int combine_prefix_forced()
 {
-    static const int v = getenv("HSK_COMBINE_PREFIX") ? std::min(16, std::max(9, atoi(getenv("HSK_COMBINE_PREFIX")))) : 0;
-    return v;
+    const long long v = tune("combine_prefix", 0);
+    return v ? (int)std::min<long long>(16, std::max<long long>(9, v)) : 0;
 }
 static int combine_prefix_bits(const hsk_ctx *c)
 {
@@ -34,13 +33,11 @@ static int combine_prefix_for(u64 max_pairs_per_task)
 // more than one pair per combine_ratio() k-mers: the instance path (break-even measured at one per ~15); HSK_COMBINE_RATIO=1: never leave (measurements)
 static u64 combine_ratio()
 {
-    static const u64 v = getenv("HSK_COMBINE_RATIO") ? (u64)std::max(1, atoi(getenv("HSK_COMBINE_RATIO"))) : 16;
-    return v;
+    return (u64)std::max<long long>(1, tune("combine_ratio", 16));
 }
 static u64 combine_bucket_kmers()
 {
-    static const u64 v = getenv("HSK_COMBINE_BUCKET") ? (u64)std::max(256, atoi(getenv("HSK_COMBINE_BUCKET"))) : 12288;
-    return v;
+    return (u64)std::max<long long>(256, tune("combine_bucket", 12288));
 }
 
 // the supermer items of the owned tasks in bucket order
@@ -101,6 +98,68 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     bo.active = true;
+    return HSK_OK;
+}
+
+// Several ranks: the items of a batch of owned tasks, built from the supermers the exchange delivered (jobs[i]: segments, len[], byte runs;
+// sub16[i]: their minimizer bits), grouped by (task, virtual task).  gsegs[t] / gsrc then describe an item-mode store of these tasks for
+// bucket_order_tasks (16 virtual tasks per task: vt_shift 4).  One wait (the runs' sizes come back to the host).
+struct FedItems { ulonglong2 *items = nullptr; u32 *subs = nullptr, *vt_cnt = nullptr; u64 *vt_cur = nullptr; ExpandScratch x[XCD_BATCH]; };
+constexpr u32 FED_VT_SHIFT = 4;
+static void fed_release(hsk_ctx *c, FedItems &f)
+{
+    c->pool.release(f.items); c->pool.release(f.subs); c->pool.release(f.vt_cnt); c->pool.release(f.vt_cur);
+    for (int i = 0; i < XCD_BATCH; ++i) expand_release(c, f.x[i]);
+    f = FedItems();
+}
+static int build_items_batch(hsk_ctx *c, u32 ntasks, const u32 *tk, const ExpandJob *jobs, const unsigned short *const *sub16, std::vector<TaskSegs> &gsegs,
+                             BaseSource &gsrc, FedItems &f, hipStream_t stream)
+{
+    f = FedItems();
+    gsegs.assign(ntasks, TaskSegs());
+    const TaskSegs *tsp[XCD_BATCH]; const u8 *lens[XCD_BATCH]; int idx[XCD_BATCH], m = 0;
+    u64 total = 0, max_tiles = 0;
+    for (int i = 0; i < XCD_BATCH; ++i) {
+        if (tk[i] == ~0u || !jobs[i].ts->ntiles) continue;
+        if (!sub16[i]) return fail(c, HSK_ERR_INTERNAL, "a received task without minimizer bits");
+        tsp[m] = jobs[i].ts; lens[m] = jobs[i].sm_len; idx[m] = i; ++m;
+        for (const ExpSeg &sg : jobs[i].ts->segs) total += sg.n_sup;
+        max_tiles = std::max(max_tiles, jobs[i].ts->ntiles);
+    }
+    if (!m) return HSK_OK;
+    if (total >= (1ULL << 32)) return fail(c, HSK_ERR_UNSUPPORTED, "a batch of more than 2^32 supermers");
+    int rc = expand_prepare_batch(c, m, tsp, lens, f.x, stream, false, true); if (rc) return rc;
+    DALLOC(c, f.items, ulonglong2 *, total * 16 + 64); DALLOC(c, f.subs, u32 *, total * 4 + 64);
+    DALLOC(c, f.vt_cnt, u32 *, 128 * 4); DALLOC(c, f.vt_cur, u64 *, 128 * 8);
+    HIPCHK(c, hipMemsetAsync(f.vt_cnt, 0, 128 * 4, stream));
+    ItemBuildArgs a; memset(&a, 0, sizeof a);
+    for (int j = 0; j < m; ++j) {
+        const ExpandJob &jb = jobs[idx[j]];
+        ItemBuildTask &t = a.t[j];
+        t.segs = f.x[j].d_segs; t.nseg = (int)jb.ts->segs.size(); t.sm_len = jb.sm_len; t.sub16 = sub16[idx[j]]; t.src8 = jb.src.src8; t.src_words = jb.src.nwords;
+        t.tile_off = f.x[j].d_tile_off; t.ntiles = jb.ts->ntiles;
+    }
+    a.vt_cnt = f.vt_cnt; a.vt_cur = f.vt_cur; a.items = f.items; a.subs = f.subs; a.k = c->cfg.kmer_size; a.err = c->d_err;
+    hipLaunchKernelGGL(vt_hist_kernel, dim3((u32)max_tiles, m), dim3(EXP_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(vt_scan_kernel, dim3(1), dim3(128), 0, stream, a);
+    u32 *h_cnt = (u32 *)((char *)c->pinned + (320u << 10));
+    HIPCHK(c, hipMemcpyAsync(h_cnt, f.vt_cnt, 128 * 4, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(items_build_kernel, dim3((u32)max_tiles, m), dim3(EXP_THREADS), 0, stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hsk_sync(c, stream));
+    u64 run = 0;
+    for (int j = 0; j < m; ++j) {
+        const u32 t = tk[idx[j]];
+        TaskSegs &ts = gsegs[t];
+        ts.nkmers = jobs[idx[j]].ts->nkmers;
+        for (u32 v = 0; v < 16; ++v) {
+            const u32 n = h_cnt[j * 16 + v];
+            if (n) { ExpSeg sg; sg.sup_off = run; sg.n_sup = n; sg.byte_off = v; sg.kmer_off = 0; sg.tile_start = 0; ts.segs.push_back(sg); }
+            run += n;
+        }
+    }
+    if (run != total) return fail(c, HSK_ERR_INTERNAL, "item build: %llu of %llu supermers placed", (unsigned long long)run, (unsigned long long)total);
+    gsrc = BaseSource(); gsrc.sub = f.subs; gsrc.item = reinterpret_cast<const u64 *>(f.items);
     return HSK_OK;
 }
 

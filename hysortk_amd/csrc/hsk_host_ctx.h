@@ -116,8 +116,27 @@ struct PlanEstimate {
     double ms = 0;                     // host wall clock of the estimate
 };
 
+// Tuning: "name=value,name=value" from hsk_config::tuning (copied at hsk_init), behind it the environment's HSK_TUNING (ad-hoc diagnostics
+// without touching the client).  Forced paths for the byte-identity tests and a handful of measured thresholds; never an algorithm a caller
+// would choose (those are hsk_config fields and HSK_FLAG_*).  Read per CONTEXT: two contexts of one process may differ (round 3 read ~35
+// environment variables once per process into function-local statics).  INTEGRATION.md section 5 lists the names.
+struct Tuning {
+    std::map<std::string, long long> v;
+    void parse(const char *s)
+    {
+        while (s && *s) {
+            const char *e = strchr(s, ','); const std::string item = e ? std::string(s, e - s) : std::string(s);
+            const size_t q = item.find('=');
+            if (q != std::string::npos && q > 0) { std::string k = item.substr(0, q); while (!k.empty() && k[0] == ' ') k.erase(0, 1); if (!v.count(k)) v[k] = atoll(item.c_str() + q + 1); }
+            s = e ? e + 1 : nullptr;
+        }
+    }
+    long long get(const char *name, long long dflt) const { auto it = v.find(name); return it == v.end() ? dflt : it->second; }
+};
+
 struct hsk_ctx {
     hsk_config cfg;
+    Tuning tune;
     int nw = 1;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;
@@ -177,6 +196,10 @@ struct hsk_ctx {
 // HSK_FLAG_NO_AGGREGATION / HSK_FLAG_FULL_SORT of the context whose call is running on this thread (set by the counting entry
 // points): the plan switches below (agg_enabled, hybrid_enabled, finish_enabled) are asked in places that have no context at hand
 static thread_local int g_plan_flags = 0;
+// ... and its tuning table (same lifetime: set by every entry point that takes a context)
+static thread_local const Tuning *g_tune = nullptr;
+static long long tune(const char *name, long long dflt) { return g_tune ? g_tune->get(name, dflt) : dflt; }
+static void enter_ctx(hsk_ctx *c) { g_plan_flags = c->cfg.flags; g_tune = &c->tune; }
 
 static int fail(hsk_ctx *c, int code, const char *fmt, ...)
 {

@@ -60,7 +60,7 @@ static int expand_batch(hsk_ctx *c, const ExpandJob *jobs, int njobs, int npass 
     ExpandScratch xown[EXP_BATCH];
     ExpandScratch *x = pre ? pre : xown;
     int nt = 0; u64 max_tiles = 0;
-    static const bool reserve_enabled = !(getenv("HSK_EXPAND_RESERVE") && atoi(getenv("HSK_EXPAND_RESERVE")) == 0);
+    const bool reserve_enabled = tune("expand_reserve", 1) != 0;
     bool reserve = true;
     {
         const TaskSegs *tsp[EXP_BATCH]; const u8 *lens[EXP_BATCH]; int m = 0;

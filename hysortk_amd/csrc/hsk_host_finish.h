@@ -327,6 +327,34 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
     return HSK_OK;
 }
 
+// {k-mer, count} records ordered by key (a key may occur several times: partial pairs of the combining extraction, the per-rank lists of a
+// heavy-hitter task): counts of equal keys summed, [L, U] applied, entries and histogram out (hsk_heavy.h: heavy_merge_kernel)
+template <int NW>
+static int merge_sorted_pairs(hsk_ctx *c, const u64 *sk, const u64 *sv, u64 n, u64 *d_histo, u32 histo_len, TaskOut &out)
+{
+    out = TaskOut();
+    if (n == 0) return HSK_OK;
+    const u64 ntiles = (n + HV_THREADS - 1) / HV_THREADS;
+    u64 *d_tile, *d_total;
+    DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
+    HeavyMergeArgs a; memset(&a, 0, sizeof a);
+    a.keys = sk; a.cnts = sv; a.n = n; a.lower = (u64)c->cfg.lower_freq; a.upper = (u64)c->cfg.upper_freq; a.tile_cnt = d_tile; a.histo = d_histo; a.histo_len = histo_len;
+    hipLaunchKernelGGL((heavy_merge_kernel<NW, false>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
+    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
+    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));
+    out.n = tot[0];
+    if (out.n) {
+        DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
+        a.entries = out.entries;
+        hipLaunchKernelGGL((heavy_merge_kernel<NW, true>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->pool.release(d_tile); c->pool.release(d_total);      // (stream-ordered reuse)
+    return HSK_OK;
+}
+
 // covered: later work has already been enqueued behind stage 1 (the wait does not leave the GPU idle)
 template <int NW>
 static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, TaskOut *outs, bool covered)
@@ -352,7 +380,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         else if (ovf_bins == 0 && p.first_cap > AG_LOG2CAP_SMALL &&
                  (NW == 1 ? maxd < (1u << (p.first_cap - 1)) * 3 / 4 : ++c->agg_clean_batches >= 4)) { c->agg_first_cap = p.first_cap - 1; c->agg_clean_batches = 0; }
     }
-    { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
+    { const bool force_off = tune("agg_adapt", 1) == 2;     // (tests: as if this batch had been found hopeless, but finished normally)
       if (force_off && !c->forbid_long_way && !p.weighted) { if (NW == 1) c->agg_off = true; else c->agg_off_wide = true; } }
     // ---- the ladder, bin by bin: the listed bins again one table size up, until no bin is left or the rungs are ----------------
     if (!big && ovf_bins) {
@@ -362,14 +390,14 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
         for (;;) {
             u32 longest = 0; u64 nb = 0; for (int i = 0; i < AG_BATCH; ++i) { longest = std::max(longest, n_cur[i]); nb += n_cur[i]; }
             if (!longest) break;
-            static const int max_rung = getenv("HSK_AGG_MAXRUNG") ? atoi(getenv("HSK_AGG_MAXRUNG")) : AG_LOG2CAP_HUGE;     // (tests: stop the ladder early, the listed bins' tasks take the long way)
+            const int max_rung = (int)tune("agg_maxrung", AG_LOG2CAP_HUGE);     // (tests: stop the ladder early, the listed bins' tasks take the long way)
             int next = (NW >= 2 || p.weighted) ? (cap < AG_LOG2CAP_LARGE ? cap + 1 : 0) : (cap < AG_LOG2CAP_HUGE ? cap + 1 : 0);
             if (next > max_rung) next = 0;
             if (!next) { for (int i = 0; i < AG_BATCH; ++i) if (n_cur[i]) done[i] = false; break; }   // a bin beyond the last rung: the task takes the long way
             // More than half of all bins did not fit 2048 slots: this input has (nearly) as many distinct k-mers as k-mers -- reads with
             // 5 % errors and more -- and the aggregation is the wrong tool.  No further rungs: the tasks of this batch take the long way
             // now, the batches after it (and later calls on this context) four prefix passes + the tile finish instead of two + tables.
-            static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
+            const bool adapt = tune("agg_adapt", 1) != 0;
             // (multi-word keys have no tile finish to change to: their tasks just stop climbing a ladder that ends in the long way anyway)
             if (adapt && !c->forbid_long_way && !p.weighted && cap >= AG_LOG2CAP_MEDIUM && nb * 2 > (u64)nact * nbins) {
                 if (NW == 1) c->agg_off = true; else c->agg_off_wide = true;
@@ -426,7 +454,20 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     }
     for (int i = 0; i < AG_BATCH && rc == HSK_OK; ++i) {
         if (bt[i].n == 0 || done[i]) continue;
-        if (big || c->forbid_long_way || p.weighted) { outs[i].failed = true; continue; }      // (pairs: the caller goes back to the instance path)
+        if (big || c->forbid_long_way) { outs[i].failed = true; continue; }
+        if (p.weighted) {
+            // {k-mer, count} pairs with a bin beyond the last table (a skewed key prefix: poly-A, satellites): the long way for this task --
+            // full-width passes over the pairs with the counts as payload, then equal keys summed (round 4; rounds 2-3 ran the whole CALL
+            // again on the instance path, which several ranks cannot do: their peers would wait in the exchange)
+            c->stats.redone_tasks++;
+            if (p.own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; p.own_scratch[i] = false; }
+            SortScratch scw; rc = alloc_sort_scratch(c, scw); if (rc) break;
+            u64 *ck = bt[i].out_k, *ok_ = (ck == bt[i].kA) ? bt[i].kB : bt[i].kA, *cv = bt[i].out_v, *ov = (cv == bt[i].vA) ? bt[i].vB : bt[i].vA, *sk, *sv;
+            rc = sort_task_device<NW>(c, ck, ok_, cv, ov, bt[i].n, p.K, scw, &sk, &sv, false);
+            free_sort_scratch(c, scw);
+            if (rc == HSK_OK) rc = merge_sorted_pairs<NW>(c, sk, sv, bt[i].n, d_histo, histo_len, outs[i]);
+            continue;
+        }
         // the long way for this task: full-width passes from the current order, then the two-pass counter
         c->stats.redone_tasks++;
         if (p.own_scratch[i]) { c->pool.release(a.t[i].scratch); a.t[i].scratch = nullptr; p.own_scratch[i] = false; }   // (stream-ordered reuse)
@@ -536,7 +577,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
             if (!longest) break;
             // more than half of all bins beyond 2048 slots: (nearly) as many distinct k-mers as k-mers; the listed bins' tasks take the
             // long way now instead of after the last table
-            static const bool adapt = !(getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 0);
+            const bool adapt = tune("agg_adapt", 1) != 0;
             if (adapt && cap >= AG_LOG2CAP_MEDIUM && listed * 2 > (u64)nact * nbins) {
                 for (int i = 0; i < AG_BATCH; ++i) if (keep.t[i].active && h.flags[(1 + cur) * AG_BATCH + i]) hopeless[i] = true;
                 c->agg_off_wide = true;                      // the batches after this one: no prefix passes and tables at all
@@ -547,7 +588,7 @@ static int agg_ext_finish_batch_device(hsk_ctx *c, BatchTask *bt, int K, const u
         }
         a = keep;
     }
-    { static const bool force_off = getenv("HSK_AGG_ADAPT") && atoi(getenv("HSK_AGG_ADAPT")) == 2;     // (tests: as in agg_stage2)
+    { const bool force_off = tune("agg_adapt", 1) == 2;     // (tests: as in agg_stage2)
       if (force_off) c->agg_off_wide = true; }
     for (int i = 0; i < AG_BATCH; ++i) sa.t[i].active = a.t[i].active;
     hipLaunchKernelGGL(agg_scan_kernel, dim3(AG_BATCH), dim3(AG_THREADS), 0, c->stream, sa);

@@ -29,6 +29,7 @@ struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
     u32 *sm_boff = nullptr;       // byte-store mode (place_bytes_kernel): sm_bytes is complete, sm_boff[slot] = offset inside the task's byte run
+    unsigned short *sm_sub16 = nullptr;   // several ranks, combining extraction on the owner's side: the top 16 minimizer bits of every supermer (they travel with sm_len)
     u32 *sm_sub = nullptr;        // combining extraction (hsk_combine.h): 32 mixed bits of the supermer's minimizer hash ...
     u64 *sm_item = nullptr;       // ... and the supermer itself (place_items_kernel); sm_len / sm_gpos do not exist in this mode
     u64 tot_sup = 0, tot_bytes = 0, tot_kmers = 0;
@@ -41,6 +42,7 @@ struct SupermerStore {
 
 static void free_store(hsk_ctx *c, SupermerStore &s)
 {
+    c->pool.release(s.sm_sub16); s.sm_sub16 = nullptr;
     c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid); c->pool.release(s.sm_boff); c->pool.release(s.sm_sub); s.sm_sub = nullptr; c->pool.release(s.sm_item); s.sm_item = nullptr;
     s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr; s.sm_boff = nullptr;
 }
@@ -62,7 +64,7 @@ static BaseSource source_from_store(const SupermerStore &st, const u8 *d_packed,
 // they stay; HSK_PLACE_BYTES=0/1 forces either.
 static bool place_bytes_enabled(bool supermers_travel)
 {
-    static const int env = getenv("HSK_PLACE_BYTES") ? atoi(getenv("HSK_PLACE_BYTES")) : -1;
+    const int env = (int)tune("place_bytes", -1);
     return env < 0 ? supermers_travel : env != 0;
 }
 
@@ -139,15 +141,14 @@ static int launch_parse_scan(hsk_ctx *c, hipStream_t st, const u64 *blk_cnt, u32
 }
 static bool parse_fast_enabled()
 {
-    static const bool on = !(getenv("HSK_PARSE_FAST") && atoi(getenv("HSK_PARSE_FAST")) == 0);
-    return on;
+    return tune("parse_fast", 1) != 0;
 }
 // Record slots per 2048-position tile.  A window of W k-mers starts a supermer every (W + 1) / 2 positions on random
 // sequence (+ one per 128 positions and per read): 40 % head room, a power of two from SCAN_REC_CAP (W >= 12) to 2048
 // (tiny windows); a tile that still overflows sends the parse through the general kernels.
 static u32 parse_rec_cap(int W)
 {
-    static const int forced = getenv("HSK_PARSE_REC_CAP") ? std::min(std::max(atoi(getenv("HSK_PARSE_REC_CAP")), 1), (int)PLACE_MAX_REC) : 0;
+    const int forced = tune("parse_rec_cap", 0) ? (int)std::min<long long>(std::max<long long>(tune("parse_rec_cap", 0), 1), (long long)PLACE_MAX_REC) : 0;
     if (forced) return (u32)forced;
     const u32 need = (u32)(1.4 * (2.0 * PARSE_TILE / (W + 1) + 40));
     u32 cap = SCAN_REC_CAP;
@@ -188,7 +189,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
-        static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;      // (tests: the default (k, m) through the generic instance)
+        const bool scan_generic = tune("scan_generic", 0) != 0;      // (tests: the default (k, m) through the generic instance)
         auto launch_scan = [&]() {
             if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
             else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
@@ -323,6 +324,10 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     // place_bytes_kernel once; positions are kept only where something still needs them (EXTENSION: pos / rid lookup)
     bool bytes_mode = !item_mode && j.fast && place_bytes_enabled(supermers_travel) && a.rec_cap <= PLACE_BYTES_REC;
     for (u32 t = 0; t < ntasks && bytes_mode; ++t) if (st.task_tot[3 * t + 1] >= (1ULL << 32)) bytes_mode = false;     // 32-bit offsets inside a task's run
+    // several ranks with the combining extraction planned (c->combine_now): the supermers' minimizer bits go into the store as well
+    const bool with_sub16 = bytes_mode && supermers_travel && c->combine_now && a.tile_sub && !ext && !skip;
+    a.sm_sub16 = nullptr;
+    if (with_sub16) { DALLOC(c, st.sm_sub16, unsigned short *, st.tot_sup * 2 + 64); a.sm_sub16 = st.sm_sub16; }
     if (bytes_mode) {
         DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 256);
         DALLOC(c, st.sm_boff, u32 *, st.tot_sup * 4 + 64);
@@ -340,7 +345,7 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
             if (bytes_mode) {
                 ParseArgs ab = a;
                 ab.place_group = std::max<u32>(1, std::min<u32>(PLACE_BYTES_TILES, PLACE_BYTES_REC / a.rec_cap));
-                hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4, c->stream, ab);
+                hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4 + (ab.sm_sub16 ? PLACE_BYTES_REC * 2 : 0), c->stream, ab);
             } else if (item_mode) {
                 ParseArgs ai = a;
                 ai.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));
@@ -435,7 +440,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     EvPair sp{}, pp{};
     if (profile) { sp.a = ev_get(c); sp.b = ev_get(c); sp.kind = 3; sp.bytes = packed_bytes; (void)hipEventRecord(sp.a, sA);
                    pp.a = ev_get(c); pp.b = ev_get(c); pp.kind = 4; (void)hipEventRecord(pp.a, sB); }
-    static const bool scan_generic = getenv("HSK_SCAN_GENERIC") && atoi(getenv("HSK_SCAN_GENERIC")) != 0;
+    const bool scan_generic = tune("scan_generic", 0) != 0;
     for (u32 sl = 0; sl < nsl; ++sl) {
         HIPCHK(c, hipStreamWaitEvent(sA, landed[std::min(sl + 1, nsl - 1)], 0));
         a.slab = sl; a.blk_cnt = d_blk_cnt + (size_t)sl * mat * 3;

@@ -10,7 +10,9 @@
 // (src/kmerops.cpp:130-196, exchange_supermer's stage loop); here the unit is a task group so that a
 // sort batch never waits for bytes it does not need.  HSK_OVERLAP=0 selects one exchange up front.
 // ------------------------------------------------------------------------------------------------
-struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; };
+static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads);      // hsk_api.hip
+
+struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; const unsigned short *sub16 = nullptr; };
 
 // HSK_TEST_FAIL="<rank>:<site>" (tests/test_gpu_rccl.py, read at every call): the named step of that rank fails as if an
 // allocation had returned null.  Sites: sortbuf (before the first task group travels), group1 (the exchange buffers of the
@@ -38,6 +40,7 @@ struct GroupFeeder {
     std::vector<std::vector<PackJob>> packs;           // [group] byte-packing jobs issued with the group (scratch released with it)
     bool lazy_pack = false;                            // the stores' bytes are produced group by group (pack_group_*)
     bool live = false;                                 // RCCL: every rank got past the last agreement before the exchange and will post every group
+    bool with_sub = false;                             // every rank's store carries the supermers' minimizer bits (sm_sub16): they travel, the owners take the combining extraction
     const std::vector<std::vector<ExchangePlan>> *pl_all = nullptr;     // [rank][group]
     u64 bytes_moved = 0;
 
@@ -57,7 +60,8 @@ struct GroupFeeder {
         if (g == 1 && !draining && test_fail(c, "group1")) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d (injected)", g);
         b.len = (u8 *)c->pool.alloc(p.recv_tot_sup + 64); b.bytes = (u8 *)c->pool.alloc(p.recv_tot_bytes + 64); b.nbytes = p.recv_tot_bytes;
         if (ext) { b.pos = (u32 *)c->pool.alloc(p.recv_tot_sup * 4 + 64); b.rid = (int32_t *)c->pool.alloc(p.recv_tot_sup * 4 + 64); }
-        if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid))) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
+        if (with_sub) b.sub16 = (unsigned short *)c->pool.alloc(p.recv_tot_sup * 2 + 64);
+        if (!b.len || !b.bytes || (ext && (!b.pos || !b.rid)) || (with_sub && !b.sub16)) return fail(c, HSK_ERR_OOM, "exchange buffers of group %d", g);
         // the bytes this group sends are packed now, on the communication stream (RCCL: this rank's store; virtual ranks:
         // the store of every source that has not produced group g yet)
         std::vector<SupermerStore *> to_pack;
@@ -86,16 +90,17 @@ struct GroupFeeder {
                 if (!n) continue;
                 HIPCHK(c, hipMemcpyAsync(b.len + p.recv_sup_off[src], ss.sm_len + sp.send_sup_off[rank], n, hipMemcpyDeviceToDevice, s));
                 HIPCHK(c, hipMemcpyAsync(b.bytes + p.recv_byte_off[src], ss.sm_bytes + sp.send_byte_off[rank], nb, hipMemcpyDeviceToDevice, s));
+                if (with_sub) HIPCHK(c, hipMemcpyAsync(b.sub16 + p.recv_sup_off[src], ss.sm_sub16 + sp.send_sup_off[rank], n * 2, hipMemcpyDeviceToDevice, s));
                 if (ext) {
                     HIPCHK(c, hipMemcpyAsync(b.pos + p.recv_sup_off[src], ss.sm_pos + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
                     HIPCHK(c, hipMemcpyAsync(b.rid + p.recv_sup_off[src], ss.sm_rid + sp.send_sup_off[rank], n * 4, hipMemcpyDeviceToDevice, s));
                 }
             }
         } else {
-            int rc = post_exchange(c->comm, s, ext, p, st->sm_len, st->sm_bytes, st->sm_pos, st->sm_rid, b);
+            int rc = post_exchange(c->comm, s, ext, p, st->sm_len, st->sm_bytes, st->sm_pos, st->sm_rid, b, with_sub ? st->sm_sub16 : nullptr);
             if (rc) return fail(c, HSK_ERR_COMM, "supermer exchange (group %d) failed: %d (%s)", g, rc, c->comm.last_error.c_str());
         }
-        bytes_moved += p.recv_tot_bytes + p.recv_tot_sup * (ext ? 9 : 1);
+        bytes_moved += p.recv_tot_bytes + p.recv_tot_sup * (ext ? 9 : 1) + (with_sub ? p.recv_tot_sup * 2 : 0);
         arrived[g] = ev_get(c);
         HIPCHK(c, hipEventRecord(arrived[g], s));
         return HSK_OK;
@@ -155,15 +160,14 @@ struct GroupFeeder {
     TaskInput input(u32 t) const
     {
         const ExchangeBuffers &b = xb[group_of[t]];
-        TaskInput in; in.len = b.len; in.src = source_from_bytes(b.bytes, b.nbytes); in.pos = b.pos; in.rid = b.rid;
+        TaskInput in; in.len = b.len; in.src = source_from_bytes(b.bytes, b.nbytes); in.pos = b.pos; in.rid = b.rid; in.sub16 = b.sub16;
         return in;
     }
 };
 
 static bool overlap_enabled()
 {
-    static const bool on = !(getenv("HSK_OVERLAP") && atoi(getenv("HSK_OVERLAP")) == 0);
-    return on;
+    return tune("overlap", 1) != 0;
 }
 
 // ---- heavy-hitter tasks (a8): the owner's side --------------------------------------------------------------
@@ -182,25 +186,9 @@ static int heavy_merge_task(hsk_ctx *c, const u64 *d_entries, u64 n, u64 *d_hist
     rc = sort_task_device<NW>(c, kA, kB, vA, vB, n, c->cfg.kmer_size, sc, &sk, &sv);
     free_sort_scratch(c, sc);
     if (rc) return rc;
-    const u64 ntiles = (n + HV_THREADS - 1) / HV_THREADS;
-    u64 *d_tile, *d_total;
-    DALLOC(c, d_tile, u64 *, ntiles * 8 + 64); DALLOC(c, d_total, u64 *, 256);
-    HeavyMergeArgs a; memset(&a, 0, sizeof a);
-    a.keys = sk; a.cnts = sv; a.n = n; a.lower = (u64)c->cfg.lower_freq; a.upper = (u64)c->cfg.upper_freq; a.tile_cnt = d_tile; a.histo = d_histo; a.histo_len = histo_len;
-    hipLaunchKernelGGL((heavy_merge_kernel<NW, false>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
-    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(CNT_THREADS), 0, c->stream, d_tile, ntiles, d_total);
-    u64 *tot = (u64 *)((char *)c->pinned + c->pinned_bytes - 128);
-    HIPCHK(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    rc = merge_sorted_pairs<NW>(c, sk, sv, n, d_histo, histo_len, out); if (rc) return rc;
     HIPCHK(c, hsk_sync(c, c->stream));
-    out.n = tot[0];
-    if (out.n) {
-        DALLOC(c, out.entries, u64 *, out.n * (NW + 1) * 8);
-        a.entries = out.entries;
-        hipLaunchKernelGGL((heavy_merge_kernel<NW, true>), dim3((u32)ntiles), dim3(HV_THREADS), 0, c->stream, a);
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hsk_sync(c, c->stream));
-    c->pool.release(kA); c->pool.release(kB); c->pool.release(vA); c->pool.release(vB); c->pool.release(d_tile); c->pool.release(d_total);
+    c->pool.release(kA); c->pool.release(kB); c->pool.release(vA); c->pool.release(vB);
     return HSK_OK;
 }
 
@@ -219,11 +207,8 @@ struct WidenPool {
     explicit WidenPool(hsk_ctx *c_) : c(c_) {}
     static int nthreads()
     {
-        static const int n = []() {
-            if (const char *e = getenv("HSK_WIDEN_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 64); }
-            const unsigned hc = std::thread::hardware_concurrency();
-            return (int)std::min<unsigned>(32, std::max<unsigned>(2, hc / 2));
-        }();
+        { const int v = (int)tune("widen_threads", 0); if (v > 0) return std::min(v, 64); }
+        static const int n = []() { const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min<unsigned>(32, std::max<unsigned>(2, hc / 2)); }();
         return n;
     }
     // A batch arrives task by task (one copy + one event per piece): thread t widens slice t of every piece in turn, so that all
@@ -303,7 +288,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     HIPCHK(c, hipMemsetAsync(d_histo, 0, (size_t)histo_len * 8, c->stream));
     // Tasks are sorted eight at a time, one per XCD (sort_batch_device); a remainder of fewer than eight
     // tasks goes through the single-task kernel.  HSK_XCD_BATCH=0 forces the single-task path.
-    static const bool batch_env = !(getenv("HSK_XCD_BATCH") && atoi(getenv("HSK_XCD_BATCH")) == 0);
+    const bool batch_env = tune("xcd_batch", 1) != 0;
     const bool batch_enabled = batch_env && c->xcd_batch_ok;          // the one-task-per-XCD kernels need all eight XCDs (hsk_init's census)
     std::vector<u32> mine;
     for (u32 t = 0; t < ntasks; ++t) if (owner[t] == rank && segs[t].nkmers) mine.push_back(t);
@@ -312,7 +297,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     const u32 EMPTY_TASK = ~0u;
     TaskSegs empty_segs;
     std::vector<TaskOut> touts(ntasks);
-    const bool forced = ((ex && ex->force_batch) || x_src.item != nullptr) && batch_enabled;      // (item-mode store: every task goes through whole batches)
+    // several ranks, the supermers arrived with their minimizer bits: the owner builds the items, batch by batch (hsk_combine.h, 1b)
+    const bool fed_wanted = NW == 1 && feeder && feeder->with_sub && c->combine_now && !ext;
+    const bool forced = ((ex && ex->force_batch) || x_src.item != nullptr || fed_wanted) && batch_enabled;      // (item-mode store: every task goes through whole batches)
     // a caller's task count below eight (the reference's default for one rank is five): three to seven tasks of some size still
     // go faster as one padded batch (5/8 of the batch path's rate) than one by one on the single-task path (about 1/3 of it)
     u64 mine_kmers = 0; for (u32 t : mine) mine_kmers += segs[t].nkmers;
@@ -336,14 +323,14 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // and with it the batch's result copy, by one batch: host results take 214 ms with it and 197 ms without.  Default: on
     // when the result stays in HBM (nothing to copy), off when it goes to the host; HSK_LAG=0/1 forces it.
     const bool keep_dev = (c->cfg.flags & HSK_FLAG_KEEP_DEVICE) != 0;
-    static const int lag_env = getenv("HSK_LAG") ? atoi(getenv("HSK_LAG")) : -1;
+    const int lag_env = (int)tune("lag", -1);
     const bool lag_enabled = lag_env < 0 ? keep_dev : lag_env != 0;
     const bool lag = batch && agg && NW <= 2 && lag_enabled && mine.size() >= 2 * (size_t)XCD_BATCH;
     const int nslot = lag ? 2 : 1;
     // expand fused with the first scatter pass (hsk_scatter.h): one-word keys, aggregating finish, whole batches
     // (EXTENSION: payload chunks beside the key chunks, HSK_FUSED_SCATTER_EXT=0 turns that variant off)
-    static const bool xs_ext_enabled = !(getenv("HSK_FUSED_SCATTER_EXT") && atoi(getenv("HSK_FUSED_SCATTER_EXT")) == 0);
-    static const bool xs_wide_enabled = !(getenv("HSK_FUSED_SCATTER_WIDE") && atoi(getenv("HSK_FUSED_SCATTER_WIDE")) == 0);      // two-word keys
+    const bool xs_ext_enabled = tune("fused_scatter_ext", 1) != 0;
+    const bool xs_wide_enabled = tune("fused_scatter_wide", 1) != 0;      // two-word keys
     constexpr int XS_CH = XsCfg<(NW <= 2 ? NW : 1)>::CHUNK;
     const bool xs = batch && (NW == 1 ? (!ext || xs_ext_enabled) : (NW == 2 && !ext && xs_wide_enabled && prefix_top_bits(K, NW) == 16)) && scatter_enabled() &&
                     scatter_store_keys(max_task, XS_CH) < (1ULL << 32) && finish_enabled() && hybrid_enabled() && agg_enabled() && prefix_plan_ok<NW>(K, true);
@@ -352,9 +339,15 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // (an item-mode store -- x_src.item -- holds nothing the instance path could read: every batch takes the combining extraction, or the
     //  call starts again without it)
     const bool item_mode = x_src.item != nullptr;
-    if constexpr (NW == 1) combine = item_mode && xs && agg && !c->agg_off && !ext && !feeder && mine.size() % XCD_BATCH == 0;
+    bool fed_combine = false;
+    if constexpr (NW == 1) {
+        combine = item_mode && xs && agg && !c->agg_off && !ext && !feeder && mine.size() % XCD_BATCH == 0;
+        fed_combine = fed_wanted && !item_mode && xs && agg && !c->agg_off && batch && mine.size() % XCD_BATCH == 0;
+        combine = combine || fed_combine;
+    }
     if (item_mode && !combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
     BucketOrder border;
+    BucketOrder border_fed[2]; FedItems fed_items[2];      // per slot: the items and the bucket order of the batch in flight (several ranks)
     bool slot_combine[2] = {false, false};
     ScatterBatch sbatch[2];                               // per slot
     PassDesc xs_plan[MAX_PASSES];
@@ -396,13 +389,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     // The pinned block is sized from the entries-per-k-mer ratio of the previous call (or of this call's first batch);
     // should the list outgrow it, the early copies are abandoned and everything is copied again at the end.
     const bool keep = keep_dev;
-    static const bool early_enabled = !(getenv("HSK_EARLY_D2H") && atoi(getenv("HSK_EARLY_D2H")) == 0);
+    const bool early_enabled = tune("early_d2h", 1) != 0;
     bool early = batch && agg && NW <= 2 && !keep && !ext && early_enabled && !(ex && ex->heavy_in && !ex->heavy_in->empty());
     u64 *early_buf = nullptr; u64 early_cap = 0, early_used = 0, early_kmers = 0;
     // compact copies (HSK_COMPACT_D2H=0: entries travel as they are): counts fit 16 bits whenever the filter's upper bound does
     // HSK_COMPACT_D2H: 0 entries as they are (16 bytes), 1 k-mer words + 16-bit counts (10 bytes), 2 (default) the prefix form for
     // one-word keys (7 bytes with U <= 255, else 8; + 256 KB of directory per task)
-    static const int compact_mode = getenv("HSK_COMPACT_D2H") ? atoi(getenv("HSK_COMPACT_D2H")) : 2;
+    const int compact_mode = (int)tune("compact_d2h", 2);
     const bool compact = compact_mode > 0 && c->cfg.upper_freq <= 65535;
     WidenPool widen(c);
     u64 compact_bytes = 0, compact_entries = 0;
@@ -516,8 +509,8 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         slot_agg[sl] = agg && !(NW == 1 ? c->agg_off : c->agg_off_wide);
         slot_fext[sl] = fused_ext && !c->agg_off_wide;
         slot_follow[sl] = slot_agg[sl] || slot_fext[sl] || (NW == 1 && fused);
-        const bool will_combine = combine && border.active && slot_agg[sl];
-        if (combine && !will_combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+        const bool will_combine = combine && (fed_combine || border.active) && slot_agg[sl];
+        if (combine && !will_combine && !fed_combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }      // (several ranks: the batch simply takes the instance path -- nobody starts a call again while peers wait)
         const int prefix_bits = will_combine ? combine_prefix_bits(c) : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
@@ -546,7 +539,16 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                 for (int i = 0; i < XCD_BATCH; ++i) { tk[i] = mine[bpos + i]; gh[i] = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
                 u64 *h_nout = (u64 *)((char *)c->pinned + c->pinned_bytes - 2048 + (size_t)sl * 128);
-                rc = combine_batch(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc;
+                if (fed_combine) {
+                    const unsigned short *s16[XCD_BATCH];
+                    for (int i = 0; i < XCD_BATCH; ++i) s16[i] = tk[i] == EMPTY_TASK ? nullptr : feeder->input(tk[i]).sub16;
+                    std::vector<TaskSegs> gsegs; BaseSource gsrc;
+                    rc = build_items_batch(c, ntasks, tk, jobs, s16, gsegs, gsrc, fed_items[sl], c->stream); if (rc) return rc;
+                    rc = bucket_order_tasks(c, ntasks, gsegs, std::vector<u32>(tk, tk + XCD_BATCH), gsrc, FED_VT_SHIFT, border_fed[sl]); if (rc) return rc;
+                    if (!border_fed[sl].active) return fail(c, HSK_ERR_UNSUPPORTED, "a task of 2^32 supermers and more");
+                    rc = combine_batch(c, tk, bts[sl], gh, plan, border_fed[sl], h_nout, sbatch[sl], c->stream); if (rc) return rc;
+                    fed_release(c, fed_items[sl]); bucket_release(c, border_fed[sl]);      // (stream-ordered reuse: their readers are enqueued)
+                } else { rc = combine_batch(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc; }
                 slot_combine[sl] = sbatch[sl].active;
             }
         } else
@@ -586,7 +588,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         return HSK_OK;
     };
-    if (combine) {
+    if (combine && !fed_combine) {
         pt.begin(PH_EXTRACT);
         int rc = bucket_order_tasks(c, ntasks, segs, mine, x_src, ex ? ex->vt_shift : 0, border); if (rc) return rc;
         pt.end(PH_EXTRACT);
@@ -848,13 +850,16 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     if (c->combine_off && ++c->combine_off_calls >= c->combine_off_period) { c->combine_off = false; c->combine_off_calls = 0; c->combine_prefix_floor = 0; }      // (another look: the bin width starts from the default again as well)
     // the combining extraction pays from a few hundred million k-mers on (a bucket order of the supermers comes first); HSK_COMBINE_MIN_BYTES
     // moves the limit (tests: 0)
-    static const u64 combine_min = getenv("HSK_COMBINE_MIN_BYTES") ? (u64)atoll(getenv("HSK_COMBINE_MIN_BYTES")) : (64ULL << 20);
+    const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
     // this call's own estimate of the input (estimate_plan) decides where there is one; the context's memory of earlier calls (combine_off, agg_off) where there is none
     const bool est = c->est.valid;
     const bool combine_pays = !c->combine_left_now && (est ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off);
     if (est && c->agg_off && c->plan_attempt == 0) { c->agg_off = false; c->agg_off_calls = 0; }      // (process_rank decides again, from the estimate and the task sizes)
-    c->combine_now = NW == 1 && nranks == 1 && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
-                     c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok;
+    // several ranks (round 4): the supermers travel as byte runs with 16 of their minimizer bits, the OWNER of a task builds the items (hsk_combine.h, 1b);
+    // needs the grouped exchange and the byte-store placement, and every rank's consent (below)
+    c->combine_now = NW == 1 && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
+                     c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok &&
+                     (nranks == 1 || (overlap_enabled() && place_bytes_enabled(true)));
     c->combine_veto = false;
     // the combining extraction wants buckets of ~12 k k-mers: the parse itself splits every task by the top minimizer bits (virtual
     // tasks, up to 16 per task and HSK_MAX_TASKS in all: ParseArgs::vt_shift), the bucket order does the rest (hsk_combine.h)
@@ -863,16 +868,19 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     pt.begin(PH_TOTAL);
 
     u32 ntasks = c->cfg.ntasks ? (u32)c->cfg.ntasks : auto_ntasks(c, packed_bytes, nranks);
-    if (c->comm.active() && !c->cfg.ntasks) {
-        // every rank must use the same task count: take the maximum of the local proposals
-        u64 v = ntasks; int rc = c->comm.allreduce_max_u64(&v, 1, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks) failed: %d", rc);
-        ntasks = (u32)v;
+    if (c->comm.active()) {
+        // every rank must use the same task count (the maximum of the local proposals) and the same plan (the combining extraction only if
+        // every rank's own estimate says its input pays for it: the minimizer bits either travel from all ranks or from none)
+        u64 v[2] = {c->cfg.ntasks ? 0ULL : (u64)ntasks, c->combine_now ? 0ULL : 1ULL};
+        int rc = c->comm.allreduce_max_u64(v, 2, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks, plan) failed: %d", rc);
+        if (!c->cfg.ntasks) ntasks = (u32)v[0];
+        if (v[1]) c->combine_now = false;
     }
     out->ntasks = (int32_t)ntasks;
     // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records; more real tasks than that: the instance path)
-    if (ntasks > 768) c->combine_now = false;
-    if (c->combine_now) { u32 sh = 0; while (sh < 4 && ((u64)ntasks << (sh + 1)) <= 768) ++sh; c->vt_shift = sh; }
-    if (c->combine_now && est) {
+    if (ntasks > 768 && nranks == 1) c->combine_now = false;
+    if (c->combine_now && nranks == 1) { u32 sh = 0; while (sh < 4 && ((u64)ntasks << (sh + 1)) <= 768) ++sh; c->vt_shift = sh; }
+    if (c->combine_now && est && nranks == 1) {
         // a task has at most 2^14 buckets (CS_MAX_LOG2NB; 2^(10 + virtual-task bits)): few, large tasks make buckets whose distinct k-mers overflow the
         // 2048-slot tables again and again (partial pairs: the detour stops paying) -- predicted from the estimate instead of found out by a batch
         const u32 lg = (u32)std::min<int>(CS_MAX_LOG2NB, CS_MAX_LOCAL + (int)c->vt_shift);
@@ -895,7 +903,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     bool pipelined = false;
     pt.begin(PH_PARSE);
     // one GPU, reads arriving from pinned host memory, no payload: ingest, scan and placement as one pipeline over slabs
-    static const bool pipe_enabled = !(getenv("HSK_INGEST_PIPELINE") && atoi(getenv("HSK_INGEST_PIPELINE")) == 0);
+    const bool pipe_enabled = tune("ingest_pipeline", 1) != 0;
     if (nranks == 1 && !ext && c->h2d_src && pipe_enabled && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M) {
         const u8 *src = c->h2d_src; c->h2d_src = nullptr;
         std::vector<TaskSegs> segs_v;
@@ -990,11 +998,14 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
             // placement or byte packing failed leaves together with its peers)
             std::vector<u64> M((size_t)nranks * ntasks * 3, 0);
             if (!local_rc) for (size_t i = 0; i < (size_t)ntasks * 3; ++i) M[(size_t)rank * ntasks * 3 + i] = st.task_tot[i];
+            M.push_back((!local_rc && (st.sm_sub16 != nullptr || st.tot_sup == 0)) ? 1 : 0);      // this rank's supermers carry their minimizer bits (or it has none to send)
             const int st_ = c->comm.allreduce_with_status(M, RCCL_SUM, local_rc != 0, c->stream, c->pool);
             if (st_ < 0) return fail(c, HSK_ERR_COMM, "allreduce(size matrix) failed: %d (%s)", st_, c->comm.last_error.c_str());
             if (st_ > 0) return local_rc ? local_rc : fail(c, HSK_ERR_COMM, "another rank failed before the supermer exchange");
+            const bool all_sub = M.back() == (u64)nranks && c->combine_now;
+            M.pop_back();
             rc = feeder.plan(c, nranks, rank, ntasks, owner, order, M, st.task_base, segs); if (rc) return rc;
-            feeder.st = &st; feeder.lazy_pack = true; fed = true;
+            feeder.st = &st; feeder.lazy_pack = true; feeder.with_sub = all_sub; fed = true;
         } else {
             rc = exchange_supermers(c->comm, c->stream, c->pool, ext, K, ntasks, owner, order, st.task_tot, st.task_base,
                                     st.sm_len, st.sm_bytes, st.sm_pos, st.sm_rid, xb, segs, local_rc != 0);
@@ -1115,6 +1126,16 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<int64_t> rid_base(R, 0);
     for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
+    // the plan, as run_pipeline chooses it with several ranks: the sketch of a rank's reads (here: of the first virtual rank that has some)
+    c->combine_now = false; c->vt_shift = 0; c->combine_left_now = false;
+    if (NW == 1 && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
+        const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
+        int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;
+        int erc = estimate_plan(c, in[r0].packed, packed_bytes[r0], in[r0].roff, in[r0].rlen, nreads[r0]); if (erc) return erc;
+        const bool pays = c->est.valid ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off;
+        c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !c->agg_off;
+    }
+    struct PlanReset { hsk_ctx *c; ~PlanReset() { c->combine_now = false; c->est.valid = false; } } plan_reset{c};
     // 1. hash every rank's reads once (parse_count), sum the task sizes, dispatch
     std::vector<u64> bytes(ntasks, 0);
     std::vector<ParseJob> jobs(R);
@@ -1205,7 +1226,9 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         std::vector<GroupFeeder> fd(R);
         std::vector<std::vector<ExchangePlan>> pl_all(R);
         std::vector<std::vector<TaskSegs>> segs(R);
-        for (int d = 0; d < R; ++d) { int rc = fd[d].plan(c, R, d, ntasks, owner, order, M, st[d].task_base, segs[d]); if (rc) return rc; pl_all[d] = fd[d].pl; }
+        bool all_sub = c->combine_now;
+        for (int r = 0; r < R; ++r) if (st[r].tot_sup && !st[r].sm_sub16) all_sub = false;
+        for (int d = 0; d < R; ++d) { int rc = fd[d].plan(c, R, d, ntasks, owner, order, M, st[d].task_base, segs[d]); if (rc) return rc; pl_all[d] = fd[d].pl; fd[d].with_sub = all_sub; }
         int rc_all = HSK_OK;
         for (int r = 0; r < R && rc_all == HSK_OK; ++r) {
             fd[r].st_all = &st; fd[r].pl_all = &pl_all; fd[r].lazy_pack = true;

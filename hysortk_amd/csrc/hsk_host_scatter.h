@@ -19,8 +19,7 @@ struct ScatterBatch {
 
 static bool scatter_enabled()
 {
-    static const bool on = !(getenv("HSK_FUSED_SCATTER") && atoi(getenv("HSK_FUSED_SCATTER")) == 0);
-    return on;
+    return tune("fused_scatter", 1) != 0;
 }
 // keys the chunk store of a task of n k-mers must hold (less than one chunk is wasted per digit)
 static size_t scatter_store_keys(u64 n, int chunk) { return (size_t)(n / chunk + 257) * chunk; }
@@ -82,7 +81,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     const bool ext = c->cfg.extension != 0;
     // expand_scatter2_kernel (two sweeps per flush, three workgroups per CU: 33.0 against 36.2 ms per step on the benchmark) takes
     // one-word keys without payload whose bases are read in place, at most XS_MAXSEG segments per task; HSK_XS2=0: the one-sweep kernel
-    static const bool xs2_env = !(getenv("HSK_XS2") && atoi(getenv("HSK_XS2")) == 0);
+    const bool xs2_env = tune("xs2", 1) != 0;
     bool xs2 = xs2_env && NW == 1 && !ext;
     for (int i = 0; i < XCD_BATCH && xs2; ++i) if (xi[i] >= 0 && !(reads_in_place(jobs[i].src) && jobs[i].ts->segs.size() <= (size_t)XS_MAXSEG)) xs2 = false;
     if constexpr (NW == 1) {
@@ -111,7 +110,7 @@ static int scatter_expand_batch(hsk_ctx *c, const ExpandJob *jobs, const BatchTa
     }
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 1; ep.keys = ntot; ep.bytes = ntot * (ext ? 16 : 8 * NW); (void)hipEventRecord(ep.a, stream); }
     const u32 grid = (u32)occ * 256u;
-    static const bool xs_generic = getenv("HSK_SCATTER_GENERIC") && atoi(getenv("HSK_SCATTER_GENERIC")) != 0;        // (tests: the default k through the generic instance)
+    const bool xs_generic = tune("scatter_generic", 0) != 0;        // (tests: the default k through the generic instance)
     if constexpr (NW == 1) {
         if (ext) hipLaunchKernelGGL((expand_scatter_kernel<1, true>), dim3(grid), dim3(XS_THREADS), 0, stream, a);
         else if (a.k == 31 && a.shift0 == 48 && a.shift1 == 56 && !xs_generic) hipLaunchKernelGGL((expand_scatter_kernel<1, false, 31>), dim3(grid), dim3(XS_THREADS), 0, stream, a);

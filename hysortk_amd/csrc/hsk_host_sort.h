@@ -57,16 +57,14 @@ static int make_split_prefix_plan(PassDesc *out, int top, int nw)
 // tasks of 2^30 keys and more use 64-bit look-back words; HSK_WIDE_LOOKBACK=1 forces them (tests: such tasks do not fit a test)
 static bool force_wide_lookback()
 {
-    static const bool on = getenv("HSK_WIDE_LOOKBACK") && atoi(getenv("HSK_WIDE_LOOKBACK")) != 0;
-    return on;
+    return tune("wide_lookback", 0) != 0;
 }
 
 // The first of several prefix passes need not be stable when an aggregation (which only needs the records GROUPED by the
 // prefix) follows: its ranking is then a single LDS atomic per key.  HSK_UNSTABLE_FIRST=0 keeps it stable.
 static bool unstable_first_pass()
 {
-    static const bool on = !(getenv("HSK_UNSTABLE_FIRST") && atoi(getenv("HSK_UNSTABLE_FIRST")) == 0);
-    return on;
+    return tune("unstable_first", 1) != 0;
 }
 
 struct SortScratch {

@@ -82,6 +82,8 @@ struct ParseArgs {
     // k-mer among them -- get the same value, independent of the task id (which is the hash modulo the task count)
     u32 *tile_sub;
     u32 *sm_sub;
+    unsigned short *sm_sub16;  // byte-store placement with several ranks (round 4): the top 16 of those bits beside sm_len -- they travel with the supermers, and the
+                               // OWNER of a task builds the items and orders them by minimizer bucket (hsk_combine.h: items_build_kernel)
     u32 vt_shift;              // virtual tasks: `ntasks` = real tasks << vt_shift, task id = (hash mod real tasks) << vt_shift | top vt_shift minimizer bits (fm is the real count's)
     u64 *sm_item;              // place_items_kernel: two words per supermer -- its first 64 bases, left-aligned, the k-mer count (<= 16) in the low byte of the second
     const u8 *task_skip;       // optional [ntasks]: supermers of these tasks are not stored (heavy-hitter tasks travel as k-mer lists)
@@ -992,6 +994,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
     u32 *s_tpre = reinterpret_cast<u32 *>(s_tc + nt);
     u64 *s_srt = reinterpret_cast<u64 *>(s_tpre + 2 * nt);
     u32 *s_words = reinterpret_cast<u32 *>(s_srt + PLACE_BYTES_REC);
+    unsigned short *s_sub = reinterpret_cast<unsigned short *>(s_words + PLACE_BYTES_WORDS);      // (only with a.sm_sub16: the host adds the room)
     for (u32 t = tid; t < nt; t += PARSE_THREADS) {
         s_cur[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2];
         s_curb[t] = a.blk_base[((u64)blockIdx.x * nt + t) * 2 + 1];
@@ -1028,15 +1031,16 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
         }
         __syncthreads();
         const u32 total = s_go[PLACE_BYTES_TILES];
-        u32 rec[RPT]; u64 got[RPT];
+        u32 rec[RPT]; u64 got[RPT]; unsigned short sb16[RPT];
 #pragma unroll
         for (int x = 0; x < RPT; ++x) {
             const u32 i = x * PARSE_THREADS + tid;
-            rec[x] = 0xFFFFFFFFu; got[x] = 0;
+            rec[x] = 0xFFFFFFFFu; got[x] = 0; sb16[x] = 0;
             if (i < total) {
                 u32 j = 0;
                 while (j + 1 < ng && s_go[j + 1] <= i) ++j;
                 const u32 r = a.tile_rec[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])];
+                if (a.sm_sub16) sb16[x] = (unsigned short)(a.tile_sub[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])] >> 16);
                 rec[x] = r | (j << 28);
                 const u32 nb = (((r >> 11) & 127u) + (u32)K + 3u) >> 2;          // (k-mers - 1) + K bases
                 got[x] = atomicAdd((unsigned long long *)&s_tc[(r >> 18) & 1023u], (1ULL << 32) | (unsigned long long)nb);
@@ -1054,7 +1058,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
         __syncthreads();
 #pragma unroll
         for (int x = 0; x < RPT; ++x)
-            if (rec[x] != 0xFFFFFFFFu) s_srt[s_tpre[(rec[x] >> 18) & 1023u] + (u32)(got[x] >> 32)] = (u64)rec[x] | (got[x] << 32);   // {record, byte offset in the task's run}
+            if (rec[x] != 0xFFFFFFFFu) {
+                const u32 at = s_tpre[(rec[x] >> 18) & 1023u] + (u32)(got[x] >> 32);
+                s_srt[at] = (u64)rec[x] | (got[x] << 32);   // {record, byte offset in the task's run}
+                if (a.sm_sub16) s_sub[at] = sb16[x];
+            }
         __syncthreads();
         for (u32 i = tid; i < total; i += PARSE_THREADS) {
             const u64 e = s_srt[i];
@@ -1067,6 +1075,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
             const u32 nb = (len + 3) >> 2;
             a.sm_len[slot] = (u8)len;
             a.sm_boff[slot] = (u32)(babs - s_tbase[d]);
+            if (a.sm_sub16) a.sm_sub16[slot] = s_sub[i];
             if (a.sm_gpos) a.sm_gpos[slot] = (tfirst + (r >> 28)) * PARSE_TILE + (u64)(r & 2047);
             const u32 bit0 = 2u * ((r >> 28) * (u32)PARSE_TILE + (r & 2047u));
             const u64 tailmask = (len & 3u) ? ~(u64)(0xFFu >> (2 * (len & 3u))) : ~0ULL;   // zero bits behind the last base (in its byte = the lowest byte of a big-endian word)

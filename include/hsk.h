@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HSK_ABI_VERSION 3
+#define HSK_ABI_VERSION 4
 
 typedef enum {
     HSK_OK = 0,
@@ -54,7 +54,9 @@ typedef struct {
     int32_t radix_bits;       /* digit width of the LSD radix sort: 8 (default) */
     int32_t flags;            /* HSK_FLAG_* */
     double  unbalanced_ratio; /* UNBALANCED_RATIO (2.3): a task is a heavy hitter above ratio x the mean task (kmerops.cpp:1190); ABI 3 */
-    int64_t reserved[3];
+    const char *tuning;       /* ABI 4 (was reserved[0]): NULL, or "name=value,name=value": forced paths for tests and a few measured thresholds, read per
+                                 context (rounds 1-3: process-wide environment variables).  Copied by hsk_init. */
+    int64_t reserved[2];
 } hsk_config;
 
 #define HSK_FLAG_PROFILE      1   /* HIP-event timing of every radix scatter launch (hsk_stats) */

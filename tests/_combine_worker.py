@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_combine.py: counts one synthetic input under the environment the parent chose (the switches of the
-combining extraction are read once per process) and prints one JSON line per call: digest of the list, entries, and the
+"""Helper of tests/test_gpu_combine.py (run_spec, called in process; `python _combine_worker.py <json>` prints the same as JSON lines): counts one
+synthetic input on a context with the tuning the test chose and returns one dict per call: digest of the list, entries, and the
 statistics that tell which plan ran.  spec: K, M, L, U, ntasks, genome, read_len, nreads, seed, error_rate, calls (list of
 "device" | "host" | "pinned"), plan."""
 import hashlib
@@ -19,9 +19,10 @@ def digest(r):
     return hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest()
 
 
-def main():
-    spec = json.loads(sys.argv[1])
-    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], ntasks=spec["ntasks"], profile=True, plan=spec.get("plan"))
+def run_spec(spec):
+    """counts one synthetic input on a context of its own; returns one dict per call (tests/test_gpu_combine.py calls this in process)"""
+    out = []
+    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], ntasks=spec["ntasks"], profile=True, plan=spec.get("plan"), tuning=spec.get("tuning"))
     dp, nb, do, dl = ctx.synth_reads(spec["genome"], spec["read_len"], spec["nreads"], spec["seed"], error_rate=spec.get("error_rate", 0.0))
     n = spec["nreads"]
     packed = np.empty(nb, np.uint8); off = np.empty(n, np.uint64); lens = np.empty(n, np.uint32)
@@ -29,6 +30,24 @@ def main():
     pinned = None
     for how in spec["calls"]:
         ctx.stats(reset=True)
+        if how.startswith("loopback:"):
+            # R virtual ranks over the same reads, split evenly (hsk_count_loopback_device): one line per call, digest over the ranks' lists in rank order
+            R = int(how.split(":")[1])
+            per = n // R
+            nbr = (spec["read_len"] + 3) // 4
+            reads = [(dp.value + r * per * nbr, per * nbr, do, dl, per) for r in range(R)]      # (fixed-length reads: every rank's offsets start at 0 again -- the same array serves)
+            res, owner = ctx.count_loopback_device(reads)
+            st = ctx.stats(reset=True)
+            h = hashlib.sha256()
+            ent = 0
+            for t in range(len(owner)):
+                kl = res[int(owner[t])]
+                a, b = int(kl.task_off[t]), int(kl.task_off[t + 1])
+                h.update(kl.kmers[a:b].tobytes()); h.update(kl.cnt[a:b].tobytes()); ent += b - a
+            out.append({"how": how, "digest": h.hexdigest(), "entries": ent, "total_kmers": int(sum(k.info["total_kmers"] for k in res)),
+                              "combine_launches": int(st["combine_launches"]), "combine_pairs": int(st["combine_pairs"]), "combine_kmers": int(st["combine_kmers"]),
+                              "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"])})
+            continue
         if how == "device":
             r = ctx.count_device(dp, nb, do, dl, n)
         elif how == "host":
@@ -39,9 +58,9 @@ def main():
                 pinned[0][:] = packed; pinned[1][:] = off; pinned[2][:] = lens
             r = ctx.count(pinned)
         st = ctx.stats(reset=True)
-        print(json.dumps({"how": how, "digest": digest(r), "entries": len(r), "total_kmers": int(r.info["total_kmers"]),
+        out.append({"how": how, "digest": digest(r), "entries": len(r), "total_kmers": int(r.info["total_kmers"]),
                           "combine_launches": int(st["combine_launches"]), "combine_pairs": int(st["combine_pairs"]), "combine_kmers": int(st["combine_kmers"]),
-                          "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"])}), flush=True)
+                          "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"])})
     if spec.get("dump"):
         np.savez(spec["dump"], kmers=r.kmers, cnt=r.cnt, task_off=r.task_off, packed=packed, off=off, lens=lens)
     if pinned is not None:
@@ -49,6 +68,12 @@ def main():
             H.pinned_free(a)
     ctx.synth_free(dp, do, dl)
     ctx.close()
+    return out
+
+
+def main():
+    for d in run_spec(json.loads(sys.argv[1])):
+        print(json.dumps(d), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), "libhsk.so does not export " + name
     assert sorted(_lib.SYMBOLS) == decl, "hysortk_amd/_lib.py SYMBOLS out of sync with include/hsk.h"
-    assert lib.hsk_abi_version() == 3
+    assert lib.hsk_abi_version() == 4
 
 
 def test_struct_sizes_match_header():

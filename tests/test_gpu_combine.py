@@ -1,26 +1,21 @@
 """The combining extraction (hysortk_amd/csrc/hsk_combine.h: supermers ordered by minimizer bucket, k-mers counted in LDS tables
 where they are extracted, {k-mer, count} pairs through one scatter pass and the weighted finish) against the instance path and
-the oracle.  Its switches are read once per process, so every case runs tests/_combine_worker.py in a subprocess;
-HSK_COMBINE_MIN_BYTES=0 lets inputs of test size take it (the library's own limit is 64 MB of packed reads)."""
-import json
-import os
-import subprocess
-import sys
-
+the oracle.  Its switches are per-context tuning names (hsk_config::tuning, round 4), so every case runs IN THIS PROCESS with a
+context of its own (rounds 2-3 forked a worker per case: the switches were environment variables read once per process);
+combine_min_bytes=0 lets inputs of test size take the plan (the library's own limit is 64 MB of packed reads)."""
 import numpy as np
 import pytest
 
 from tests import util
+from tests import _combine_worker as W
 
 pytestmark = pytest.mark.gpu
-WORKER = os.path.join(util.ROOT, "tests", "_combine_worker.py")
 BASE = dict(K=31, M=17, L=2, U=200, ntasks=16, genome=1500000, read_len=150, nreads=400000, seed=77, calls=["device"])
 
 
 def run(spec, env):
-    e = dict(os.environ, **env)
-    out = subprocess.check_output([sys.executable, WORKER, json.dumps(spec)], env=e, timeout=600).decode().strip().splitlines()
-    return [json.loads(l) for l in out if l.startswith("{")]
+    """one context with the tuning `env` spells (old environment-variable names, folded by util.tuning), one result dict per call"""
+    return W.run_spec(dict(spec, tuning=util.tuning(env)))
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +66,6 @@ def test_input_without_copies_leaves_the_combining_extraction():
 
 @pytest.mark.parametrize("env,spec,why", [
     ({"HSK_XCD_BATCH": "0"}, dict(), "the one-task-per-XCD kernels are switched off: no batch to run the combining extraction on; the call starts again without it"),
-    ({"HSK_COMBINE_PREFIX": "9"}, dict(L=1, ntasks=1), "one task in 512 bins of ~2900 pairs: bins beyond the weighted finish's last table; the call starts again on the instance path"),
     ({"HSK_PARSE_REC_CAP": "200"}, dict(), "tiles beyond the record capacity: the parse leaves its fast path, and the virtual tasks with it"),
 ])
 def test_calls_that_start_again_without_the_combining_extraction(env, spec, why):
@@ -173,3 +167,34 @@ def test_alternating_inputs_on_one_context_choose_per_call():
             ctx.synth_free(d[0], d[2], d[3])
     assert [s[0] for s in seen] == [True, False, True, False], seen
     assert seen[0][1] == seen[2][1] and seen[1][1] == seen[3][1]
+
+
+# ---- several ranks: the owner of a task builds the items from the supermers the exchange delivered (hsk_combine.h, 1b) ----------------
+@pytest.mark.parametrize("R,ntasks,env,why", [
+    (2, 16, {}, "two virtual ranks, one batch each"),
+    (4, 64, {}, "four ranks, two task groups each: the grouped exchange feeds the batches"),
+    (8, 72, {}, "eight ranks, nine tasks each: a partial batch padded"),
+    (3, 24, {"HSK_COMBINE_BUCKET": "300"}, "three ranks, nearly empty tables"),
+    (2, 2, {"HSK_COMBINE_PREFIX": "9"}, "one task per rank in 512 bins of ~6000 pairs: bins beyond the weighted finish's last table; those tasks take the weighted long way (full-width passes over the pairs + sums of equal keys), nobody starts again"),
+])
+def test_owner_side_combining_extraction_equals_instance_path(R, ntasks, env, why):
+    sp = dict(BASE, ntasks=ntasks, genome=2000000, nreads=480000, L=1, U=65535, calls=["loopback:%d" % R])
+    if ntasks == 2:
+        sp.update(genome=8000000, nreads=800000)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
+    assert ref["combine_launches"] == 0 and r["combine_launches"] > 0 and r["instance_extractions"] == 0, why
+    assert r["combine_kmers"] == r["total_kmers"] == ref["total_kmers"], why
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"]), why
+    if "HSK_COMBINE_PREFIX" in env:
+        assert r["redone_tasks"] > 0, why
+
+
+def test_weighted_long_way_on_one_gpu():
+    """ONE task in 512 bins of ~2900 pairs: bins beyond the weighted finish's last table.  Rounds 2-3 started the call again on the instance path;
+    now the task's pairs are sorted and summed (the call goes on): combine_kernel ran, no instance extraction, same list."""
+    sp = dict(BASE, L=1, ntasks=1)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_COMBINE_PREFIX": "9"})[0]
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0

@@ -133,7 +133,7 @@ def test_slab_ingest_equals_reads_in_place(K, EXT):
     if EXT:
         envs = envs[:1] + envs[2:3]                              # (payloads take the slab ingest without the placement pipeline: default and in-place suffice)
     for env in envs:
-        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
+        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().strip().splitlines()]
     assert len(outs) == 3 * len(envs) and len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
 

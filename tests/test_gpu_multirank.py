@@ -111,7 +111,7 @@ def test_overlap_switch_gives_identical_lists():
     outs = []
     # ... and so do the two supermer stores: bytes written by the placement (default when supermers travel) or positions + pack_kernel
     for env in ({"HSK_OVERLAP": "1"}, {"HSK_OVERLAP": "0"}, {"HSK_PLACE_BYTES": "0"}, {"HSK_PLACE_BYTES": "0", "HSK_OVERLAP": "0"}):
-        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().split())
     assert all(o == outs[0] for o in outs), outs
     assert int(outs[0][1]) > 10000
 

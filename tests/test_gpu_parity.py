@@ -410,7 +410,7 @@ def test_full_size_properties_both_expand_paths():
             "assert bool(d.all())\n"
             "h = int(np.bitwise_xor.reduce(k * np.uint64(0x9E3779B97F4A7C15) + cnt.astype(np.uint64)))\n"
             "print(len(k), h, int(k.sum(dtype=np.uint64)), r.info['ntasks'], c.stats()['fused_tasks'])\n") % util.ROOT
-    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split() for env in ({}, {"HSK_FUSED_SCATTER": "0"})]
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().split() for env in ({}, {"HSK_FUSED_SCATTER": "0"})]
     assert outs[0] == outs[1], outs
     assert int(outs[0][0]) > 300_000_000 and int(outs[0][3]) == 40 and int(outs[0][4]) == 40
 
@@ -677,7 +677,7 @@ def test_fused_finish_equals_two_pass_path(H):
     # capacity (falls back to the general kernels; a capacity of 300 is hit by some tiles only)
     for env in ({}, {"HSK_TEST_PLAN": "no_aggregation"}, {"HSK_TEST_PLAN": "full_sort"}, {"HSK_TEST_PLAN": "full_sort", "HSK_XCD_BATCH": "0"}, {"HSK_XCD_BATCH": "0"},
                 {"HSK_PARSE_FAST": "0"}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}, {"HSK_SCAN_GENERIC": "1"}, {"HSK_SCATTER_GENERIC": "1"}, {"HSK_PARSE_REC_CAP": "300"}, {"HSK_PARSE_REC_CAP": "2048"}, {"HSK_WIDE_LOOKBACK": "1"}, {"HSK_WIDE_LOOKBACK": "1", "HSK_XCD_BATCH": "0"}, {"HSK_UNSTABLE_FIRST": "0"}, {"HSK_EXPAND_RESERVE": "0"}, {"HSK_FUSED_SCATTER": "0"}, {"HSK_FORCE_NO_XCD": "1"}, {"HSK_LAG": "0"}, {"HSK_LAG": "1"}, {"HSK_EARLY_D2H": "0"}, {"HSK_COMPACT_D2H": "0"}, {"HSK_COMPACT_D2H": "1"}, {"HSK_WIDEN_THREADS": "3"}, {"HSK_ZERO_COPY": "0"}, {"HSK_XS2": "0"}, {"HSK_PLACE_BYTES": "1"}, {"HSK_DERIVE_OFFSETS": "0"}):
-        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split())
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().split())
     assert len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
 
@@ -706,7 +706,7 @@ def test_leaving_the_aggregation_in_the_middle_of_a_call(K, EXT):
             "    print(h.hexdigest(), len(r))\n") % (util.ROOT, K, EXT, EXT)
     outs = []
     for env in ({}, {"HSK_AGG_ADAPT": "2"}, {"HSK_AGG_ADAPT": "2", "HSK_LAG": "1"}):
-        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().strip().splitlines()]
+        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().strip().splitlines()]
     assert len(outs) == 6 and len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
 
@@ -960,7 +960,7 @@ def test_extension_fused_scatter_equals_two_pass_path():
             "h = (r.pos.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (r.rid.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))\n"
             "per = np.add.reduceat(h, r.payload_off[:len(r)].astype(np.int64)) if len(r) else h[:0]\n"
             "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + per.tobytes()).hexdigest(), len(r), len(r.pos))\n") % util.ROOT
-    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().split()
             for env in ({}, {"HSK_FUSED_SCATTER_EXT": "0"}, {"HSK_FUSED_SCATTER": "0"})]
     assert outs[0] == outs[1] == outs[2], outs
     assert int(outs[0][1]) > 100000 and int(outs[0][2]) > int(outs[0][1])
@@ -976,7 +976,7 @@ def test_two_word_keys_fused_scatter_equals_two_pass_path(K):
             "dp, nb, do, dl = c.synth_reads(3000000, 150, 400000, 5)\n"
             "r = c.count_device(dp, nb, do, dl, 400000)\n"
             "import hashlib; print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest(), len(r), c.stats()['fused_tasks'])\n") % (util.ROOT, K)
-    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().split()
             for env in ({}, {"HSK_FUSED_SCATTER_WIDE": "0"})]
     assert outs[0] == outs[1], outs
     assert int(outs[0][1]) > 100000 and int(outs[0][2]) == 16

@@ -79,3 +79,27 @@ def result_strings(keys, k):
 
 def hex_words(lst):
     return np.array([int(x, 16) for x in lst], dtype=np.uint64)
+
+
+# Round 4: the library's test switches are per-context tuning names (hsk_config::tuning / the environment's HSK_TUNING string), no longer one
+# environment variable each.  Tests written as {"HSK_PARSE_FAST": "0"} keep reading that way: tune_env() folds every such key into HSK_TUNING
+# (the names below are NOT tuning names: transport hooks, diagnostics, harness variables).
+_NOT_TUNING = {"HSK_TEST_PLAN", "HSK_RCCL_LIB", "HSK_RCCL_MSG_MAX", "HSK_TEST_FAIL", "HSK_FORCE_DEVICE", "HSK_FAKERCCL_TIMEOUT", "HSK_LIB", "HSK_TIMING", "HSK_BACKTRACE",
+               "HSK_HOST_INGEST", "HSK_TEST_FORCE_FAKERCCL", "HSK_TUNING", "HSK_GPUS_PER_NODE"}
+
+
+def tune_env(env):
+    out, items = {}, []
+    for k, v in (env or {}).items():
+        if k.startswith("HSK_") and k not in _NOT_TUNING:
+            items.append("%s=%s" % (k[4:].lower(), v))
+        else:
+            out[k] = v
+    if items:
+        out["HSK_TUNING"] = ",".join(items)
+    return out
+
+
+def tuning(env):
+    """the same as a Context(tuning=...) string"""
+    return tune_env(env).get("HSK_TUNING")
