@@ -507,12 +507,14 @@ def main():
                                     "v_lshrrev_b32 / v_bitop3 issue in 2.3 - 2.8 cycles per wave-instruction (the SIMD-32 rate: 0.72 - 0.84 of 78.6 T lane-ops/s); every multiply, 64-bit "
                                     "operation, left shift, three-operand add / logic, compare, select, DPP and cross-lane instruction in 4.1 - 5.2 cycles (31 - 38 T lane-ops/s)"}
             return d
-        nsup = st["place_supermers"]
+        nsup = st["place_supermers"] or (info.get("total_supermers", 0) * S)      # (scan-placed items: no placement launch to count them)
         item_mode = bool(st.get("combine_launches"))
+        scan_places = item_mode and not st["place_launches"]                        # round 4: scan_kernel writes the 16-byte items itself (ParseArgs::bin_*)
         kernels = [
-            kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] + nsup * (8.0 if item_mode else 4.0), "valu",
-                 "minimizer hashes + supermer records: bound by VALU issue (MurmurHash3 of every m-mer: six 64-bit multiplies and the xor-shifts, then window minima and supermer cuts); "
-                 "algorithmic bytes = packed reads in + 4 bytes of record per supermer out (8 with the minimizer bits of the combining extraction), so its HBM fraction says nothing about it",
+            kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] + nsup * (20.0 if scan_places else 8.0 if item_mode else 4.0), "valu",
+                 "minimizer hashes + supermer cuts: bound by VALU issue (MurmurHash3 of every m-mer: six 64-bit multiplies and the xor-shifts, then window minima and supermer cuts); "
+                 "algorithmic bytes = packed reads in + per supermer out: a 4-byte record (instance path), or -- combining extraction -- the 16-byte item + 4 bytes of minimizer bits, placed by the "
+                 "scan itself into (XCD, virtual task) chunk lists (round 4; round 3: 8 bytes of records and a placement kernel): its HBM fraction says nothing about it",
                  pmc_prefix="scan_kernel", mix_key="scan_kernelILi%dELi17E" % KK if KK in (31, 51) else "scan_kernelILi31ELi17E"),
             kern("expand_scatter2_kernel" if KK <= 32 and not a.ext else "expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins; "
@@ -530,10 +532,10 @@ def main():
             # writes 20; the bucket order reads 4 (histogram), then 4 + 16 and writes 16.
             kernels = [k_ for k_ in kernels if k_["kernel"] not in ("expand_scatter2_kernel", "expand_scatter_kernel", "place_kernel")]
             items = st["bucket_items"]
-            kernels += [
+            kernels += ([] if scan_places else [
                 kern("place_items_kernel", st["place_ms"], st["place_launches"], nsup * 30.4, "hbm-scattered",
                      "supermers (as 16-byte items: 64 bases + k-mer count, with 4 bytes of minimizer bits) to their virtual-task slots (16 virtual tasks per task: the top "
-                     "minimizer bits); bases read once from the packed reads staged in LDS; 8 bytes of records in, 20 out in runs of ~25 items"),
+                     "minimizer bits); bases read once from the packed reads staged in LDS; 8 bytes of records in, 20 out in runs of ~25 items")]) + [
                 kern("bucket_scatter_kernel", st["bucket_ms"], st["bucket_launches"], items * 40.0, "hbm-scattered",
                      "bucket order of the items inside a virtual task (histogram launch + scatter launch): 8192 items staged and ordered in LDS, every bucket's run written in one piece (~8 items = 128 bytes)",
                      pmc_prefix="bucket_"),

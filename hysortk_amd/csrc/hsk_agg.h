@@ -438,12 +438,12 @@ __device__ __forceinline__ void agg_order_many(u32 D, u64 *const (&kw)[NW], u32 
 // between the claim and the store) and counts itself if it is its own.  Returns the lanes that ran out of probes; timed_out:
 // a word 0 never appeared (cannot happen; the bin is then redone on the next rung like an overflowing one).
 template <u32 MASK>
-__device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base, u32 cnt_base, u32 &h, u64 w1, u64 w0, u32 &timed_out)
+__device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base, u32 cnt_base, u32 &h, u64 w1, u64 w0, u32 &timed_out, u32 inc = 1u)      // inc: as in agg_count_keys
 {
     u64 save, cur, v;
     u32 ka1, ka0, ca, p, spin, tmo = 0;
     const u64 empty = AG_EMPTY;
-    const u32 one = 1u;
+    const u32 one = inc;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "s_movk_i32 %[p], %[maxp]\n\t"
@@ -506,7 +506,7 @@ __device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base
 
 __device__ __forceinline__ bool key2_less(u64 a1, u64 a0, u64 b1, u64 b0) { return a1 < b1 || (a1 == b1 && a0 < b0); }
 
-template <int LOG2CAP>
+template <int LOG2CAP, bool W = false>      // W: the records are {k-mer, count} pairs (AggTask::vals), the table adds the counts up (combining extraction, two-word keys)
 __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 {
     constexpr int CAP = 1 << LOG2CAP;
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     const u32 k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
     const ulonglong2 *recs = reinterpret_cast<const ulonglong2 *>(t.keys);       // {word 0, word 1}
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
-        ulonglong2 k[UNR];
+        ulonglong2 k[UNR]; u32 wt[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? recs[idx] : make_ulonglong2(AG_EMPTY, AG_EMPTY); }
+        for (int u = 0; u < UNR; ++u) { const u64 idx = i + (u64)u * AG_THREADS; k[u] = idx < e ? recs[idx] : make_ulonglong2(AG_EMPTY, AG_EMPTY); wt[u] = (W && idx < e) ? (u32)t.vals[idx] : 1u; }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const u64 w0 = k[u].x, w1 = k[u].y;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
             const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
             const u32 x = (u32)(m >> 32) ^ (u32)m;
             u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
-            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo) != 0 || tmo) s_ovf = 1;      // (uniform)
+            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo, wt[u]) != 0 || tmo) s_ovf = 1;      // (uniform)
         }
         if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }

@@ -27,6 +27,7 @@
 // beyond the weighted finish's last table, no batch of eight tasks, a parse that left its fast path) starts again from the reads
 // in HBM (HSK_RETRY_PLAN, dispatch_pipeline).
 #pragma once
+#include "hsk_parse.h"
 #include "hsk_expand.h"
 #include "hsk_scatter.h"
 #include "hsk_agg.h"
@@ -74,6 +75,23 @@ __device__ __forceinline__ bool bucket_map_ok(const BucketSortArgs &a, const Buc
     return ok;
 }
 __device__ __forceinline__ u32 bucket_local(u32 sub, const BucketMap &m) { return m.lgl ? (sub >> (32 - m.lg)) & ((1u << m.lgl) - 1u) : 0u; }
+
+// scan-placed bins (hsk_parse.h: bin_place) -> the bucket order's work list: one work item per chunk, in allocation order
+struct BinItemsArgs { const u32 *cursor; const u32 *map; u32 vmax; const u32 *chunk_bin; u32 nchunks; u32 nvt; u32 vt_shift; BucketItem *items; };
+__global__ __launch_bounds__(256) void bins_items_kernel(BinItemsArgs a)
+{
+    const u32 ph = blockIdx.x * 256u + threadIdx.x;
+    if (ph >= a.nchunks) return;
+    const u32 bin = a.chunk_bin[ph], vt = bin % a.nvt;
+    const u64 cur = a.cursor[(u64)bin * BIN_CUR_STRIDE];
+    const u64 last_v = cur ? (cur - 1) / BIN_CHUNK : 0;
+    const u32 last_ph = last_v < a.vmax ? a.map[(u64)bin * a.vmax + last_v] : 0u;
+    BucketItem it;
+    it.first = (u64)ph * BIN_CHUNK;
+    it.n = (last_ph == ph + 1u) ? (u32)(cur - last_v * BIN_CHUNK) : BIN_CHUNK;
+    it.task = (u16)(vt >> a.vt_shift); it.hi = (u16)(vt & ((1u << a.vt_shift) - 1u));
+    a.items[ph] = it;
+}
 
 __global__ __launch_bounds__(CS_THREADS) void bucket_hist_kernel(BucketSortArgs a)
 {

@@ -8,7 +8,8 @@
 //     the sample are seen, so the chosen k-mers' multiplicities are exact),
 //   * counted in a global open-addressing table (a few million inserts: ~0.3 ms), whose occupancy histogram gives n1, n2, n3 (k-mers
 //     seen once, twice, three times), the distinct chosen k-mers and their instances.
-// No minimizers, no supermers, no sort: one kernel rolls every k-mer of the sample once.  K <= 32 (one-word keys); the canonical form
+// No minimizers, no supermers, no sort: one kernel rolls every k-mer of the sample once.  K < 64 (two-word k-mers enter the table as a
+// 64-bit fingerprint of the smaller strand); the canonical form
 // here is right-aligned (any consistent choice of strand does), so nothing of this is comparable with the lists the path produces.
 #pragma once
 #include "hsk_device.h"
@@ -35,6 +36,46 @@ __device__ __forceinline__ u64 est_find_read(const u64 *roff, u64 nreads, u64 by
     return lo;
 }
 
+__device__ __forceinline__ u32 est_insert(const EstimateArgs &a, u64 key)      // key: the k-mer itself (K <= 32) or a 64-bit fingerprint of it; 1: no slot found
+{
+    const u64 h = fmix64(key + 0x9e3779b97f4a7c15ULL);
+    if (h >> (64 - EST_SELECT_BITS)) return 0;                           // not in the slice
+    u64 slot = (h >> 8) & a.cap_mask;
+    const unsigned long long want = key + 1ULL;
+    for (int probes = 0; probes < EST_MAX_PROBES; ++probes) {
+        unsigned long long prev = a.keys[slot];
+        if (prev == 0ULL) prev = atomicCAS(&a.keys[slot], 0ULL, want);
+        if (prev == 0ULL || prev == want) { atomicAdd(&a.cnts[slot], 1u); return 0; }
+        slot = (slot + 1) & a.cap_mask;
+    }
+    return 1;
+}
+
+// two-word k-mers (32 < K < 64): both strands rolled as {hi, lo} of a right-aligned 2K-bit number, the smaller one folded to 64 bits
+__device__ __forceinline__ void estimate_insert_wide(const EstimateArgs &a, u64 p0, u64 p1)
+{
+    const int k = a.k, hb = 2 * k - 64;                                  // bits of the high word
+    const u64 hmask = (1ULL << hb) - 1ULL;
+    u64 r = est_find_read(a.roff, a.nreads, p0 >> 2);
+    u64 rstart = a.roff[r] * 4, rend = rstart + a.rlen[r];
+    u64 nxt = r + 1 < a.nreads ? a.roff[r + 1] * 4 : ~0ULL;
+    u64 fh = 0, fl = 0, rh = 0, rl = 0; u32 have = 0, lost = 0;
+    u64 p = p0 >= (u64)(k - 1) ? p0 - (u64)(k - 1) : 0;
+    if (p < rstart) p = rstart < p0 ? rstart : p0;
+    for (; p < p1; ++p) {
+        while (p >= nxt) { ++r; rstart = nxt; rend = rstart + a.rlen[r]; nxt = r + 1 < a.nreads ? a.roff[r + 1] * 4 : ~0ULL; have = 0; }
+        if (p < rstart || p >= rend) { have = 0; continue; }
+        const u64 b = (a.packed[p >> 2] >> (6 - 2 * (u32)(p & 3))) & 3u;
+        fh = ((fh << 2) | (fl >> 62)) & hmask; fl = (fl << 2) | b;
+        rl = (rl >> 2) | (rh << 62); rh = (rh >> 2) | ((3ULL - b) << (hb - 2));
+        if (++have < (u32)k || p < p0) continue;
+        const bool rc_less = rh < fh || (rh == fh && rl < fl);
+        const u64 kh = rc_less ? rh : fh, kl = rc_less ? rl : fl;
+        lost += est_insert(a, (kl ^ fmix64(kh + 0x632be59bd9b4e019ULL)) & ~(1ULL << 63));      // (fingerprint; bit 63 cleared so that key + 1 never wraps to the empty marker)
+    }
+    if (lost) atomicAdd(&a.out[0], (unsigned long long)lost);
+}
+
 __global__ __launch_bounds__(EST_THREADS) void estimate_insert_kernel(EstimateArgs a)
 {
     const u64 t = (u64)blockIdx.x * EST_THREADS + threadIdx.x;
@@ -42,6 +83,7 @@ __global__ __launch_bounds__(EST_THREADS) void estimate_insert_kernel(EstimateAr
     if (p0 >= a.positions || a.nreads == 0) return;
     const u64 p1 = p0 + EST_SPAN < a.positions ? p0 + EST_SPAN : a.positions;
     const int k = a.k;
+    if (k > 32) { estimate_insert_wide(a, p0, p1); return; }
     const u64 kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
     u64 r = est_find_read(a.roff, a.nreads, p0 >> 2);
     u64 rstart = a.roff[r] * 4, rend = rstart + a.rlen[r];
@@ -58,19 +100,7 @@ __global__ __launch_bounds__(EST_THREADS) void estimate_insert_kernel(EstimateAr
         fw = ((fw << 2) | b) & kmask;
         rc = (rc >> 2) | ((u64)(3u - b) << (2 * (k - 1)));
         if (++have < (u32)k || p < p0) continue;
-        const u64 key = rc < fw ? rc : fw;
-        const u64 h = fmix64(key + 0x9e3779b97f4a7c15ULL);
-        if (h >> (64 - EST_SELECT_BITS)) continue;                       // not in the slice
-        u64 slot = (h >> 8) & a.cap_mask;
-        const unsigned long long want = key + 1ULL;
-        int probes = 0;
-        for (; probes < EST_MAX_PROBES; ++probes) {
-            unsigned long long prev = a.keys[slot];
-            if (prev == 0ULL) prev = atomicCAS(&a.keys[slot], 0ULL, want);
-            if (prev == 0ULL || prev == want) { atomicAdd(&a.cnts[slot], 1u); break; }
-            slot = (slot + 1) & a.cap_mask;
-        }
-        if (probes == EST_MAX_PROBES) ++lost;
+        lost += est_insert(a, rc < fw ? rc : fw);
     }
     if (lost) atomicAdd(&a.out[0], (unsigned long long)lost);
 }

@@ -40,6 +40,20 @@ static u64 combine_bucket_kmers()
     return (u64)std::max<long long>(256, tune("combine_bucket", 12288));
 }
 
+static int bins_to_store(hsk_ctx *c, ScanBins &b, SupermerStore &st, u32 nvt, u32 vt_shift, hipStream_t stream)
+{
+    BucketItem *d_items; DALLOC(c, d_items, BucketItem *, (size_t)std::max<u32>(b.nchunks, 1) * sizeof(BucketItem));
+    if (b.nchunks) {
+        BinItemsArgs ba; ba.cursor = b.cursor; ba.map = b.map; ba.vmax = b.vmax; ba.chunk_bin = b.chunk_bin; ba.nchunks = b.nchunks; ba.nvt = nvt; ba.vt_shift = vt_shift; ba.items = d_items;
+        hipLaunchKernelGGL(bins_items_kernel, dim3((b.nchunks + 255) / 256), dim3(256), 0, stream, ba);
+        HIPCHK(c, hipGetLastError());
+    }
+    st.sm_item = reinterpret_cast<u64 *>(b.items); st.sm_sub = b.subs; st.d_bitems = d_items; st.n_bitems = b.nchunks;
+    st.bin_aux[0] = b.cursor; st.bin_aux[1] = b.map; st.bin_aux[2] = b.ctl; st.bin_aux[3] = b.chunk_bin; c->pool.release(b.d_table);
+    b = ScanBins();                                         // (the store owns everything now)
+    return HSK_OK;
+}
+
 // the supermer items of the owned tasks in bucket order
 struct BucketOrder {
     ulonglong2 *recs = nullptr; u32 *off = nullptr, *cur = nullptr, *d_log2nb = nullptr; u64 *d_out_base = nullptr; BucketItem *d_items = nullptr;
@@ -74,27 +88,29 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
         bo.log2nb[t] = lg; maxlg = std::max(maxlg, lg);
         bo.out_base[t] = run; run += nsup;
     }
-    if (items.empty()) return HSK_OK;
+    const bool dev_list = src.bitems != nullptr;             // scan-placed bins: the work list is on the device already (one item per chunk)
+    if (dev_list ? src.n_bitems == 0 : items.empty()) return HSK_OK;
+    const u32 nwork = dev_list ? src.n_bitems : (u32)items.size();
     bo.stride = (1u << maxlg) + 1;
     DALLOC(c, bo.recs, ulonglong2 *, run * 16 + 64);
     DALLOC(c, bo.off, u32 *, (size_t)ntasks * bo.stride * 4);
     DALLOC(c, bo.cur, u32 *, (size_t)ntasks * bo.stride * 4);
     DALLOC(c, bo.d_log2nb, u32 *, (size_t)ntasks * 4);
     DALLOC(c, bo.d_out_base, u64 *, (size_t)ntasks * 8);
-    DALLOC(c, bo.d_items, BucketItem *, items.size() * sizeof(BucketItem));
+    if (!dev_list) DALLOC(c, bo.d_items, BucketItem *, items.size() * sizeof(BucketItem));
     HIPCHK(c, hipMemsetAsync(bo.off, 0, (size_t)ntasks * bo.stride * 4, c->stream));
     HIPCHK(c, hipMemcpyAsync(bo.d_log2nb, bo.log2nb.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(bo.d_out_base, bo.out_base.data(), (size_t)ntasks * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(bo.d_items, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hsk_sync(c, c->stream));                  // (the item list is host memory of this function)
+    if (!dev_list) HIPCHK(c, hipMemcpyAsync(bo.d_items, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hsk_sync(c, c->stream));                  // (the item list and the small tables are host memory of this function)
     BucketSortArgs a; memset(&a, 0, sizeof a);
-    a.items = bo.d_items; a.sm_sub = src.sub; a.sm_item = reinterpret_cast<const ulonglong2 *>(src.item); a.off = bo.off; a.cur = bo.cur; a.log2nb = bo.d_log2nb; a.out_base = bo.d_out_base;
+    a.items = dev_list ? reinterpret_cast<const BucketItem *>(src.bitems) : bo.d_items; a.sm_sub = src.sub; a.sm_item = reinterpret_cast<const ulonglong2 *>(src.item); a.off = bo.off; a.cur = bo.cur; a.log2nb = bo.d_log2nb; a.out_base = bo.d_out_base;
     a.stride = bo.stride; a.recs = bo.recs; a.vt_shift = vt_shift; a.err = c->d_err;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 8; ep.keys = run; (void)hipEventRecord(ep.a, c->stream); }
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3((u32)items.size()), dim3(CS_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nwork), dim3(CS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(ntasks), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((u32)items.size()), dim3(CS_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nwork), dim3(CS_THREADS), 0, c->stream, a);
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
     bo.active = true;

@@ -181,6 +181,7 @@ struct hsk_ctx {
     int combine_off_period = 8, combine_good_calls = 0;
     bool combine_left_now = false;     // ... during THIS call (binding for the attempts that follow, whatever the estimate said)
     void leave_combine() { combine_left_now = true; combine_off_period = combine_good_calls ? 8 : std::min(combine_off_period * 2, 64); combine_good_calls = 0; combine_off = true; combine_off_calls = 0; }
+    bool item_mode_now = false;        // ... on ONE GPU: the store holds items (several ranks: byte runs + minimizer bits, items built by the owners)
     u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)
     int combine_prefix_floor = 0;      // ... never below this again (set when a bin beat the last table with fewer bits)
     int combine_prefix = 0;            // key bits of the weighted finish's bins the next batch is planned with (0: the default; follows the pairs per task)

@@ -239,7 +239,12 @@ static int agg_launch_rung(hsk_ctx *c, AggPending &p, int log2cap, u32 grid_x, u
         else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg3_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else if (NW == 2) {
-        if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (p.weighted) {
+            if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_MEDIUM, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE, true>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        }
+        else if (log2cap == AG_LOG2CAP_SMALL) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_SMALL>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else if (log2cap == AG_LOG2CAP_MEDIUM) hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_MEDIUM>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((agg2_finish_kernel<AG_LOG2CAP_LARGE>), dim3(grid_x, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
     } else

@@ -10,6 +10,7 @@ struct BaseSource {
     const u64 *src8 = nullptr; u64 bit0 = 0; u64 nwords = 0;   // byte stream rounded down to 8 bytes
     const u64 *gpos = nullptr;                                  // reference mode positions (null: prefix-sum byte offsets)
     const u32 *boff = nullptr;                                  // byte-store mode: supermer s starts at byte seg.byte_off + boff[s] of the stream
+    const void *bitems = nullptr; u32 n_bitems = 0;             // item mode with scan-placed bins: the bucket order's work list (BucketItem[], one per chunk), built on the device
     const u32 *sub = nullptr; const u64 *item = nullptr;        // item mode (combining extraction): minimizer bits and the two item words of every supermer (SupermerStore::sm_sub / sm_item); nothing else
 };
 static bool reads_in_place(const BaseSource &b) { return b.gpos != nullptr || b.boff != nullptr; }   // no prefix sums needed to find a supermer's bases
@@ -29,6 +30,7 @@ struct SupermerStore {
     u32 ntasks = 0, nblocks = 0;
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
     u32 *sm_boff = nullptr;       // byte-store mode (place_bytes_kernel): sm_bytes is complete, sm_boff[slot] = offset inside the task's byte run
+    void *d_bitems = nullptr; u32 n_bitems = 0; void *bin_aux[4] = {nullptr, nullptr, nullptr, nullptr};      // scan-placed bins: work list + cursor / map / control / chunk owners (released with the store)
     unsigned short *sm_sub16 = nullptr;   // several ranks, combining extraction on the owner's side: the top 16 minimizer bits of every supermer (they travel with sm_len)
     u32 *sm_sub = nullptr;        // combining extraction (hsk_combine.h): 32 mixed bits of the supermer's minimizer hash ...
     u64 *sm_item = nullptr;       // ... and the supermer itself (place_items_kernel); sm_len / sm_gpos do not exist in this mode
@@ -43,6 +45,7 @@ struct SupermerStore {
 static void free_store(hsk_ctx *c, SupermerStore &s)
 {
     c->pool.release(s.sm_sub16); s.sm_sub16 = nullptr;
+    c->pool.release(s.d_bitems); s.d_bitems = nullptr; s.n_bitems = 0; for (void *&p : s.bin_aux) { c->pool.release(p); p = nullptr; }
     c->pool.release(s.sm_len); c->pool.release(s.sm_bytes); c->pool.release(s.sm_gpos); c->pool.release(s.sm_pos); c->pool.release(s.sm_rid); c->pool.release(s.sm_boff); c->pool.release(s.sm_sub); s.sm_sub = nullptr; c->pool.release(s.sm_item); s.sm_item = nullptr;
     s.sm_len = s.sm_bytes = nullptr; s.sm_gpos = nullptr; s.sm_pos = nullptr; s.sm_rid = nullptr; s.sm_boff = nullptr;
 }
@@ -50,7 +53,7 @@ static void free_store(hsk_ctx *c, SupermerStore &s)
 // where the extraction finds the bases of the store's supermers: the store's own byte runs, or (position mode) the packed reads
 static BaseSource source_from_store(const SupermerStore &st, const u8 *d_packed, u64 packed_bytes)
 {
-    if (!st.sm_boff) { BaseSource b = source_from_packed(d_packed, packed_bytes, st.sm_gpos); b.sub = st.sm_sub; b.item = st.sm_item; return b; }
+    if (!st.sm_boff) { BaseSource b = source_from_packed(d_packed, packed_bytes, st.sm_gpos); b.sub = st.sm_sub; b.item = st.sm_item; b.bitems = st.d_bitems; b.n_bitems = st.n_bitems; return b; }
     BaseSource b = source_from_bytes(st.sm_bytes, st.tot_bytes);
     b.boff = st.sm_boff;
     return b;
@@ -75,6 +78,7 @@ static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_byte
     ParseArgs a; memset(&a, 0, sizeof a);
     a.packed = d_packed; a.packed_bytes = packed_bytes; a.roff = d_roff; a.rlen = d_rlen; a.nreads = nreads;
     a.k = c->cfg.kmer_size; a.m = c->cfg.minimizer_size; a.ntasks = ntasks; a.fm = make_fastmod(ntasks >> c->vt_shift); a.vt_shift = c->vt_shift;      // (virtual tasks: `ntasks` counts them)
+    a.item_maxk = (u32)std::max(1, std::min(16, 61 - c->cfg.kmer_size));
     a.ntiles = (packed_bytes * 4 + PARSE_TILE - 1) / PARSE_TILE;
     u32 nblocks = (u32)std::min<u64>(a.ntiles, c->scan_blocks ? c->scan_blocks : 1024);
     a.rid_base = rid_base;
@@ -99,12 +103,63 @@ static ParseArgs make_parse_args(hsk_ctx *c, const u8 *d_packed, u64 packed_byte
 //   parse_place: exclusive scan of the counts in the storage order `order`, supermers to their slots
 // Fast path = scan_kernel + place_kernel (compact supermer records kept in between); the general path
 // (M > 25, or a tile with more supermers than the record capacity) = parse_kernel<COUNT> + emit_kernel.
+// scan_kernel places the items of the combining extraction itself (one GPU; ParseArgs::bin_*, hsk_parse.h: bin_place): bins = (XCD, virtual
+// task) chunk lists.  The chunk store is sized from the EXPECTED supermer count (a window of W k-mers starts a supermer every (W + 1) / 2
+// positions on random sequence, every 16 k-mers at least, once per read) with a quarter to spare; real genomes with long low-complexity
+// stretches make FEWER supermers, and an input that does overrun it (error bit 128; a bin beyond its map: 256) sends the call round again
+// without the combining extraction.  tuning "scan_place=1" selects it (default: tile records + place_items_kernel, see scan_place_enabled).
+struct ScanBins {
+    u32 *cursor = nullptr, *map = nullptr, *ctl = nullptr, *chunk_bin = nullptr, *subs = nullptr; ulonglong2 *items = nullptr;
+    BinTable *d_table = nullptr;                          // the table scan_kernel<.., true> reads (ParseArgs::bins)
+    u32 vmax = 0, cap = 0, nchunks = 0, nbins = 0;
+};
+// Measured (10 Gbp, round 4): scan 47.6 ms with the items placed by it against 33.9 + 13.4 ms (scan + place_items_kernel): the same ~13.5 ms wherever the
+// placement runs, 101.7 ms per step either way -- and from host memory the separate placement hides behind the ingest's DMA while the longer scan
+// does not (140 against 123 ms).  So the default stays the placement kernel; "scan_place=1" takes the fused form (no tile records: 13 GB less device
+// memory and 20 GB less traffic per 10 Gbp).
+static bool scan_place_enabled() { return tune("scan_place", 0) != 0; }
+static void bins_release(hsk_ctx *c, ScanBins &b)
+{
+    c->pool.release(b.cursor); c->pool.release(b.map); c->pool.release(b.ctl); c->pool.release(b.chunk_bin); c->pool.release(b.subs); c->pool.release(b.items); c->pool.release(b.d_table);
+    b = ScanBins();
+}
+static int bins_alloc(hsk_ctx *c, ScanBins &b, u32 nvt, u64 packed_bytes, u64 nreads, int W, hipStream_t stream)
+{
+    b = ScanBins();
+    const double positions = (double)packed_bytes * 4.0;
+    const double expect = positions * std::max(2.2 / (double)(W + 1), 1.0 / 14.0) + 2.0 * (double)nreads + 65536.0;
+    b.nbins = 8u * nvt;
+    const u64 cap = (u64)(expect * (double)tune("bin_cap_pct", 125) / 100.0 / BIN_CHUNK) + (tune("bin_cap_pct", 125) >= 100 ? b.nbins + 64 : 1);      // (tests: a store that runs out)
+    if (cap >= 0xFFFFFFF0ULL) return fail(c, HSK_ERR_UNSUPPORTED, "item store of %llu chunks", (unsigned long long)cap);
+    b.cap = (u32)cap;
+    b.vmax = (u32)std::min<u64>(std::max<u64>(cap / b.nbins * 64, 256), 1u << 16);
+    if (tune("bin_vmax", 0) > 0) b.vmax = (u32)tune("bin_vmax", 0);                                    // (tests: a bin beyond its map)
+    DALLOC(c, b.cursor, u32 *, (size_t)b.nbins * 4 * BIN_CUR_STRIDE);
+    DALLOC(c, b.map, u32 *, (size_t)b.nbins * b.vmax * 4);
+    DALLOC(c, b.ctl, u32 *, 256);
+    DALLOC(c, b.chunk_bin, u32 *, (size_t)b.cap * 4 + 64);
+    DALLOC(c, b.items, ulonglong2 *, (size_t)b.cap * BIN_CHUNK * 16 + 64);
+    DALLOC(c, b.subs, u32 *, (size_t)b.cap * BIN_CHUNK * 4 + 64);
+    HIPCHK(c, hipMemsetAsync(b.cursor, 0, (size_t)b.nbins * 4 * BIN_CUR_STRIDE, stream));
+    HIPCHK(c, hipMemsetAsync(b.map, 0, (size_t)b.nbins * b.vmax * 4, stream));
+    HIPCHK(c, hipMemsetAsync(b.ctl, 0, 256, stream));
+    DALLOC(c, b.d_table, BinTable *, 256);
+    BinTable *h = (BinTable *)((char *)c->pinned + (384u << 10));      // (pinned staging: the copy is asynchronous)
+    h->cursor = b.cursor; h->map = b.map; h->vmax = b.vmax; h->cap_chunks = b.cap; h->ctl = b.ctl; h->chunk_bin = b.chunk_bin; h->items = b.items; h->subs = b.subs; h->err = c->d_err;
+    HIPCHK(c, hipMemcpyAsync(b.d_table, h, sizeof(BinTable), hipMemcpyHostToDevice, stream));
+    return HSK_OK;
+}
+static void bins_args(hsk_ctx *, ParseArgs &a, const ScanBins &b) { a.bins = b.d_table; }
+// the store takes the bins over: items and minimizer bits where they are, the bucket order's work list from the chunk lists
+static int bins_to_store(hsk_ctx *c, ScanBins &b, SupermerStore &st, u32 nvt, u32 vt_shift, hipStream_t stream);
+
 struct ParseJob {
     ParseArgs a; u32 nblocks = 0, ntasks = 0; bool fast = false, empty = true;
     const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
     u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
     u32 *d_tile_r0 = nullptr;     // EXTENSION: first read of every tile (hint for the (pos, rid) lookup)
     u32 *d_tile_sub = nullptr;    // combining extraction: minimizer bits of every record
+    ScanBins bins;                // ... or no records at all: scan_kernel places the items itself
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
 };
 
@@ -112,6 +167,7 @@ static void parse_release(hsk_ctx *c, ParseJob &j)
 {
     c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
     c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; c->pool.release(j.d_tile_sub); j.d_tile_sub = nullptr;
+    bins_release(c, j.bins);
     j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
 }
 
@@ -179,19 +235,30 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
     if (j.fast) {
         a.rec_cap = parse_rec_cap(c->cfg.kmer_size - c->cfg.minimizer_size + 1);
         a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
-        DALLOC(c, j.d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
-        DALLOC(c, j.d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+        const bool bins = c->item_mode_now && c->combine_now && scan_place_enabled() && a.rec_cap <= PLACE_ITEM_REC;
         DALLOC(c, j.d_overflow, u32 *, 256);
         HIPCHK(c, hipMemsetAsync(j.d_overflow, 0, 4, c->stream));
-        a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec; a.overflow = j.d_overflow;
+        a.overflow = j.d_overflow;
+        if (bins) {
+            int brc = bins_alloc(c, j.bins, ntasks, packed_bytes, nreads, c->cfg.kmer_size - c->cfg.minimizer_size + 1, c->stream); if (brc) return brc;
+            bins_args(c, a, j.bins);
+        } else {
+            DALLOC(c, j.d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+            DALLOC(c, j.d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+            a.tile_rec = j.d_tile_rec; a.tile_nrec = j.d_tile_nrec;
+        }
         if (c->cfg.extension && nreads < (1ULL << 32)) { DALLOC(c, j.d_tile_r0, u32 *, (size_t)a.ntiles * 4 + 64); a.tile_r0 = j.d_tile_r0; }
-        if (c->combine_now && a.rec_cap <= PLACE_ITEM_REC) { DALLOC(c, j.d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64); a.tile_sub = j.d_tile_sub; }
+        if (!bins && c->combine_now && a.rec_cap <= PLACE_ITEM_REC) { DALLOC(c, j.d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64); a.tile_sub = j.d_tile_sub; }
         const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
         const bool scan_generic = tune("scan_generic", 0) != 0;      // (tests: the default (k, m) through the generic instance)
         auto launch_scan = [&]() {
-            if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+            if (a.bins) {
+                if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+                else hipLaunchKernelGGL((scan_kernel<0, 0, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+            }
+            else if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
             else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
             else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         };
@@ -222,8 +289,10 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
         HIPCHK(c, hipMemcpyAsync(h_ovf, j.d_overflow, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        if (j.bins.items) HIPCHK(c, hipMemcpyAsync(h_ovf + 2, j.bins.ctl, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
+        if (j.bins.items) j.bins.nchunks = std::min(h_ovf[2], j.bins.cap);
         bool gaps = c->roff_bad; c->roff_bad = false;
         if (c->roff_check.valid() && !c->roff_check.get()) gaps = true;
         if (gaps) {
@@ -246,6 +315,9 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         if (c->index_unchecked) {
             c->index_unchecked = false;
             if (h_ovf[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }
+        }
+        if (j.bins.items && (h_ovf[1] & (2u | 128u | 256u))) {          // the chunk store or a bin's map ran out: the call again, without the combining extraction
+            (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); c->combine_veto = true; return HSK_RETRY_PLAN;
         }
         if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return HSK_RETRY_PLAN; }      // (the general kernels know no virtual tasks: the call again, without them)
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
@@ -318,7 +390,8 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     }
     a.task_skip = d_skip;
     { int prc = launch_parse_scan(c, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_order, d_skip, d_task_tot, d_task_base, d_blk_base); if (prc) return prc; }
-    const bool item_mode = j.fast && a.tile_sub && !skip && !supermers_travel && !ext;      // combining extraction: the slots hold the supermers themselves
+    const bool from_bins = j.fast && j.bins.items != nullptr && !skip && !supermers_travel && !ext;      // scan_kernel has placed the items already
+    const bool item_mode = from_bins || (j.fast && a.tile_sub && !skip && !supermers_travel && !ext);      // combining extraction: the slots hold the supermers themselves
     if (!item_mode) DALLOC(c, st.sm_len, u8 *, st.tot_sup + 64);
     // byte-store mode (fast parse path): the supermers' bases are copied into per-task byte runs while the reads stream through
     // place_bytes_kernel once; positions are kept only where something still needs them (EXTENSION: pos / rid lookup)
@@ -336,6 +409,12 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     if ((!bytes_mode && !item_mode) || ext) DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);      // position mode: bases stay in the packed reads
     if (ext) { DALLOC(c, st.sm_pos, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_rid, int32_t *, st.tot_sup * 4 + 64); }
     a.sm_sub = nullptr; a.sm_item = nullptr;
+    if (from_bins) {
+        int brc = bins_to_store(c, j.bins, st, ntasks, c->vt_shift, c->stream);
+        c->pool.release(d_blk_base); c->pool.release(d_task_tot); c->pool.release(d_task_base); c->pool.release(d_order); c->pool.release(d_skip);
+        a.task_skip = nullptr;
+        return brc;
+    }
     if (item_mode) { DALLOC(c, st.sm_sub, u32 *, st.tot_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, st.tot_sup * 16 + 64); a.sm_sub = st.sm_sub; a.sm_item = st.sm_item; }
     a.blk_base = d_blk_base; a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.sm_bytes = st.sm_bytes; a.sm_boff = st.sm_boff; a.task_base3 = d_task_base;
     if (st.tot_sup) {
@@ -388,7 +467,9 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     a.rec_cap = parse_rec_cap(c->cfg.kmer_size - c->cfg.minimizer_size + 1);
     a.place_group = std::max<u32>(1, std::min<u32>(16, PLACE_MAX_REC / a.rec_cap));
     a.place_one = 1;
-    u64 *d_blk_cnt, *d_blk_base, *d_tot, *d_task_base, *d_run; u32 *d_order, *d_tile_rec, *d_tile_nrec, *d_overflow, *d_tile_sub = nullptr;
+    const bool bins = c->item_mode_now && c->combine_now && scan_place_enabled() && a.rec_cap <= PLACE_ITEM_REC;      // scan_kernel places the items itself: no records, no placement kernel
+    ScanBins sbins;
+    u64 *d_blk_cnt, *d_blk_base, *d_tot, *d_task_base, *d_run; u32 *d_order, *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow, *d_tile_sub = nullptr;
     const size_t mat = (size_t)nblocks * ntasks;
     DALLOC(c, d_blk_cnt, u64 *, mat * 3 * 8 * nsl);
     DALLOC(c, d_blk_base, u64 *, mat * 2 * 8);
@@ -396,18 +477,20 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     DALLOC(c, d_task_base, u64 *, (size_t)ntasks * 3 * 8);
     DALLOC(c, d_run, u64 *, 256);
     DALLOC(c, d_order, u32 *, (size_t)ntasks * 4);
-    DALLOC(c, d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
-    DALLOC(c, d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64);
+    if (!bins) { DALLOC(c, d_tile_rec, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64); DALLOC(c, d_tile_nrec, u32 *, (size_t)a.ntiles * 4 + 64); }
     DALLOC(c, d_overflow, u32 *, 256);
-    if (c->combine_now && a.rec_cap <= PLACE_ITEM_REC) DALLOC(c, d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+    if (!bins && c->combine_now && a.rec_cap <= PLACE_ITEM_REC) DALLOC(c, d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
+    if (bins) { int brc = bins_alloc(c, sbins, ntasks, packed_bytes, nreads, c->cfg.kmer_size - c->cfg.minimizer_size + 1, c->stream); if (brc) return brc; }
     u64 *d_ps; DALLOC(c, d_ps, u64 *, (size_t)PS_SEGS * ntasks * 3 * 8);
     // the store holds at most rec_cap supermers per tile (a tile beyond that falls back); its real size is known when the last slab is in
     const u64 cap_sup = a.ntiles * (u64)a.rec_cap;
     st = SupermerStore();
     st.ntasks = ntasks; st.nblocks = nblocks;
-    if (d_tile_sub) { DALLOC(c, st.sm_sub, u32 *, cap_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, cap_sup * 16 + 64); }      // item mode (combining extraction)
+    if (bins) {}                                                            // (the items live in the bins' chunk store)
+    else if (d_tile_sub) { DALLOC(c, st.sm_sub, u32 *, cap_sup * 4 + 64); DALLOC(c, st.sm_item, u64 *, cap_sup * 16 + 64); }      // item mode (combining extraction)
     else { DALLOC(c, st.sm_len, u8 *, cap_sup + 64); DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64); }
     auto release_all = [&]() {
+        bins_release(c, sbins);
         c->pool.release(d_tile_sub); c->pool.release(d_ps);
         c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_tot); c->pool.release(d_task_base); c->pool.release(d_run);
         c->pool.release(d_order); c->pool.release(d_tile_rec); c->pool.release(d_tile_nrec); c->pool.release(d_overflow);
@@ -424,6 +507,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     a.sm_len = st.sm_len; a.sm_gpos = st.sm_gpos; a.blk_base = d_blk_base; a.task_base3 = d_task_base;
     a.tile_sub = d_tile_sub; a.sm_sub = st.sm_sub; a.sm_item = st.sm_item;
     if (d_tile_sub) a.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));
+    if (bins) bins_args(c, a, sbins);
     EvList evs(c);
     hipEvent_t ready = evs.get();                                          // the small buffers above are set up; the second stream may start
     HIPCHK(c, hipEventRecord(ready, sA));
@@ -444,7 +528,11 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     for (u32 sl = 0; sl < nsl; ++sl) {
         HIPCHK(c, hipStreamWaitEvent(sA, landed[std::min(sl + 1, nsl - 1)], 0));
         a.slab = sl; a.blk_cnt = d_blk_cnt + (size_t)sl * mat * 3;
-        if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        if (a.bins) {
+            if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+            else hipLaunchKernelGGL((scan_kernel<0, 0, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        }
+        else if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         else if (a.k == 51 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<51, 17>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         else hipLaunchKernelGGL((scan_kernel<0, 0>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         scanned[sl] = evs.get();
@@ -453,7 +541,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         HIPCHK(c, hipStreamWaitEvent(sB, scanned[sl], 0));
         { int prc = launch_parse_scan(c, sB, (const u64 *)a.blk_cnt, nblocks, ntasks, (const u32 *)d_order, (const u8 *)nullptr,
                                       d_tot + (size_t)sl * ntasks * 3, d_task_base, d_blk_base, d_run, d_ps); if (prc) return prc; }
-        if (d_tile_sub) hipLaunchKernelGGL(place_items_kernel, dim3(nblocks), dim3(PLACE_ITEM_THREADS), place_items_lds(ntasks), sB, a);
+        if (bins) {}                                                        // (placed by the scan)
+        else if (d_tile_sub) hipLaunchKernelGGL(place_items_kernel, dim3(nblocks), dim3(PLACE_ITEM_THREADS), place_items_lds(ntasks), sB, a);
         else hipLaunchKernelGGL(place_kernel, dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16 + PLACE_MAX_REC * 4, sB, a);
     }
     if (profile) { (void)hipEventRecord(sp.b, sA); c->ev_pending.push_back(sp); (void)hipEventRecord(pp.b, sB); }
@@ -464,6 +553,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     const bool staged = (size_t)nsl * ntasks * 24 <= (64u << 10);
     HIPCHK(c, hipMemcpyAsync(h_flags, d_overflow, 4, hipMemcpyDeviceToHost, sB));
     HIPCHK(c, hipMemcpyAsync(h_flags + 1, c->d_err, 4, hipMemcpyDeviceToHost, sB));
+    if (bins) HIPCHK(c, hipMemcpyAsync(h_flags + 2, sbins.ctl, 4, hipMemcpyDeviceToHost, sB));
     HIPCHK(c, hipMemcpyAsync(staged ? h_tot : tot.data(), d_tot, (size_t)nsl * ntasks * 24, hipMemcpyDeviceToHost, sB));
     hipEvent_t placed = evs.get();
     HIPCHK(c, hipEventRecord(placed, sB));
@@ -474,7 +564,12 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     bool fallback = *h_flags != 0;                                          // a tile with more supermers than the record capacity
     if (c->roff_check.valid() && !c->roff_check.get()) { fallback = true; c->roff_bad = true; }     // the reads do not lie back to back: the caller's offsets are needed
     if (c->index_unchecked && (h_flags[1] & 32u)) fallback = true;          // (parse_count reports it)
+    if (bins && (h_flags[1] & (2u | 128u | 256u))) { fallback = true; (void)hipMemsetAsync(c->d_err, 0, 4, sA); }      // the chunk store or a bin's map ran out (run_pipeline: the call again, without virtual tasks)
     if (fallback) { HIPCHK(c, hsk_sync(c, sA)); release_all(); free_store(c, st); return PARSE_FALLBACK; }
+    if (bins) {
+        sbins.nchunks = std::min(h_flags[2], sbins.cap);
+        int brc = bins_to_store(c, sbins, st, ntasks, c->vt_shift, sA); if (brc) { release_all(); return brc; }      // (main stream: behind the `placed` wait above)
+    }
     c->index_unchecked = false;
     // segments: slab by slab, tasks in storage order inside a slab (what parse_scan_kernel laid out on the device)
     st.task_tot.assign((size_t)ntasks * 3, 0); st.task_base.assign((size_t)ntasks * 3, 0);
@@ -484,7 +579,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         for (u32 i = 0; i < ntasks; ++i) {
             const u32 t = order[i];
             const u64 *m = &tot[((size_t)sl * ntasks + t) * 3];
-            if (m[0]) {
+            if (m[0] && bins && !segs[t].segs.empty()) segs[t].segs[0].n_sup += m[0];      // (bins: one pseudo segment per task -- only its supermer total is used)
+            else if (m[0]) {
                 ExpSeg sg; sg.sup_off = run_s; sg.n_sup = m[0]; sg.byte_off = run_b; sg.kmer_off = segs[t].nkmers; sg.tile_start = 0;
                 segs[t].segs.push_back(sg);
             }
@@ -494,7 +590,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         }
     st.tot_sup = run_s; st.tot_bytes = run_b; st.tot_kmers = 0;
     for (u32 t = 0; t < ntasks; ++t) st.tot_kmers += st.task_tot[3 * t + 2];
-    if (run_s > cap_sup) { release_all(); free_store(c, st); return fail(c, HSK_ERR_INTERNAL, "supermer store overrun (%llu > %llu)", (unsigned long long)run_s, (unsigned long long)cap_sup); }
+    if (!bins && run_s > cap_sup) { release_all(); free_store(c, st); return fail(c, HSK_ERR_INTERNAL, "supermer store overrun (%llu > %llu)", (unsigned long long)run_s, (unsigned long long)cap_sup); }
     if (profile && !c->ev_pending.empty()) c->ev_pending.back().keys = run_s;
     release_all();                                                          // (stream-ordered reuse: later users are enqueued behind the kernels above)
     return HSK_OK;

@@ -887,6 +887,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         const double per_bucket = (double)packed_bytes * 4.0 / (double)ntasks / (double)(1u << lg);
         if (per_bucket > (double)combine_bucket_kmers() && c->est.distinct_per_kmer * per_bucket > 1400.0) { c->combine_now = false; c->vt_shift = 0; }
     }
+    c->item_mode_now = c->combine_now && nranks == 1;      // one GPU: the store holds items (several ranks: byte runs + minimizer bits, the owners build the items)
     const u32 vts = c->vt_shift, nvt = ntasks << vts;       // what the parse calls tasks
     std::vector<int32_t> owner(ntasks, 0);
     std::vector<u32> order(ntasks);
@@ -928,7 +929,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         ParseJob job;
         int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, nvt, job);
         if (rc && nranks == 1) { parse_release(c, job); c->vt_shift = 0; return rc; }
-        if (vts && !job.d_tile_sub && !job.empty) { parse_release(c, job); c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }   // (the parse left its fast path: no items)
+        if (vts && !job.d_tile_sub && !job.bins.items && !job.empty) { parse_release(c, job); c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }   // (the parse left its fast path: no items)
         if (nranks > 1) {
             // Several ranks: a rank that fails must not return alone (its peers would wait for it in the next collective for
             // ever).  Every all-reduce below carries the ranks' status as one more element; a failed rank keeps taking part
@@ -1127,7 +1128,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
     // the plan, as run_pipeline chooses it with several ranks: the sketch of a rank's reads (here: of the first virtual rank that has some)
-    c->combine_now = false; c->vt_shift = 0; c->combine_left_now = false;
+    c->combine_now = false; c->item_mode_now = false; c->vt_shift = 0; c->combine_left_now = false;
     if (NW == 1 && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
         const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
         int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;

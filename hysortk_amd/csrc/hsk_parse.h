@@ -39,6 +39,8 @@ constexpr int PARSE_HMAX = PARSE_TILE + 96;           // hashes for TILE + (K-M)
 constexpr int PARSE_RWIN = 64;                        // reads looked at per tile by the wave-parallel index search
 static_assert(PARSE_RWIN + PARSE_WORDS <= PARSE_THREADS, "scan_kernel prefetches the next tile with one lane per read-index entry and per word");
 
+struct BinTable { u32 *cursor; u32 *map; u32 vmax; u32 cap_chunks; u32 *ctl; u32 *chunk_bin; ulonglong2 *items; u32 *subs; u32 *err; };
+
 struct ParseArgs {
     const u8 *packed;          // 4-byte aligned; nothing beyond packed_bytes is read
     u64 packed_bytes;
@@ -82,6 +84,15 @@ struct ParseArgs {
     // k-mer among them -- get the same value, independent of the task id (which is the hash modulo the task count)
     u32 *tile_sub;
     u32 *sm_sub;
+    // scan_kernel places the items ITSELF (round 4; one GPU, combining extraction): no tile records, no placement kernel.  A bin = (XCD of the
+    // workgroup, virtual task); a bin is a list of chunks of BIN_CHUNK items: cursor[bin] counts the items reserved, map[bin][v] names the
+    // physical chunk of the bin's v-th chunk (+ 1; allocated from bin_ctl[0] by the lane whose item opens the chunk: the protocol of
+    // hsk_scatter.h), chunk_bin[chunk] says whose it is.  All of a bin's writers run on ONE XCD: cursors, map words and the short runs that
+    // fill a 128-byte line one 16-byte item at a time stay in that XCD's L2.
+    u32 item_maxk;             // combining extraction: k-mers per item at most = min(16, 61 - K): the item is the supermer's first 64 bases, the last four of
+                               // which give way to the k-mer count (0: 16)
+    const struct BinTable *bins;   // the bins (device memory: scan_kernel<.., BINS = true> reads its fields where it needs them -- nine more pointers among the kernel's
+                               // arguments cost the record-writing instances 12 % more instructions: the scalar registers spilled into vector lanes)
     unsigned short *sm_sub16;  // byte-store placement with several ranks (round 4): the top 16 of those bits beside sm_len -- they travel with the supermers, and the
                                // OWNER of a task builds the items and orders them by minimizer bucket (hsk_combine.h: items_build_kernel)
     u32 vt_shift;              // virtual tasks: `ntasks` = real tasks << vt_shift, task id = (hash mod real tasks) << vt_shift | top vt_shift minimizer bits (fm is the real count's)
@@ -494,6 +505,59 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
 // Requires 2*M + 14 <= 64 (M <= 25) so that the 8 m-mers of a lane fit one 64-bit window.
 // ======================================================================================================
 constexpr int SCAN_MAX_M = 25;
+constexpr u32 BIN_CHUNK = 8192;                       // items per chunk of a scan-placed bin (= one staging step of bucket_scatter_kernel)
+constexpr unsigned PARSE_XCC_GETREG = 20u | (0u << 6) | (3u << 11);      // HW_REG_XCC_ID, bits [3:0] (as hsk_sort.h)
+constexpr u32 BIN_SPIN_LIMIT = 1u << 22;
+constexpr u32 BIN_CUR_STRIDE = 32;                    // a bin's 32-bit cursor has a 128-byte line to itself: the L2 takes the atomics of one LINE one after the other, and 16 cursors
+                                                      // to a line made 40 hot lines per XCD carry 131 M atomics each call (measured: the scan 75 instead of 60 ms)
+
+// one item into its bin, in three steps that scan_kernel keeps a tile apart: (1) a slot is reserved with an atomic on the bin's cursor; (2) the
+// chunk of that slot is found (or opened) through the map -- the workgroup remembers the last chunk of every virtual task in LDS (`mc`), so only
+// one lookup in a few thousand goes to memory; (3) the item is stored.  Returns 0xFFFFFFFF (and sets error bit 128 / 256 / 2: chunk store or map
+// exhausted, a chunk that never appeared -- the host runs the call again without the combining extraction) when there is no slot.
+__device__ __forceinline__ u32 bin_reserve(const BinTable &a, u32 bin)
+{
+    return __hip_atomic_fetch_add(&a.cursor[(u64)bin * BIN_CUR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ u64 bin_slot(const BinTable &a, u32 bin, u32 p, unsigned long long *mc /* LDS: {v << 32 | chunk + 1} of virtual task vt at mc[2 vt] */, u32 vt)
+{
+    u32 *const err = a.err;
+    typedef __attribute__((address_space(1))) u32 G32;
+    const u32 v = p / BIN_CHUNK, off = p % BIN_CHUNK;
+    if (v >= a.vmax) { atomicOr(err, 256u); return ~0ULL; }
+    G32 *mp = (G32 *)(a.map + (u64)bin * a.vmax + v);
+    // Publish BEFORE anybody waits (two statements one after the other, as in hsk_scatter.h): a lane that opens a chunk and a lane that waits for
+    // that very chunk may sit in the same wave -- as the two arms of one `if` the waiting arm could run first and never end
+    u32 ph = 0;
+    if (off == 0) {
+        ph = __hip_atomic_fetch_add(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (ph > a.cap_chunks) { atomicOr(err, 128u); ph = 0xFFFFFFFFu; }
+        else a.chunk_bin[ph - 1u] = bin;
+        __hip_atomic_store(mp, ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        mc[2u * vt] = ((unsigned long long)v << 32) | ph;
+    }
+    if (off != 0) {
+        const unsigned long long e = mc[2u * vt];
+        if ((u32)(e >> 32) == v && (u32)e != 0u) ph = (u32)e;
+        else {
+            u32 spins = 0;
+            while ((ph = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                if (++spins > BIN_SPIN_LIMIT) { atomicOr(err, 2u); ph = 0xFFFFFFFFu; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            mc[2u * vt] = ((unsigned long long)v << 32) | ph;
+        }
+    }
+    if (ph == 0xFFFFFFFFu) return ~0ULL;                                 // (the chunk store ran out when this chunk was opened)
+    return (u64)(ph - 1u) * BIN_CHUNK + off;
+}
+__device__ __forceinline__ void bin_store(const BinTable &a, u64 slot, u64 w0, u64 w1, u32 nk, u32 sub)
+{
+    if (slot == ~0ULL) return;
+    a.items[slot] = make_ulonglong2(w0, (w1 & ~0xFFULL) | (u64)nk);
+    a.subs[slot] = sub;
+}
+
 constexpr u32 SCAN_REC_CAP = 512;                     // default records kept per tile (expected ~270 at K=31, M=17)
 constexpr u32 PLACE_MAX_REC = 8192;                   // records of one placement step (rec_cap * place_group)
 // LDS layout of the tile's hashes: position p = 8*t + i lives at [i][t] (row stride SCAN_HSTRIDE), so that the 64
@@ -507,10 +571,11 @@ __device__ unsigned long long g_scan_diag[16];
 #endif
 // KT, MT: k and m as compile-time constants (0: taken from the arguments).  The reference fixes both at compile time
 // (KMER_SIZE, MINIMIZER_SIZE); here the default pair gets its own instance: shifts, masks and the window loop fold.
-template <int KT, int MT>
+template <int KT, int MT, bool BINS = false>      // BINS: the items of the combining extraction are placed by this kernel (ParseArgs::bins) instead of records being written
 __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 {
-    __shared__ u32 s_words[PARSE_WORDS];
+    __shared__ u32 s_words2[BINS ? 2 : 1][PARSE_WORDS];                             // the tile's packed words (+ halo); two buffers: the items of a tile are stored while the NEXT tile is hashed (bins)
+    __shared__ uint2 s_pend[BINS ? 2 * PARSE_THREADS : 1];                          // scan-placed items: {position | k-mers << 11 | virtual task << 16, minimizer bits} of the supermers whose slots are on their way
     __shared__ __attribute__((aligned(16))) u64 s_hash[8 * SCAN_HSTRIDE]; // hashes of the tile ([i][t] layout); later the minima of the supermer starts
     __shared__ u64 s_last[PARSE_THREADS];                                // window minimum of every lane's last position
     __shared__ __attribute__((aligned(8))) u8 s_v8[PARSE_THREADS];       // valid mask of every lane's 8 positions
@@ -520,28 +585,51 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     __shared__ u64 s_roff[PARSE_RWIN];
     __shared__ u32 s_rlen[PARSE_RWIN];
     __shared__ u32 s_scan[12];
-    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];          // [task] {supermers << 40 | k-mers, bytes}
+    extern __shared__ __attribute__((aligned(16))) u64 s_cur[];          // [task] {supermers << 40 | k-mers, bytes}; behind it (scan-placed items) [task] the chunk the workgroup last saw the bin in
 
     const int tid = threadIdx.x;
     const int K = KT ? KT : a.k, M = MT ? MT : a.m, W = K - M + 1;
     const u64 mmask = ~0ULL << (64 - 2 * M);
     for (u32 i = tid; i < 2 * a.ntasks; i += PARSE_THREADS) s_cur[i] = 0;
+    // (scan-placed items: nobody needs the supermers' byte totals -- a task's second word is the workgroup's memory of the bin's last chunk instead:
+    //  mc[vt] = s_cur[2 vt + 1]; a third word per task would cost the fourth workgroup per CU)
+    unsigned long long *s_mc = reinterpret_cast<unsigned long long *>(s_cur) + 1;
+    u32 pend_pos0 = 0, pend_pos1 = 0, pend_mask = 0;                     // slots reserved for this lane's (up to two) supermers of the previous tile, not yet resolved
     const u64 tile0 = (u64)a.slab * a.slab_tiles + (u64)blockIdx.x * a.tiles_per_block;
     const u64 tile_end = (a.nslabs > 1 && ((u64)a.slab + 1) * a.slab_tiles < a.ntiles) ? ((u64)a.slab + 1) * a.slab_tiles : a.ntiles;   // this launch's tiles end here
     if (tid == 0) s_rng[1] = (tile0 < a.ntiles) ? find_read(a.roff, 0, a.nreads - 1, (tile0 * PARSE_TILE) >> 2) : 0;
     __syncthreads();
     const u64 RINF = ~0ULL >> 2;
     const int p0 = tid * PARSE_PPT;
+    const u32 maxk = a.item_maxk ? a.item_maxk : 16u;
+    const u32 xcc_nvt = BINS ? (__builtin_amdgcn_s_getreg(PARSE_XCC_GETREG) & 7u) * a.ntasks : 0u;      // first bin of this workgroup's XCD
     u32 pf0 = 0, pf1 = 0, pf2 = 0; bool pf_have = false;      // prefetched: lanes < PARSE_RWIN {read offset, length}, the next PARSE_WORDS lanes one tile word each
 
 #ifdef HSK_DIAG
     unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    // the items whose slots were reserved while the previous tile was cut into supermers are resolved and stored now (their words: the other buffer)
+    auto complete_pending = [&](const u32 *wprev) {
+        const BinTable &bt = *a.bins;
+        if (pend_mask & 1u) {
+            const uint2 m = s_pend[tid]; const u32 pp = m.x & 2047u, vt = m.x >> 16;
+            bin_store(bt, bin_slot(bt, xcc_nvt + vt, pend_pos0, s_mc, vt), bits64_be32(wprev, 2u * pp), bits64_be32(wprev, 2u * pp + 64u), (m.x >> 11) & 31u, m.y);
+        }
+        if (pend_mask & 2u) {
+            const uint2 m = s_pend[PARSE_THREADS + tid]; const u32 pp = m.x & 2047u, vt = m.x >> 16;
+            bin_store(bt, bin_slot(bt, xcc_nvt + vt, pend_pos1, s_mc, vt), bits64_be32(wprev, 2u * pp), bits64_be32(wprev, 2u * pp + 64u), (m.x >> 11) & 31u, m.y);
+        }
+        pend_mask = 0;
+    };
+    u32 wsel = 0;
     for (u32 ti = 0; ti < a.tiles_per_block; ++ti) {
         const u64 tile = tile0 + ti;
         if (tile >= tile_end) break;
         const u64 gbase = tile * PARSE_TILE;
         const u64 bbase = gbase >> 2;
+        u32 *const s_words = s_words2[BINS ? wsel : 0u];
+        const u32 *const s_wprev = s_words2[BINS ? (wsel ^ 1u) : 0u];
+        if (BINS) wsel ^= 1u;
 #ifdef HSK_DIAG
         unsigned long long sd[6];
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[0] = t_; }
@@ -723,6 +811,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd[4] = t_; }
 #endif
 
+        if (BINS) complete_pending(s_wprev);                      // (the previous tile's items: their slots have had a tile's time to arrive)
         // ---- 5. one lane per supermer: task, run length, counters, record ----------------------------------
         {
             const u64 *bw = reinterpret_cast<const u64 *>(s_bnd8);
@@ -738,19 +827,38 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 if (m) nb = w * 64 + (u32)__builtin_ctzll(m);
                 else if ((w & 1) == 0) { const u64 m2 = bw[w + 1]; if (m2) nb = (w + 1) * 64 + (u32)__builtin_ctzll(m2); }
                 u32 nk = nb - p;
-                if (a.tile_sub && nk > 16u) {
+                if constexpr (BINS) {
+                    const BinTable &bt = *a.bins;
+                    // the combining extraction on one GPU, items placed by this kernel.  The supermer's slot is RESERVED here (one atomic on its bin's
+                    // cursor) and the answer is taken up a tile later (complete_pending, before the next tile's supermers are cut): the round trip
+                    // to the L2 hides behind the next tile's hashes.  Only a lane's first two supermers of a tile travel that way; the rest -- more
+                    // than 512 supermers in a tile, the pieces behind the first of a supermer longer than an item -- resolve at once.
+                    const u32 bin = xcc_nvt + d;
+                    for (u32 pp = p, rest = nk, first = 1u; rest; first = 0u) {
+                        const u32 piece = rest < maxk ? rest : maxk;
+                        atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)piece);
+                        const u32 pos = bin_reserve(bt, bin);
+                        if (first && r < 2u * PARSE_THREADS) {
+                            s_pend[r] = make_uint2(pp | (piece << 11) | (d << 16), sub);
+                            if (r < (u32)PARSE_THREADS) { pend_pos0 = pos; pend_mask |= 1u; } else { pend_pos1 = pos; pend_mask |= 2u; }
+                        } else bin_store(bt, bin_slot(bt, bin, pos, s_mc, d), bits64_be32(s_words, 2u * pp), bits64_be32(s_words, 2u * pp + 64u), piece, sub);
+                        pp += piece; rest -= piece;
+                    }
+                    continue;
+                }
+                if (a.tile_sub && nk > maxk) {
                     // combining extraction (hsk_combine.h): no supermer longer than 16 k-mers -- one work item, one 16-byte record.  A window
                     // minimum lives for at most W <= 15 positions unless its m-mer repeats (homopolymers, tandem repeats): rare; the rest of
                     // such a run leaves as extra records of 16 k-mers behind the tile's regular ones (their order does not matter)
-                    for (u32 pp = p + 16u, rest = nk - 16u; rest; ) {
-                        const u32 piece = rest < 16u ? rest : 16u;
+                    for (u32 pp = p + maxk, rest = nk - maxk; rest; ) {
+                        const u32 piece = rest < maxk ? rest : maxk;
                         const u32 rx = nrec + atomicAdd(&s_scan[10], 1u);
                         atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)piece);
                         atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((piece + K - 1 + 3) >> 2));
                         if (rx < a.rec_cap) { trec[rx] = pp | ((piece - 1) << 11) | (d << 18); a.tile_sub[tile * (u64)a.rec_cap + rx] = sub; }
                         pp += piece; rest -= piece;
                     }
-                    nk = 16u;
+                    nk = maxk;
                 }
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 0], (1ULL << 40) | (unsigned long long)nk);
                 atomicAdd((unsigned long long *)&s_cur[2 * d + 1], (unsigned long long)((nk + K - 1 + 3) >> 2));
@@ -758,7 +866,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
         }
         lds_barrier();
-        if (tid == 0) {
+        if (tid == 0 && !BINS) {
             const u32 nall = nrec + s_scan[10];                           // (the extra records have been counted: barrier above)
             a.tile_nrec[tile] = nall;
             if (nall > a.rec_cap) atomicOr(a.overflow, 1u);
@@ -773,11 +881,13 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 #ifdef HSK_DIAG
     if (tid == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_scan_diag[q], dacc[q]); atomicAdd(&g_scan_diag[8], dacc[5]); }
 #endif
+    if (BINS) complete_pending(s_words2[BINS ? (wsel ^ 1u) : 0u]);              // the last tile's items (its words: the buffer the loop used last)
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
         u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
         const u64 pk = s_cur[2 * t];
-        if (a.slab == 0 || a.place_one) { o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1); }      // (place_one: every slab has its own matrix)
-        else { o[0] += pk >> 40; o[1] += s_cur[2 * t + 1]; o[2] += pk & ((1ULL << 40) - 1); }      // (same workgroup, launches in stream order)
+        const u64 bytes_t = BINS ? 0ULL : s_cur[2 * t + 1];
+        if (a.slab == 0 || a.place_one) { o[0] = pk >> 40; o[1] = bytes_t; o[2] = pk & ((1ULL << 40) - 1); }      // (place_one: every slab has its own matrix)
+        else { o[0] += pk >> 40; o[1] += bytes_t; o[2] += pk & ((1ULL << 40) - 1); }      // (same workgroup, launches in stream order)
     }
 }
 

@@ -32,6 +32,8 @@ def instance():
     ({"HSK_COMBINE_BUCKET": "300"}, "as many buckets as the order allows: nearly empty tables"),
     ({"HSK_COMBINE_PREFIX": "16"}, "bins of the instance path's width"),
     ({"HSK_COMBINE_PREFIX": "11"}, "few, long bins: the ladder of the weighted finish"),
+    ({"HSK_SCAN_PLACE": "1"}, "items placed by scan_kernel itself into (XCD, virtual task) chunk lists: no tile records, no placement kernel"),
+    ({"HSK_SCAN_PLACE": "1", "HSK_COMBINE_BUCKET": "300"}, "... with nearly empty tables"),
 ])
 def test_combining_extraction_equals_instance_path(instance, env, why):
     r = run(BASE, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
@@ -67,6 +69,8 @@ def test_input_without_copies_leaves_the_combining_extraction():
 @pytest.mark.parametrize("env,spec,why", [
     ({"HSK_XCD_BATCH": "0"}, dict(), "the one-task-per-XCD kernels are switched off: no batch to run the combining extraction on; the call starts again without it"),
     ({"HSK_PARSE_REC_CAP": "200"}, dict(), "tiles beyond the record capacity: the parse leaves its fast path, and the virtual tasks with it"),
+    ({"HSK_SCAN_PLACE": "1", "HSK_BIN_CAP_PCT": "20"}, dict(), "items placed by the scan, and their chunk store runs out (sized at a fifth of the expected supermers): error bit, the call again on the instance path"),
+    ({"HSK_SCAN_PLACE": "1", "HSK_BIN_VMAX": "1"}, dict(genome=6000000, nreads=1500000), "items placed by the scan, a bin of more chunks than its map has entries"),
 ])
 def test_calls_that_start_again_without_the_combining_extraction(env, spec, why):
     sp = dict(BASE, **spec)
@@ -114,7 +118,7 @@ def test_host_paths_through_the_combining_extraction(instance):
     """hsk_count() from pageable and from pinned host memory (slab ingest pipelined with scan and item placement: the store is laid out
     [slab][virtual task]) give the list of the device-resident call"""
     spec = dict(BASE, genome=3000000, nreads=1100000, calls=["device", "host", "pinned", "pinned"])      # 41 MB of packed reads: above the slab-ingest limit
-    rs = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})
+    rs = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"}) + run(spec, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_SCAN_PLACE": "1"})      # (... and with the items placed by the scan, slab by slab)
     ref = run(dict(spec, calls=["device"]), {"HSK_COMBINE": "0"})[0]
     assert all(r["combine_launches"] > 0 for r in rs)
     assert {r["digest"] for r in rs} == {ref["digest"]}
@@ -183,7 +187,8 @@ def test_owner_side_combining_extraction_equals_instance_path(R, ntasks, env, wh
         sp.update(genome=8000000, nreads=800000)
     ref = run(sp, {"HSK_COMBINE": "0"})[0]
     r = run(sp, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
-    assert ref["combine_launches"] == 0 and r["combine_launches"] > 0 and r["instance_extractions"] == 0, why
+    assert ref["combine_launches"] == 0 and r["combine_launches"] > 0, why
+    assert r["instance_extractions"] == 0 or "HSK_COMBINE_PREFIX" in env, why        # (the weighted long way's full-width passes count their histogram launches there)
     assert r["combine_kmers"] == r["total_kmers"] == ref["total_kmers"], why
     assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"]), why
     if "HSK_COMBINE_PREFIX" in env:
@@ -197,4 +202,4 @@ def test_weighted_long_way_on_one_gpu():
     ref = run(sp, {"HSK_COMBINE": "0"})[0]
     r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_COMBINE_PREFIX": "9"})[0]
     assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
-    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    assert r["combine_launches"] > 0 and r["redone_tasks"] > 0
