@@ -227,7 +227,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 // ------------------------------------------------------------------------------------------------
 // The plan is chosen INSIDE the call (hysortk::kmer_count() is called once per process, reference src/hysortk.cpp:36-96: there is
 // no "next call" that could profit from what this one learned).  Before anything is parsed, a sketch of the input is counted
-// (hsk_estimate.h: the reads inside the first 1/256 of the packed buffer (4 - 32 MB), 1/32 of their canonical k-mers by hash, a global table):
+// (hsk_estimate.h: the reads inside the first 1/64 of the packed buffer (4 - 64 MB), 1/32 of their canonical k-mers by hash, a global table):
 // n1, n2, n3 = chosen k-mers seen once, twice, three times in the sample.  Two components explain them: genomic k-mers, Poisson with
 // mean lambda_s copies inside the sample (lambda_s = 3 n3 / n2, their number G = 2 n2 exp(lambda_s) / lambda_s^2 -- doubletons and
 // tripletons are nearly free of sequencing errors), and k-mers that occur once whatever the depth (errors, a uniform input):
@@ -244,12 +244,12 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
 {
     c->est = PlanEstimate();
     const bool enabled = tune("plan_sample", 1) != 0;
-    constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 32ULL << 20;
+    constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 64ULL << 20;
     // who would use it: one-word keys without payload on one GPU (combining extraction or not, first table, aggregation or not)
-    if (!enabled || c->nw != 1 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
+    if (!enabled || c->nw > 2 || c->cfg.kmer_size >= 64 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
     if (c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT)) return HSK_OK;         // nothing to choose
     const auto t0 = std::chrono::steady_clock::now();
-    u64 want = std::min<u64>(std::max<u64>(packed_bytes / 256, MIN_SAMPLE), MAX_SAMPLE);      // (10 Gbp: 10 MB of reads, ~1.2 M chosen k-mer instances: 0.4 ms)
+    u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);      // (10 Gbp: 40 MB of reads, ~4 M chosen k-mer instances: 1.2 ms of kernels)
     u64 lost = 0, n1 = 0, n2 = 0, n3 = 0, ds = 0, ns = 0, s_bytes = 0;
     unsigned long long *h_out = (unsigned long long *)((char *)c->pinned + c->pinned_bytes - 512);
     for (int round = 0; round < 2; ++round) {
@@ -277,7 +277,7 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
         HIPCHK(c, hsk_sync(c, c->stream));
         release();                                                          // (stream-ordered reuse: the kernels above are done)
         lost = h_out[0]; n1 = h_out[1]; n2 = h_out[2]; n3 = h_out[3]; ds = h_out[4]; ns = h_out[5];
-        // shallow data (coverage below ~10): too few tripletons in 1/256 of the reads to tell the depth -- once more on sixteen times as many
+        // shallow data (coverage below ~3): too few tripletons in 1/64 of the reads to tell the depth -- once more on sixteen times as many
         if (round == 0 && !lost && n2 >= 16 && n3 < 256 && want * 16 <= packed_bytes / 2 && want * 16 <= (512ULL << 20)) { want *= 16; continue; }
         break;
     }
@@ -289,7 +289,11 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
         lam = std::min(30.0, std::max(1e-3, 3.0 * (double)n3 / (double)n2));
         G = 2.0 * (double)n2 * std::exp(lam) / (lam * lam);
         G = std::min(G, (double)ds / std::max(1e-9, 1.0 - std::exp(-lam)));      // (never more genomic k-mers than the sample's distinct ones can stand for)
-        Es = std::max(0.0, (double)n1 - G * lam * std::exp(-lam));
+        // E_s is the difference of two large numbers: the genomic singletons are known to 1 / sqrt(n3) of themselves (lambda_s comes from n3 / n2, and
+        // G lambda exp(-lambda) goes like 1 / lambda).  Two standard deviations are taken off: a clean, deep input must not be sent down the instance
+        // path by the noise of its own sketch (-20 %), while a few per cent of error k-mers overlooked cost a few per cent at most (the plans cross there).
+        const double gs = G * lam * std::exp(-lam);
+        Es = std::max(0.0, (double)n1 - gs - 2.0 * gs / std::sqrt((double)n3));
     }
     e.lambda_sample = lam;
     const double D = e.fraction * G * (1.0 - std::exp(-lam / e.fraction)) + Es;

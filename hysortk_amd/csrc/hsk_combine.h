@@ -82,13 +82,11 @@ __global__ __launch_bounds__(256) void bins_items_kernel(BinItemsArgs a)
 {
     const u32 ph = blockIdx.x * 256u + threadIdx.x;
     if (ph >= a.nchunks) return;
-    const u32 bin = a.chunk_bin[ph], vt = bin % a.nvt;
-    const u64 cur = a.cursor[(u64)bin * BIN_CUR_STRIDE];
-    const u64 last_v = cur ? (cur - 1) / BIN_CHUNK : 0;
-    const u32 last_ph = last_v < a.vmax ? a.map[(u64)bin * a.vmax + last_v] : 0u;
+    const u32 cb = a.chunk_bin[ph], bin = cb & 8191u, v = cb >> 13, vt = bin % a.nvt;      // (a chunk knows its bin and its place in the bin's list)
+    const u64 cur = a.cursor[(u64)bin * BIN_CUR_STRIDE], lo = (u64)v * BIN_CHUNK;
     BucketItem it;
     it.first = (u64)ph * BIN_CHUNK;
-    it.n = (last_ph == ph + 1u) ? (u32)(cur - last_v * BIN_CHUNK) : BIN_CHUNK;
+    it.n = cur <= lo ? 0u : (cur - lo >= BIN_CHUNK ? BIN_CHUNK : (u32)(cur - lo));         // (a chunk opened ahead may have stayed empty)
     it.task = (u16)(vt >> a.vt_shift); it.hi = (u16)(vt & ((1u << a.vt_shift) - 1u));
     a.items[ph] = it;
 }
@@ -458,6 +456,194 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a)
                 }
                 // one barrier per round: the round's flag is one of three taken in turn; the next round's is cleared before the barrier (its
                 // last readers read it two rounds ago, i.e. before they arrived at the previous round's barrier)
+                const u32 fl = 1u + round % 3u;
+                if (tid == 0) s_flag[1u + (round + 1u) % 3u] = 0;
+                if (mm) s_flag[fl] = 1;
+                ++round;
+                xs_barrier();
+                if (s_flag[fl] == 0) break;
+                dump();
+            }
+        }
+        dump();
+    }
+    {
+        const u32 cv = s_hist[tid];
+        if (cv) atomicAdd((unsigned long long *)&t.ghist[tid], (unsigned long long)cv);
+    }
+}
+
+// ---- 3b. two-word keys (40 <= K <= 55; round 4) ---------------------------------------------------------------------------------------
+// The same plan for k-mers of two words: an item is still the supermer's first 64 bases, so it carries at most 61 - K k-mers (ParseArgs::
+// item_maxk: the last four bases give way to the count); the table holds {word 1, word 0, count} and is filled by the probe loop of the
+// two-word finish (agg2_count_keys: a slot is claimed on word 1, word 0 published behind it); the pairs leave as 16-byte records {word 0,
+// word 1} into the chunk store of the first radix pass (digits: the top bits of word 1) with their counts beside them.  No first sweep over
+// the home slots here: a 16-byte key has no 32-byte LDS read to take a pair of slots with.
+#ifndef CB2_LOG2CAP
+#define CB2_LOG2CAP 11
+#endif
+#ifndef C2_GROUP_N
+#define C2_GROUP_N 4
+#endif
+template <int KT = 0>
+__global__ __launch_bounds__(CB_THREADS) void combine2_kernel(CombineArgs a)
+{
+    constexpr int CHUNK = XsCfg<2>::CHUNK;
+    constexpr int CB_CAP = 1 << CB2_LOG2CAP, CB_PER = CB_CAP / CB_THREADS, CB_LOG2CAP_ = CB2_LOG2CAP;
+    static_assert(CB_CAP <= (XS_SPAN - 1) * CHUNK, "a dump's reservation touches at most XS_SPAN chunks of a digit");
+    __shared__ u64 s_k1[CB_CAP];
+    __shared__ u64 s_k0[CB_CAP];
+    __shared__ u32 s_val[CB_CAP];
+    __shared__ u32 s_cnt[256], s_hist[256];
+    __shared__ uint4 s_dl[256];
+    __shared__ u32 s_scr[CB_WAVES];
+    __shared__ u32 s_flag[4];
+    typedef __attribute__((address_space(1))) u32 G32;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const int tid = threadIdx.x;
+    const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
+    const CombineTask &t = a.t[xcc];
+    if (t.nb == 0) return;
+    const int k = KT ? KT : a.k;                       // 33 .. 59
+    const u64 lastmask = ~0ULL << (128 - 2 * k);       // the bases of word 1
+    const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u, dm0 = (1u << a.bits0) - 1u;
+    const u32 k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, val_lds = (u32)(uintptr_t)(LdsPtr)s_val;
+    const int lane = lane_id();
+#pragma unroll
+    for (int j = 0; j < CB_PER; ++j) { s_k1[j * CB_THREADS + tid] = AG_EMPTY; s_k0[j * CB_THREADS + tid] = AG_EMPTY; s_val[j * CB_THREADS + tid] = 0; }
+    s_cnt[tid] = 0; s_hist[tid] = 0;
+    if (tid == 0) { s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; }
+    u32 round = 0;
+
+    auto dump = [&]() {                                 // as in combine_kernel, records of two words
+        u64 m1[CB_PER], m0[CB_PER]; u32 mv[CB_PER];
+#pragma unroll
+        for (int j = 0; j < CB_PER; ++j) {
+            m1[j] = s_k1[j * CB_THREADS + tid]; m0[j] = s_k0[j * CB_THREADS + tid]; mv[j] = s_val[j * CB_THREADS + tid];
+            if (m1[j] != AG_EMPTY) atomicAdd(&s_cnt[((u32)(m1[j] >> 32) >> sh0) & dm0], 1u);
+        }
+        xs_barrier();
+        const u32 c = s_cnt[tid];
+        u32 tot;
+        const u32 st = block_excl_scan_xs<CB_WAVES>(c, s_scr, &tot);
+        if (tot) {
+            s_cnt[tid] = st;
+            if (c) {
+                const u64 p = __hip_atomic_fetch_add(&t.cursor[tid], (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u64 v0 = p / CHUNK;
+                const u32 off0 = (u32)(p % CHUNK);
+                const u32 nv = (off0 + c - 1) / CHUNK + 1;
+                G32 *mp = (G32 *)(t.map + (u64)tid * t.vmax);
+                u32 ph[XS_SPAN] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < XS_SPAN; ++q) {
+                    if ((u32)q >= nv || (q == 0 && off0 != 0)) continue;
+                    ph[q] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    __hip_atomic_store(mp + v0 + q, ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (off0 != 0) {
+                    u32 spins = 0;
+                    while ((ph[0] = __hip_atomic_load(mp + v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                        if (++spins > XS_SPIN_LIMIT) { atomicOr(a.err, 2u); ph[0] = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const u32 split = st + ((u32)CHUNK - off0);
+                s_dl[tid] = make_uint4(split, (ph[0] - 1) * (u32)CHUNK + off0 - st, ((ph[1] ? ph[1] : 1u) - 1) * (u32)CHUNK - split,
+                                       ((ph[2] ? ph[2] : 1u) - 1) * (u32)CHUNK - (split + (u32)CHUNK));
+            }
+            xs_barrier();
+#pragma unroll
+            for (int j = 0; j < CB_PER; ++j) {
+                if (m1[j] == AG_EMPTY) continue;
+                const u32 hi = (u32)(m1[j] >> 32);
+                const u32 d = (hi >> sh0) & dm0;
+                const u32 i = atomicAdd(&s_cnt[d], 1u);
+                const uint4 dl = s_dl[d];
+                const u32 o = i + (i < dl.x ? dl.y : (i < dl.x + (u32)CHUNK ? dl.z : dl.w));   // (mod 2^32)
+                reinterpret_cast<ulonglong2 *>(t.chunks)[o] = make_ulonglong2(m0[j], m1[j]); t.vchunks[o] = (u64)mv[j];
+                atomicAdd(&s_hist[(hi >> sh1) & 255u], 1u);
+                s_k1[j * CB_THREADS + tid] = AG_EMPTY; s_k0[j * CB_THREADS + tid] = AG_EMPTY; s_val[j * CB_THREADS + tid] = 0;
+            }
+            xs_barrier();
+            s_cnt[tid] = 0;
+        }
+        xs_barrier();
+    };
+
+    for (;;) {
+        xs_barrier();
+        if (tid == 0) s_flag[0] = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        xs_barrier();
+        const u32 b = s_flag[0];
+        if (b >= t.nb) break;
+        const u32 r0 = t.boff[b], r1 = t.boff[b + 1];
+        ulonglong2 nxt = make_ulonglong2(0, 0);
+        if (r0 + (u32)tid < r1) nxt = t.recs[r0 + (u32)tid];
+        for (u32 base = r0; base < r1; base += CB_THREADS) {
+            const ulonglong2 itm = nxt;
+            { const u32 s2 = base + CB_THREADS + (u32)tid; nxt = s2 < r1 ? t.recs[s2] : make_ulonglong2(0, 0); }
+            const u64 win0 = itm.x, win1 = itm.y & ~0xFFULL;
+            u32 cnt = (u32)(itm.y & 0xFFULL);
+            if (cnt > 16u || (int)cnt + k - 1 > 60) { atomicOr(a.err, 4u); cnt = 0; }
+            u32 mm = cnt ? (0xFFFFu >> (16u - cnt)) : 0u;
+            {
+                // first sweep, as in combine_kernel: the home slots of C2_GROUP k-mers are read together (both words: one LDS latency for the group instead of
+                // one probe loop of the whole wave per k-mer); a k-mer that finds itself at home -- at c-fold coverage all but one in c -- adds one.  A slot
+                // that is claimed but not published yet (word 0 still ~0) simply does not match: that k-mer takes the probe loop below, which waits.
+                constexpr int C2_GROUP = C2_GROUP_N;
+                const int low1 = 128 - 2 * k;
+                Mer<2> fw, rc;
+                fw.w[0] = win0; fw.w[1] = win1 & lastmask;
+                rc = twin<2>(fw, k);
+#pragma unroll 1
+                for (int q0 = 0; q0 < 16; q0 += C2_GROUP) {
+                    if (__ballot((u32)q0 < cnt) == 0) break;
+                    u64 kw0[C2_GROUP], kw1[C2_GROUP], c1[C2_GROUP], c0[C2_GROUP]; u32 hh[C2_GROUP];
+#pragma unroll
+                    for (int q = 0; q < C2_GROUP; ++q) {
+                        const int r = q0 + q;
+                        if (r > 0) {
+                            fw.w[0] = funnel_left(win0, win1, 2 * r);
+                            fw.w[1] = (win1 << (2 * r)) & lastmask;
+                            const u64 nb = (fw.w[1] >> low1) & 3;                        // the base that entered: the strand's last, the twin's first
+                            rc.w[1] = ((rc.w[1] >> 2) | (rc.w[0] << 62)) & lastmask;
+                            rc.w[0] = (rc.w[0] >> 2) | ((3 - nb) << 62);
+                        }
+                        // the smaller strand without four selects on one condition (v_cndmask_b32 x 4 behind one compare issues at a quarter of the rate of
+                        // and / xor: profiles/r04_valu_rates.txt, cmp32_cnd4): a mask and three full-rate operations per half word
+                        const u64 sel = mer_less<2>(rc, fw) ? ~0ULL : 0ULL;
+                        kw0[q] = fw.w[0] ^ ((fw.w[0] ^ rc.w[0]) & sel); kw1[q] = fw.w[1] ^ ((fw.w[1] ^ rc.w[1]) & sel);
+                        const u64 m = kw0[q] ^ (kw1[q] >> 9) ^ (kw1[q] << 21);
+                        hh[q] = (((u32)(m >> 32) ^ (u32)m) * 0x9E3779B1u) >> (32 - CB_LOG2CAP_);
+                        c1[q] = s_k1[hh[q]]; c0[q] = s_k0[hh[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < C2_GROUP; ++q) {
+                        const u32 r = (u32)(q0 + q);
+                        if (r < cnt && c1[q] == kw1[q] && c0[q] == kw0[q]) { atomicAdd(&s_val[hh[q]], 1u); mm &= ~(1u << r); }
+                    }
+                }
+            }
+            for (;;) {
+                bool stuck = false;
+                for (;;) {
+                    const bool mine = mm != 0 && !stuck;
+                    const u64 act = __ballot(mine);
+                    if (act == 0) break;
+                    const u32 r = mine ? (u32)__builtin_ctz(mm) : 0u;
+                    Mer<2> fw, rc;
+                    fw.w[0] = r ? funnel_left(win0, win1, 2 * (int)r) : win0;
+                    fw.w[1] = (win1 << (2 * r)) & lastmask;
+                    rc = twin<2>(fw, k);
+                    const u64 sel = mer_less<2>(rc, fw) ? ~0ULL : 0ULL;
+                    const u64 w0 = fw.w[0] ^ ((fw.w[0] ^ rc.w[0]) & sel), w1 = fw.w[1] ^ ((fw.w[1] ^ rc.w[1]) & sel);
+                    const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
+                    const u32 x = (u32)(m >> 32) ^ (u32)m;
+                    u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - CB_LOG2CAP_);
+                    const u64 left = agg2_count_keys<(u32)CB_CAP - 1u>(act, k1_lds, k0_lds, val_lds, h, w1, w0, tmo);
+                    if (mine) { if (((left >> lane) & 1ULL) || tmo) stuck = true; else mm &= mm - 1u; }
+                }
                 const u32 fl = 1u + round % 3u;
                 if (tid == 0) s_flag[1u + (round + 1u) % 3u] = 0;
                 if (mm) s_flag[fl] = 1;

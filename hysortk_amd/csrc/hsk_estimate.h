@@ -3,7 +3,7 @@
 // hysortk::kmer_count() is called once per process (reference src/hysortk.cpp:36-96): a plan that pays only for some inputs (the
 // combining extraction of hsk_combine.h, the LDS aggregation's first table, aggregating at all) must be chosen from the input itself,
 // inside the call.  What all of these depend on is ONE number: distinct canonical k-mers per k-mer instance.  The sketch:
-//   * the reads that lie inside the first 1/256 of the packed buffer (4 - 32 MB: `sample`),
+//   * the reads that lie inside the first 1/64 of the packed buffer (4 - 64 MB: `sample`),
 //   * of their canonical k-mers those whose 64-bit mix falls into a 1/32 slice of the hash space (ALL copies of a chosen k-mer inside
 //     the sample are seen, so the chosen k-mers' multiplicities are exact),
 //   * counted in a global open-addressing table (a few million inserts: ~0.3 ms), whose occupancy histogram gives n1, n2, n3 (k-mers

@@ -182,10 +182,12 @@ static int build_items_batch(hsk_ctx *c, u32 ntasks, const u32 *tk, const Expand
 // The batch's tasks (tk[i]: task of XCD i, ~0u: none) from bucket-ordered records to {k-mer, count} pairs in the chunk stores bt[i].kB
 // (keys) / bt[i].vB (counts); the histogram of the second pass's digit goes to ghist[i] + 256.  What follows is sort_batch_prescattered
 // with the counts as payload; sb.h_nout[i] then holds the pairs of task i (read after the stream has passed chunk_tiles_kernel).
+template <int NW>
 static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *const *ghist, const PassDesc *plan, const BucketOrder &bo,
                          u64 *h_nout, ScatterBatch &sb, hipStream_t stream)
 {
-    constexpr int CH = XsCfg<1>::CHUNK;
+    static_assert(NW == 1 || NW == 2, "keys of one or two words");
+    constexpr int CH = XsCfg<NW>::CHUNK;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     sb = ScatterBatch();
     ScatterArgs &a = sb.args; memset(&a, 0, sizeof a);
@@ -225,10 +227,15 @@ static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *co
     a.k = c->cfg.kmer_size; a.shift0 = plan[0].shift; a.shift1 = plan[1].shift; a.chunk = CH; a.err = c->d_err;
     ca.k = a.k; ca.shift0 = a.shift0; ca.bits0 = plan[0].bits; ca.shift1 = a.shift1; ca.err = c->d_err;
     static int occ = 0;
-    if (!occ) { int nb = 0; occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, combine_kernel<31>, CB_THREADS, 0) == hipSuccess && nb > 0) ? nb : 2; }
+    if (!occ) {
+        int nb = 0;
+        const hipError_t e = NW == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, combine_kernel<31>, CB_THREADS, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, combine2_kernel<51>, CB_THREADS, 0);
+        occ = (e == hipSuccess && nb > 0) ? nb : 2;
+    }
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 7; ep.keys = ntot; ep.bytes = 0; (void)hipEventRecord(ep.a, stream); }
     const u32 grid = (u32)occ * 256u;
-    if (a.k == 31) hipLaunchKernelGGL((combine_kernel<31>), dim3(grid), dim3(CB_THREADS), 0, stream, ca);
+    if (NW == 2) { if (a.k == 51) hipLaunchKernelGGL((combine2_kernel<51>), dim3(grid), dim3(CB_THREADS), 0, stream, ca); else hipLaunchKernelGGL((combine2_kernel<0>), dim3(grid), dim3(CB_THREADS), 0, stream, ca); }
+    else if (a.k == 31) hipLaunchKernelGGL((combine_kernel<31>), dim3(grid), dim3(CB_THREADS), 0, stream, ca);
     else hipLaunchKernelGGL((combine_kernel<0>), dim3(grid), dim3(CB_THREADS), 0, stream, ca);
     if (profile) { (void)hipEventRecord(ep.b, stream); c->ev_pending.push_back(ep); }
     // the tile lists of the second pass and the pairs of every task (the host sizes the second pass and the finish from them)

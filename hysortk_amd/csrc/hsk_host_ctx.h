@@ -229,6 +229,8 @@ static int fail(hsk_ctx *c, int code, const char *fmt, ...)
 #include <chrono>
 constexpr int HSK_RETRY_PLAN = -2000;               // internal: the call is run again with another plan (dispatch_pipeline; never returned to the caller)
 static bool timing_enabled() { static const bool on = getenv("HSK_TIMING") && atoi(getenv("HSK_TIMING")) != 0; return on; }
+// a call that starts again with another plan says why when HSK_TIMING is set
+static int retry_plan(const char *why, unsigned info = 0) { if (timing_enabled()) fprintf(stderr, "[hsk] the call starts again without the combining extraction: %s (%u)\n", why, info); return HSK_RETRY_PLAN; }
 static void tmark(const char *what)
 {
     if (!timing_enabled()) return;

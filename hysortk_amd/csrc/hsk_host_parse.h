@@ -127,9 +127,11 @@ static int bins_alloc(hsk_ctx *c, ScanBins &b, u32 nvt, u64 packed_bytes, u64 nr
 {
     b = ScanBins();
     const double positions = (double)packed_bytes * 4.0;
-    const double expect = positions * std::max(2.2 / (double)(W + 1), 1.0 / 14.0) + 2.0 * (double)nreads + 65536.0;
+    const double maxk = (double)std::max(1, std::min(16, 61 - c->cfg.kmer_size));      // k-mers per item at most (ParseArgs::item_maxk)
+    const double expect = positions * std::max(2.2 / (double)(W + 1), 1.2 / maxk) + 2.0 * (double)nreads + 65536.0;
     b.nbins = 8u * nvt;
-    const u64 cap = (u64)(expect * (double)tune("bin_cap_pct", 125) / 100.0 / BIN_CHUNK) + (tune("bin_cap_pct", 125) >= 100 ? b.nbins + 64 : 1);      // (tests: a store that runs out)
+    if (b.nbins > 8192) return fail(c, HSK_ERR_UNSUPPORTED, "more than 8192 bins");      // (a chunk's owner word: 13 bits of bin)
+    const u64 cap = (u64)(expect * (double)tune("bin_cap_pct", 125) / 100.0 / BIN_CHUNK) + (tune("bin_cap_pct", 125) >= 100 ? 2 * b.nbins + 64 : b.nbins + 1);      // (+ a first chunk and a chunk opened ahead per bin)      // (tests: a store that runs out)
     if (cap >= 0xFFFFFFF0ULL) return fail(c, HSK_ERR_UNSUPPORTED, "item store of %llu chunks", (unsigned long long)cap);
     b.cap = (u32)cap;
     b.vmax = (u32)std::min<u64>(std::max<u64>(cap / b.nbins * 64, 256), 1u << 16);
@@ -147,6 +149,7 @@ static int bins_alloc(hsk_ctx *c, ScanBins &b, u32 nvt, u64 packed_bytes, u64 nr
     BinTable *h = (BinTable *)((char *)c->pinned + (384u << 10));      // (pinned staging: the copy is asynchronous)
     h->cursor = b.cursor; h->map = b.map; h->vmax = b.vmax; h->cap_chunks = b.cap; h->ctl = b.ctl; h->chunk_bin = b.chunk_bin; h->items = b.items; h->subs = b.subs; h->err = c->d_err;
     HIPCHK(c, hipMemcpyAsync(b.d_table, h, sizeof(BinTable), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(bins_init_kernel, dim3((b.nbins + 255) / 256), dim3(256), 0, stream, *h, b.nbins);
     return HSK_OK;
 }
 static void bins_args(hsk_ctx *, ParseArgs &a, const ScanBins &b) { a.bins = b.d_table; }
@@ -317,9 +320,9 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             if (h_ovf[1] & 32u) { (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); return fail(c, HSK_ERR_INVALID_ARG, "the read index is not ascending / overlaps / leaves the packed buffer"); }
         }
         if (j.bins.items && (h_ovf[1] & (2u | 128u | 256u))) {          // the chunk store or a bin's map ran out: the call again, without the combining extraction
-            (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); c->combine_veto = true; return HSK_RETRY_PLAN;
+            (void)hipMemsetAsync(c->d_err, 0, 4, c->stream); c->pool.release(d_task_tot); c->combine_veto = true; return retry_plan("the scan-placed items' chunk store or a bin's map ran out (error word)", h_ovf[1]);
         }
-        if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return HSK_RETRY_PLAN; }      // (the general kernels know no virtual tasks: the call again, without them)
+        if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return retry_plan("a tile beyond the record capacity"); }      // (the general kernels know no virtual tasks: the call again, without them)
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
             if (a.nslabs > 1) {                                       // the general kernels know one tile range per workgroup

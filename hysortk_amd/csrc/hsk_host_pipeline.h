@@ -340,12 +340,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     //  call starts again without it)
     const bool item_mode = x_src.item != nullptr;
     bool fed_combine = false;
-    if constexpr (NW == 1) {
-        combine = item_mode && xs && agg && !c->agg_off && !ext && !feeder && mine.size() % XCD_BATCH == 0;
+    if constexpr (NW <= 2) {
+        combine = item_mode && xs && agg && !(NW == 1 ? c->agg_off : c->agg_off_wide) && !ext && !feeder && mine.size() % XCD_BATCH == 0;
         fed_combine = fed_wanted && !item_mode && xs && agg && !c->agg_off && batch && mine.size() % XCD_BATCH == 0;
         combine = combine || fed_combine;
     }
-    if (item_mode && !combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+    if (item_mode && !combine) { c->combine_veto = true; return retry_plan("an item-mode store, but no batch to combine (xs / agg / batch)", (xs ? 1u : 0u) | (agg ? 2u : 0u) | (batch ? 4u : 0u) | ((mine.size() % XCD_BATCH == 0) ? 8u : 0u)); }
     BucketOrder border;
     BucketOrder border_fed[2]; FedItems fed_items[2];      // per slot: the items and the bucket order of the batch in flight (several ranks)
     bool slot_combine[2] = {false, false};
@@ -510,12 +510,13 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         slot_fext[sl] = fused_ext && !c->agg_off_wide;
         slot_follow[sl] = slot_agg[sl] || slot_fext[sl] || (NW == 1 && fused);
         const bool will_combine = combine && (fed_combine || border.active) && slot_agg[sl];
-        if (combine && !will_combine && !fed_combine) { c->combine_veto = true; return HSK_RETRY_PLAN; }      // (several ranks: the batch simply takes the instance path -- nobody starts a call again while peers wait)
-        const int prefix_bits = will_combine ? combine_prefix_bits(c) : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
+        if (combine && !will_combine && !fed_combine) { c->combine_veto = true; return retry_plan("a batch that cannot take the combining extraction"); }      // (several ranks: the batch simply takes the instance path -- nobody starts a call again while peers wait)
+        // (two-word keys: the finish orders a bin's keys by the bits below a 16-bit prefix, agg_order_many -- their pairs take bins of 16 bits)
+        const int prefix_bits = will_combine ? (NW == 1 ? combine_prefix_bits(c) : AG_PREFIX_BITS) : (slot_agg[sl] || slot_fext[sl]) ? AG_PREFIX_BITS : 64 - HYBRID_SHIFT;
         slot_prefix[sl] = prefix_bits;
         PassDesc plan[MAX_PASSES];
         int npass = batch_pass_plan<NW>(c, K, slot_follow[sl], will_combine ? AG_PREFIX_BITS : prefix_bits, plan);
-        if (will_combine) { npass = 2; plan[0] = PassDesc{0, 64 - prefix_bits, prefix_bits - 8}; plan[1] = PassDesc{0, 56, 8}; }      // the pairs' two digits: the low prefix bits, then the top 8
+        if (will_combine) { npass = 2; plan[0] = PassDesc{NW - 1, 64 - prefix_bits, prefix_bits - 8}; plan[1] = PassDesc{NW - 1, 56, 8}; }      // the pairs' two digits (most significant word): the low prefix bits, then the top 8
         pt.begin(PH_EXTRACT);
         HIPCHK(c, hipMemsetAsync(d_ghist_slot[sl], 0, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8, c->stream));
         ExpandJob jobs[XCD_BATCH];
@@ -534,7 +535,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         int rc;
         slot_combine[sl] = false;
         if (will_combine) {
-            if constexpr (NW == 1) {
+            if constexpr (NW <= 2) {
                 u32 tk[XCD_BATCH]; u64 *gh[XCD_BATCH];
                 for (int i = 0; i < XCD_BATCH; ++i) { tk[i] = mine[bpos + i]; gh[i] = d_ghist_slot[sl] + (size_t)i * MAX_PASSES * 256; }
                 memcpy(xs_plan, plan, sizeof(PassDesc) * 2);
@@ -546,9 +547,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                     rc = build_items_batch(c, ntasks, tk, jobs, s16, gsegs, gsrc, fed_items[sl], c->stream); if (rc) return rc;
                     rc = bucket_order_tasks(c, ntasks, gsegs, std::vector<u32>(tk, tk + XCD_BATCH), gsrc, FED_VT_SHIFT, border_fed[sl]); if (rc) return rc;
                     if (!border_fed[sl].active) return fail(c, HSK_ERR_UNSUPPORTED, "a task of 2^32 supermers and more");
-                    rc = combine_batch(c, tk, bts[sl], gh, plan, border_fed[sl], h_nout, sbatch[sl], c->stream); if (rc) return rc;
+                    rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border_fed[sl], h_nout, sbatch[sl], c->stream); if (rc) return rc;
                     fed_release(c, fed_items[sl]); bucket_release(c, border_fed[sl]);      // (stream-ordered reuse: their readers are enqueued)
-                } else { rc = combine_batch(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc; }
+                } else { rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc; }
                 slot_combine[sl] = sbatch[sl].active;
             }
         } else
@@ -581,7 +582,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                     if (!combine_prefix_forced() && slot_prefix[sl] < COMBINE_PREFIX_MAX) c->combine_prefix = c->combine_prefix_floor = COMBINE_PREFIX_MAX;      // once more with the narrowest bins
                     else if (!c->combine_off) c->leave_combine();
                     c->distrust_estimate((double)combine_ratio());
-                    return HSK_RETRY_PLAN;
+                    return retry_plan("a bin beyond the weighted finish");
                 }
             }
             return early_copy(tk, XCD_BATCH);
@@ -592,7 +593,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         pt.begin(PH_EXTRACT);
         int rc = bucket_order_tasks(c, ntasks, segs, mine, x_src, ex ? ex->vt_shift : 0, border); if (rc) return rc;
         pt.end(PH_EXTRACT);
-        if (!border.active) { c->combine_veto = true; return HSK_RETRY_PLAN; }
+        if (!border.active) { c->combine_veto = true; return retry_plan("no bucket order"); }
     }
     u64 comb_pairs = 0, comb_kmers = 0;                   // pairs the combining extraction has written / k-mers they stand for (this call)
     size_t pos = 0;
@@ -857,7 +858,9 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     if (est && c->agg_off && c->plan_attempt == 0) { c->agg_off = false; c->agg_off_calls = 0; }      // (process_rank decides again, from the estimate and the task sizes)
     // several ranks (round 4): the supermers travel as byte runs with 16 of their minimizer bits, the OWNER of a task builds the items (hsk_combine.h, 1b);
     // needs the grouped exchange and the byte-store placement, and every rank's consent (below)
-    c->combine_now = NW == 1 && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !c->agg_off && combine_enabled() && parse_fast_enabled() &&
+    // (two-word keys: 40 <= K <= 55 -- the prefix bits sit in the most significant word, an item of 64 bases holds six k-mers and more: shorter
+    //  items would be more records per tile than the parse keeps, for 16 bytes that stand for very few k-mers)
+    c->combine_now = (NW == 1 || (NW == 2 && K >= 40 && K <= 55 && nranks == 1)) && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !(NW == 1 ? c->agg_off : c->agg_off_wide) && combine_enabled() && parse_fast_enabled() &&
                      c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok &&
                      (nranks == 1 || (overlap_enabled() && place_bytes_enabled(true)));
     c->combine_veto = false;
@@ -919,7 +922,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
                 }
             }
         }
-        else if (prc == PARSE_FALLBACK && vts) { c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }      // (the fallback parse knows no virtual tasks: the call again, without them)
+        else if (prc == PARSE_FALLBACK && vts) { c->vt_shift = 0; c->combine_veto = true; return retry_plan("the pipelined ingest fell back"); }      // (the fallback parse knows no virtual tasks: the call again, without them)
         else if (prc != PARSE_FALLBACK) { c->vt_shift = 0; return prc; }
         else c->stats.parse_fallbacks++;                        // (the packed reads are in HBM now: the two-step parse below takes it from there)
     }
@@ -929,7 +932,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         ParseJob job;
         int rc = parse_count(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, nvt, job);
         if (rc && nranks == 1) { parse_release(c, job); c->vt_shift = 0; return rc; }
-        if (vts && !job.d_tile_sub && !job.bins.items && !job.empty) { parse_release(c, job); c->vt_shift = 0; c->combine_veto = true; return HSK_RETRY_PLAN; }   // (the parse left its fast path: no items)
+        if (vts && !job.d_tile_sub && !job.bins.items && !job.empty) { parse_release(c, job); c->vt_shift = 0; c->combine_veto = true; return retry_plan("the parse left its fast path: no items"); }   // (the parse left its fast path: no items)
         if (nranks > 1) {
             // Several ranks: a rank that fails must not return alone (its peers would wait for it in the next collective for
             // ever).  Every all-reduce below carries the ranks' status as one more element; a failed rank keeps taking part

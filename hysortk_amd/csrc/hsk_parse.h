@@ -507,7 +507,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void emit_kernel(ParseArgs a)
 constexpr int SCAN_MAX_M = 25;
 constexpr u32 BIN_CHUNK = 8192;                       // items per chunk of a scan-placed bin (= one staging step of bucket_scatter_kernel)
 constexpr unsigned PARSE_XCC_GETREG = 20u | (0u << 6) | (3u << 11);      // HW_REG_XCC_ID, bits [3:0] (as hsk_sort.h)
-constexpr u32 BIN_SPIN_LIMIT = 1u << 22;
+constexpr u32 BIN_SPIN_LIMIT = 1u << 12;               // (~0.25 M cycles: see bin_slot)
 constexpr u32 BIN_CUR_STRIDE = 32;                    // a bin's 32-bit cursor has a 128-byte line to itself: the L2 takes the atomics of one LINE one after the other, and 16 cursors
                                                       // to a line made 40 hot lines per XCD carry 131 M atomics each call (measured: the scan 75 instead of 60 ms)
 
@@ -521,35 +521,45 @@ __device__ __forceinline__ u32 bin_reserve(const BinTable &a, u32 bin)
 }
 __device__ __forceinline__ u64 bin_slot(const BinTable &a, u32 bin, u32 p, unsigned long long *mc /* LDS: {v << 32 | chunk + 1} of virtual task vt at mc[2 vt] */, u32 vt)
 {
-    u32 *const err = a.err;
     typedef __attribute__((address_space(1))) u32 G32;
+    u32 *const err = a.err;
     const u32 v = p / BIN_CHUNK, off = p % BIN_CHUNK;
     if (v >= a.vmax) { atomicOr(err, 256u); return ~0ULL; }
-    G32 *mp = (G32 *)(a.map + (u64)bin * a.vmax + v);
-    // Publish BEFORE anybody waits (two statements one after the other, as in hsk_scatter.h): a lane that opens a chunk and a lane that waits for
-    // that very chunk may sit in the same wave -- as the two arms of one `if` the waiting arm could run first and never end
-    u32 ph = 0;
-    if (off == 0) {
-        ph = __hip_atomic_fetch_add(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if (ph > a.cap_chunks) { atomicOr(err, 128u); ph = 0xFFFFFFFFu; }
-        else a.chunk_bin[ph - 1u] = bin;
-        __hip_atomic_store(mp, ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        mc[2u * vt] = ((unsigned long long)v << 32) | ph;
-    }
-    if (off != 0) {
-        const unsigned long long e = mc[2u * vt];
-        if ((u32)(e >> 32) == v && (u32)e != 0u) ph = (u32)e;
+    // Chunks are opened AHEAD: a bin's first chunk by the host (bins_init_kernel), chunk v + 1 by the item that lands in the middle of chunk v.  Nobody
+    // ever waits for a chunk whose opener has not even reserved its slot yet -- an item resolves its slot up to a tile after it reserved it, and a lane that
+    // waited for an opener of its own workgroup's current tile would wait for ever (both sit behind the same barrier).  A bin would have to take half a
+    // chunk of items within one tile's time to overrun the opener: only an input of ONE repeated minimizer does that, and it gets error bit 2 after a
+    // short wait (the call then runs again without the combining extraction) instead of a slot.
+    if (off == BIN_CHUNK / 2) {
+        if (v + 1 >= a.vmax) atomicOr(err, 256u);
         else {
-            u32 spins = 0;
-            while ((ph = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
-                if (++spins > BIN_SPIN_LIMIT) { atomicOr(err, 2u); ph = 0xFFFFFFFFu; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            mc[2u * vt] = ((unsigned long long)v << 32) | ph;
+            u32 nx = __hip_atomic_fetch_add(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (nx > a.cap_chunks) { atomicOr(err, 128u); nx = 0xFFFFFFFFu; }
+            else a.chunk_bin[nx - 1u] = bin | ((v + 1u) << 13);
+            __hip_atomic_store((G32 *)(a.map + (u64)bin * a.vmax + v + 1u), nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
+    u32 ph;
+    const unsigned long long e = mc[2u * vt];
+    if ((u32)(e >> 32) == v && (u32)e != 0u) ph = (u32)e;
+    else {
+        G32 *mp = (G32 *)(a.map + (u64)bin * a.vmax + v);
+        u32 spins = 0;
+        while ((ph = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+            if (++spins > BIN_SPIN_LIMIT) { atomicOr(err, 2u); ph = 0xFFFFFFFFu; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        mc[2u * vt] = ((unsigned long long)v << 32) | ph;
     }
     if (ph == 0xFFFFFFFFu) return ~0ULL;                                 // (the chunk store ran out when this chunk was opened)
     return (u64)(ph - 1u) * BIN_CHUNK + off;
+}
+// a bin's first chunk: chunk `bin` (the allocator starts behind them)
+__global__ void bins_init_kernel(BinTable t, u32 nbins)
+{
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbins) { t.map[(u64)b * t.vmax] = b + 1u; t.chunk_bin[b] = b; }
+    if (b == 0) t.ctl[0] = nbins;
 }
 __device__ __forceinline__ void bin_store(const BinTable &a, u64 slot, u64 w0, u64 w1, u32 nk, u32 sub)
 {

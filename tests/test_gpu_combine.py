@@ -203,3 +203,35 @@ def test_weighted_long_way_on_one_gpu():
     r = run(sp, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_COMBINE_PREFIX": "9"})[0]
     assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
     assert r["combine_launches"] > 0 and r["redone_tasks"] > 0
+
+
+# ---- two-word keys through the combining extraction (40 <= K <= 55): items of at most 61 - K k-mers, combine2_kernel, weighted two-word finish ----
+@pytest.mark.parametrize("K,env,why", [
+    (51, {}, "BASELINE configs[3]'s key shape: items of at most 10 k-mers"),
+    (51, {"HSK_COMBINE_BUCKET": "1000000000"}, "one bucket per virtual task: tables dumped inside a bucket, partial pairs"),
+    (51, {"HSK_COMBINE_BUCKET": "300"}, "nearly empty tables"),
+    (51, {"HSK_SCAN_PLACE": "1"}, "items placed by the scan"),
+    (41, {}, "9 bases in the second word: 16-k-mer items"),
+    (45, {}, "items of 16 k-mers exactly (61 - 45)"),
+    (55, {}, "items of six k-mers: the largest K the plan takes"),
+    (47, {"HSK_SCAN_GENERIC": "1"}, "generic scan instance, items of 14"),
+])
+def test_two_word_keys_through_the_combining_extraction(K, env, why):
+    sp = dict(BASE, K=K, L=1, U=65535)
+    ref = run(sp, {"HSK_COMBINE": "0"})[0]
+    r = run(sp, dict(env, HSK_COMBINE_MIN_BYTES="0"))[0]
+    assert ref["combine_launches"] == 0 and r["combine_launches"] > 0 and r["instance_extractions"] == 0, why
+    assert r["combine_kmers"] == r["total_kmers"] == ref["total_kmers"] and 0 < r["combine_pairs"] <= r["combine_kmers"], why
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"]), why
+
+
+def test_two_word_combining_extraction_vs_oracle(tmp_path):
+    from oracle import hsk_oracle as O
+    for K, M, nt in ((51, 17, 8), (43, 21, 24)):
+        dump = str(tmp_path / ("c%d.npz" % K))
+        spec = dict(BASE, K=K, M=M, ntasks=nt, L=1, U=65535, genome=400000, nreads=60000, dump=dump)
+        r = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
+        assert r["combine_launches"] > 0
+        z = np.load(dump)
+        want = O.count(z["packed"], z["off"], z["lens"], k=K, m=M, L=1, U=65535, ntasks=nt, fast=True)
+        assert np.array_equal(want.task_off, z["task_off"]) and np.array_equal(want.keys, z["kmers"]) and np.array_equal(want.cnt, z["cnt"]), (K, M, nt)
