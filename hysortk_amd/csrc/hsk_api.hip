@@ -309,7 +309,7 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
                              int64_t rid_base, hsk_result *out, int attempt = 0)
 {
     int rc;
-    if (attempt == 0) c->combine_left_now = false;
+    if (attempt == 0) { c->combine_left_now = false; c->pair_cap_full = false; }
     if (attempt == 0) { rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads); if (rc) return rc; }
     c->plan_attempt = attempt;                          // (from the third attempt on run_pipeline does not consider the combining extraction at all)
     const std::vector<void *> before = c->pool.snapshot();

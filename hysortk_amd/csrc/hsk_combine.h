@@ -294,6 +294,8 @@ struct CombineTask {
     const u32 *boff;           // [nb + 1] first item of every bucket
     u32 nb;                    // buckets (0: no task on this XCD)
     u32 vmax;
+    u32 cap_chunks;            // chunks the pair stores hold; the one behind them takes what does not fit (error bit 512: the host runs the call again with stores
+                               // sized for the k-mers -- they are sized for the pairs the call's sketch of the input promises, four times over)
     u64 *chunks, *vchunks;     // chunk stores of the keys and of the counts (same slots)
     u64 *cursor; u32 *map; u32 *ctl; u64 *ghist;       // as ScatterTask; ctl[0]: bucket ticket
 };
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a)
                 for (int q = 0; q < XS_SPAN; ++q) {
                     if ((u32)q >= nv || (q == 0 && off0 != 0)) continue;
                     ph[q] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    if (ph[q] > t.cap_chunks) { ph[q] = t.cap_chunks + 1u; atomicOr(a.err, 512u); }
                     __hip_atomic_store(mp + v0 + q, ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (off0 != 0) {
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine2_kernel(CombineArgs a)
                 for (int q = 0; q < XS_SPAN; ++q) {
                     if ((u32)q >= nv || (q == 0 && off0 != 0)) continue;
                     ph[q] = __hip_atomic_fetch_add(&t.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    if (ph[q] > t.cap_chunks) { ph[q] = t.cap_chunks + 1u; atomicOr(a.err, 512u); }
                     __hip_atomic_store(mp + v0 + q, ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (off0 != 0) {

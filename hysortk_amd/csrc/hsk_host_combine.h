@@ -182,9 +182,10 @@ static int build_items_batch(hsk_ctx *c, u32 ntasks, const u32 *tk, const Expand
 // The batch's tasks (tk[i]: task of XCD i, ~0u: none) from bucket-ordered records to {k-mer, count} pairs in the chunk stores bt[i].kB
 // (keys) / bt[i].vB (counts); the histogram of the second pass's digit goes to ghist[i] + 256.  What follows is sort_batch_prescattered
 // with the counts as payload; sb.h_nout[i] then holds the pairs of task i (read after the stream has passed chunk_tiles_kernel).
+// pair_cap: records the chunk stores bt[i].kB / vB hold (scatter_store_keys(pair_cap) + one chunk that takes what does not fit)
 template <int NW>
 static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *const *ghist, const PassDesc *plan, const BucketOrder &bo,
-                         u64 *h_nout, ScatterBatch &sb, hipStream_t stream)
+                         u64 *h_nout, ScatterBatch &sb, hipStream_t stream, u64 pair_cap)
 {
     static_assert(NW == 1 || NW == 2, "keys of one or two words");
     constexpr int CH = XsCfg<NW>::CHUNK;
@@ -221,6 +222,7 @@ static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *co
         t.n = ~0ULL; t.n_out = sb.d_nout + i; t.gbase = sb.d_gbase + (size_t)i * 256; t.ntiles_out = sb.d_ntiles + i;
         CombineTask &q = ca.t[i];
         q.recs = bo.recs + bo.out_base[tid]; q.boff = bo.off + (size_t)tid * bo.stride; q.nb = 1u << bo.log2nb[tid]; q.vmax = t.vmax;
+        q.cap_chunks = (u32)(scatter_store_keys(pair_cap, CH) / CH);
         q.chunks = t.chunks; q.vchunks = t.vchunks; q.cursor = t.cursor; q.map = t.map; q.ctl = t.ctl; q.ghist = t.ghist;
         ntot += n;
     }
@@ -241,6 +243,7 @@ static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *co
     // the tile lists of the second pass and the pairs of every task (the host sizes the second pass and the finish from them)
     hipLaunchKernelGGL(chunk_tiles_kernel, dim3(XCD_BATCH), dim3(256), 0, stream, sb.args);
     HIPCHK(c, hipMemcpyAsync(sb.h_nout, sb.d_nout, XCD_BATCH * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipMemcpyAsync(sb.h_nout + XCD_BATCH, c->d_err, 4, hipMemcpyDeviceToHost, stream));      // (bit 512: the pair stores ran over)
     HIPCHK(c, hipGetLastError());
     sb.active = true; sb.tiles_done = true;
     return HSK_OK;

@@ -186,6 +186,7 @@ struct hsk_ctx {
     int combine_prefix_floor = 0;      // ... never below this again (set when a bin beat the last table with fewer bits)
     int combine_prefix = 0;            // key bits of the weighted finish's bins the next batch is planned with (0: the default; follows the pairs per task)
     bool combine_veto = false;         // this call's store turned out to be no use to the combining extraction (too few tasks for a batch ...): the call again, without it
+    bool pair_cap_full = false;        // this call's pair buffers ran over once: full size for the attempt that follows (dispatch_pipeline clears it with the call)
     PlanEstimate est;                  // this call's estimate (estimate_plan); est.valid decides instead of combine_off / agg_off / agg_first_cap
     double est_bias = 1.0;             // pairs per k-mer the combining extraction really produced / what the estimate promised, when a call had to leave the plan after all
     // a call that followed its estimate into the combining extraction and had to start again: estimates like this one are not believed again on this context

@@ -298,7 +298,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     TaskSegs empty_segs;
     std::vector<TaskOut> touts(ntasks);
     // several ranks, the supermers arrived with their minimizer bits: the owner builds the items, batch by batch (hsk_combine.h, 1b)
-    const bool fed_wanted = NW == 1 && feeder && feeder->with_sub && c->combine_now && !ext;
+    const bool fed_wanted = NW <= 2 && feeder && feeder->with_sub && c->combine_now && !ext;
     const bool forced = ((ex && ex->force_batch) || x_src.item != nullptr || fed_wanted) && batch_enabled;      // (item-mode store: every task goes through whole batches)
     // a caller's task count below eight (the reference's default for one rank is five): three to seven tasks of some size still
     // go faster as one padded batch (5/8 of the batch path's rate) than one by one on the single-task path (about 1/3 of it)
@@ -342,7 +342,7 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     bool fed_combine = false;
     if constexpr (NW <= 2) {
         combine = item_mode && xs && agg && !(NW == 1 ? c->agg_off : c->agg_off_wide) && !ext && !feeder && mine.size() % XCD_BATCH == 0;
-        fed_combine = fed_wanted && !item_mode && xs && agg && !c->agg_off && batch && mine.size() % XCD_BATCH == 0;
+        fed_combine = fed_wanted && !item_mode && xs && agg && !(NW == 1 ? c->agg_off : c->agg_off_wide) && batch && mine.size() % XCD_BATCH == 0;
         combine = combine || fed_combine;
     }
     if (item_mode && !combine) { c->combine_veto = true; return retry_plan("an item-mode store, but no batch to combine (xs / agg / batch)", (xs ? 1u : 0u) | (agg ? 2u : 0u) | (batch ? 4u : 0u) | ((mine.size() % XCD_BATCH == 0) ? 8u : 0u)); }
@@ -355,12 +355,21 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
     u64 **kA = kAs[0], **kB = kBs[0], **vA = vAs[0], **vB = vBs[0];          // slot 0: also the single-task path
     SortScratch sc;
     u64 *d_ghist_slot[2] = {nullptr, nullptr};
+    // The combining extraction's buffers hold {k-mer, count} PAIRS, not k-mers: with the call's own estimate of the input (estimate_plan: distinct k-mers
+    // per k-mer) they are sized for four times the pairs it promises (+ 2 % of the k-mers) instead of one record per k-mer -- 20 GB instead of 102 at
+    // 10 Gbp, and device memory is what a process's FIRST call pays for (~20-60 ms per GB mapped for the first time, tools/exp/malloc_cost.hip).  A call
+    // whose pairs do not fit after all (error bit 512: the last chunk takes what runs over) starts again with full-sized buffers.  Several ranks: full
+    // size (nobody starts again while peers wait).
+    u64 rec_cap = max_task;
+    if (combine && !fed_combine && c->est.valid && !c->pair_cap_full && tune("pair_cap", 1) != 0)
+        rec_cap = std::min<u64>(max_task, std::max<u64>((u64)((double)max_task * std::min(1.0, 4.0 * c->est.distinct_per_kmer * c->est_bias + 0.02)), 1ULL << 22));
+    if (tune("pair_cap_records", 0) > 0 && combine && !fed_combine) rec_cap = std::min<u64>(max_task, (u64)tune("pair_cap_records", 0));      // (tests: stores that run over)
     auto alloc_sort_buffers = [&]() -> int {
         if (max_task) {
             for (int sl = 0; sl < nslot; ++sl) for (int i = 0; i < nsets; ++i) {
-                DALLOC(c, kAs[sl][i], u64 *, max_task * NW * 8 + 64);
-                DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * NW * 8 + 64);   // xs: the chunk store of the first pass
-                if (ext || combine) { DALLOC(c, vAs[sl][i], u64 *, max_task * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(max_task, XS_CH) : max_task) * 8 + 64); }
+                DALLOC(c, kAs[sl][i], u64 *, rec_cap * NW * 8 + 64);
+                DALLOC(c, kBs[sl][i], u64 *, (xs ? scatter_store_keys(rec_cap, XS_CH) + XS_CH : rec_cap) * NW * 8 + 64);   // xs: the chunk store of the first pass (+ the chunk that takes what runs over)
+                if (ext || combine) { DALLOC(c, vAs[sl][i], u64 *, rec_cap * 8 + 64); DALLOC(c, vBs[sl][i], u64 *, (xs ? scatter_store_keys(rec_cap, XS_CH) + XS_CH : rec_cap) * 8 + 64); }
             }
             int rc = alloc_sort_scratch(c, sc); if (rc) return rc;
         }
@@ -547,9 +556,9 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
                     rc = build_items_batch(c, ntasks, tk, jobs, s16, gsegs, gsrc, fed_items[sl], c->stream); if (rc) return rc;
                     rc = bucket_order_tasks(c, ntasks, gsegs, std::vector<u32>(tk, tk + XCD_BATCH), gsrc, FED_VT_SHIFT, border_fed[sl]); if (rc) return rc;
                     if (!border_fed[sl].active) return fail(c, HSK_ERR_UNSUPPORTED, "a task of 2^32 supermers and more");
-                    rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border_fed[sl], h_nout, sbatch[sl], c->stream); if (rc) return rc;
+                    rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border_fed[sl], h_nout, sbatch[sl], c->stream, rec_cap); if (rc) return rc;
                     fed_release(c, fed_items[sl]); bucket_release(c, border_fed[sl]);      // (stream-ordered reuse: their readers are enqueued)
-                } else { rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream); if (rc) return rc; }
+                } else { rc = combine_batch<NW>(c, tk, bts[sl], gh, plan, border, h_nout, sbatch[sl], c->stream, rec_cap); if (rc) return rc; }
                 slot_combine[sl] = sbatch[sl].active;
             }
         } else
@@ -616,6 +625,12 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
             c->stats.host_syncs++;
             HIPCHK(c, hsk_sync(c, c->stream));
             const u64 *h_nout = (const u64 *)((char *)c->pinned + c->pinned_bytes - 2048 + (size_t)sl * 128);
+            if ((u32)h_nout[XCD_BATCH] & 512u) {                   // the pair stores ran over (they were sized from the estimate): once more, sized for the k-mers
+                (void)hipMemsetAsync(c->d_err, 0, 4, c->stream);
+                if (fed_combine) return fail(c, HSK_ERR_INTERNAL, "pair stores overrun with several ranks");
+                c->pair_cap_full = true;
+                return retry_plan("the pair stores ran over (sized from the estimate)");
+            }
             u64 bp = 0, bk = 0, pmax = 0;
             for (int i = 0; i < XCD_BATCH; ++i) { if (mine[pos + i] == EMPTY_TASK || !bt[i].n) continue; bk += bt[i].n; bt[i].n = h_nout[i]; bp += h_nout[i]; pmax = std::max<u64>(pmax, h_nout[i]); }
             c->combine_prefix = std::max(c->combine_prefix_floor, combine_prefix_for(pmax));      // (the batches and calls after this one)
@@ -860,7 +875,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // needs the grouped exchange and the byte-store placement, and every rank's consent (below)
     // (two-word keys: 40 <= K <= 55 -- the prefix bits sit in the most significant word, an item of 64 bases holds six k-mers and more: shorter
     //  items would be more records per tile than the parse keeps, for 16 bytes that stand for very few k-mers)
-    c->combine_now = (NW == 1 || (NW == 2 && K >= 40 && K <= 55 && nranks == 1)) && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !(NW == 1 ? c->agg_off : c->agg_off_wide) && combine_enabled() && parse_fast_enabled() &&
+    c->combine_now = (NW == 1 || (NW == 2 && K >= 40 && K <= 55)) && !ext && combine_pays && !c->combine_veto && c->plan_attempt < 2 && !(NW == 1 ? c->agg_off : c->agg_off_wide) && combine_enabled() && parse_fast_enabled() &&
                      c->cfg.minimizer_size <= SCAN_MAX_M && packed_bytes >= combine_min && c->xcd_batch_ok &&
                      (nranks == 1 || (overlap_enabled() && place_bytes_enabled(true)));
     c->combine_veto = false;
@@ -1132,12 +1147,12 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
     // the plan, as run_pipeline chooses it with several ranks: the sketch of a rank's reads (here: of the first virtual rank that has some)
     c->combine_now = false; c->item_mode_now = false; c->vt_shift = 0; c->combine_left_now = false;
-    if (NW == 1 && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
+    if ((NW == 1 || (NW == 2 && c->cfg.kmer_size >= 40 && c->cfg.kmer_size <= 55)) && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
         const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
         int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;
         int erc = estimate_plan(c, in[r0].packed, packed_bytes[r0], in[r0].roff, in[r0].rlen, nreads[r0]); if (erc) return erc;
         const bool pays = c->est.valid ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off;
-        c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !c->agg_off;
+        c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !(NW == 1 ? c->agg_off : c->agg_off_wide);
     }
     struct PlanReset { hsk_ctx *c; ~PlanReset() { c->combine_now = false; c->est.valid = false; } } plan_reset{c};
     // 1. hash every rank's reads once (parse_count), sum the task sizes, dispatch

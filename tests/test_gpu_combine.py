@@ -69,7 +69,7 @@ def test_input_without_copies_leaves_the_combining_extraction():
 @pytest.mark.parametrize("env,spec,why", [
     ({"HSK_XCD_BATCH": "0"}, dict(), "the one-task-per-XCD kernels are switched off: no batch to run the combining extraction on; the call starts again without it"),
     ({"HSK_PARSE_REC_CAP": "200"}, dict(), "tiles beyond the record capacity: the parse leaves its fast path, and the virtual tasks with it"),
-    ({"HSK_SCAN_PLACE": "1", "HSK_BIN_CAP_PCT": "20"}, dict(), "items placed by the scan, and their chunk store runs out (sized at a fifth of the expected supermers): error bit, the call again on the instance path"),
+    ({"HSK_SCAN_PLACE": "1", "HSK_BIN_CAP_PCT": "1"}, dict(genome=6000000, nreads=1500000), "items placed by the scan, and their chunk store runs out (a first chunk per bin and next to nothing beyond): error bit, the call again on the instance path"),
     ({"HSK_SCAN_PLACE": "1", "HSK_BIN_VMAX": "1"}, dict(genome=6000000, nreads=1500000), "items placed by the scan, a bin of more chunks than its map has entries"),
 ])
 def test_calls_that_start_again_without_the_combining_extraction(env, spec, why):
@@ -179,10 +179,14 @@ def test_alternating_inputs_on_one_context_choose_per_call():
     (4, 64, {}, "four ranks, two task groups each: the grouped exchange feeds the batches"),
     (8, 72, {}, "eight ranks, nine tasks each: a partial batch padded"),
     (3, 24, {"HSK_COMBINE_BUCKET": "300"}, "three ranks, nearly empty tables"),
+    (4, 64, {"K": 51}, "two-word keys (configs[3]'s shape) on four ranks: items of ten k-mers built by the owners, combine2_kernel"),
     (2, 2, {"HSK_COMBINE_PREFIX": "9"}, "one task per rank in 512 bins of ~6000 pairs: bins beyond the weighted finish's last table; those tasks take the weighted long way (full-width passes over the pairs + sums of equal keys), nobody starts again"),
 ])
 def test_owner_side_combining_extraction_equals_instance_path(R, ntasks, env, why):
     sp = dict(BASE, ntasks=ntasks, genome=2000000, nreads=480000, L=1, U=65535, calls=["loopback:%d" % R])
+    env = dict(env)
+    if "K" in env:
+        sp["K"] = env.pop("K")
     if ntasks == 2:
         sp.update(genome=8000000, nreads=800000)
     ref = run(sp, {"HSK_COMBINE": "0"})[0]
@@ -235,3 +239,13 @@ def test_two_word_combining_extraction_vs_oracle(tmp_path):
         z = np.load(dump)
         want = O.count(z["packed"], z["off"], z["lens"], k=K, m=M, L=1, U=65535, ntasks=nt, fast=True)
         assert np.array_equal(want.task_off, z["task_off"]) and np.array_equal(want.keys, z["kmers"]) and np.array_equal(want.cnt, z["cnt"]), (K, M, nt)
+
+
+def test_pair_stores_that_run_over_are_enlarged_not_abandoned():
+    """The combining extraction's buffers are sized for the pairs the call's sketch promises (four times over), not for the k-mers.  Stores that
+    run over after all (here: forced to 100 000 records per task) set an error bit -- the chunk behind the store takes the overrun -- and the call
+    runs once more with full-sized buffers: still the combining extraction, same list."""
+    ref = run(BASE, {"HSK_COMBINE": "0"})[0]
+    r = run(BASE, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_PAIR_CAP_RECORDS": "100000"})[0]
+    assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
+    assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
