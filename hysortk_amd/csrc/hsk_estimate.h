@@ -16,7 +16,7 @@
 
 namespace hsk {
 
-constexpr int EST_SPAN = 256;                      // base positions per lane
+constexpr int EST_SPAN = 64;                       // base positions per lane (+ K - 1 of warm-up: short spans, many lanes -- the kernel is bound by the latency of its byte loads)
 constexpr int EST_THREADS = 256;
 constexpr u32 EST_SELECT_BITS = 5;                 // 1 / 32 of the k-mer space
 constexpr int EST_MAX_PROBES = 256;
@@ -38,8 +38,8 @@ __device__ __forceinline__ u64 est_find_read(const u64 *roff, u64 nreads, u64 by
 
 __device__ __forceinline__ u32 est_insert(const EstimateArgs &a, u64 key)      // key: the k-mer itself (K <= 32) or a 64-bit fingerprint of it; 1: no slot found
 {
+    if ((key * 0x9e3779b97f4a7c15ULL) >> (64 - EST_SELECT_BITS)) return 0;      // not in the slice (one multiply for 31 of 32 k-mers; the full mix only for the chosen)
     const u64 h = fmix64(key + 0x9e3779b97f4a7c15ULL);
-    if (h >> (64 - EST_SELECT_BITS)) return 0;                           // not in the slice
     u64 slot = (h >> 8) & a.cap_mask;
     const unsigned long long want = key + 1ULL;
     for (int probes = 0; probes < EST_MAX_PROBES; ++probes) {
