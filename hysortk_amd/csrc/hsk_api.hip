@@ -240,7 +240,7 @@ extern "C" int hsk_get_stats(hsk_ctx *c, hsk_stats *out, int reset)
 // deep data, is unaffected.  Cost: two small kernels and one wait.  tuning "plan_sample=0" turns the estimate off (the context's memory of
 // earlier calls decides, as in rounds 2-3).
 // ------------------------------------------------------------------------------------------------
-static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads)
+static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads, int nranks)
 {
     c->est = PlanEstimate();
     const bool enabled = tune("plan_sample", 1) != 0;
@@ -283,7 +283,9 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     }
     if (lost || ns < (1u << 14)) return HSK_OK;                            // (no estimate)
     PlanEstimate &e = c->est;
-    e.fraction = (double)s_bytes / (double)packed_bytes; e.sample_kmers = ns; e.n1 = n1; e.n2 = n2; e.n3 = n3; e.distinct_sample = ds;
+    // several ranks: the reads are dealt to the ranks, so this rank's sample is that much thinner a slice of the WHOLE input's depth (a rank of eight
+    // that holds 4-fold coverage of its own counts 32-fold k-mers after the exchange)
+    e.fraction = (double)s_bytes / ((double)packed_bytes * (double)std::max(nranks, 1)); e.sample_kmers = ns; e.n1 = n1; e.n2 = n2; e.n3 = n3; e.distinct_sample = ds;
     double G = 0, lam = 0, Es = (double)n1;
     if (n2 >= 64 && n3 >= 16 && (double)n2 * 2000.0 > (double)n1) {       // (a genomic component exists: more than one doubleton per 2000 singletons)
         lam = std::min(30.0, std::max(1e-3, 3.0 * (double)n3 / (double)n2));
@@ -310,7 +312,7 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
 {
     int rc;
     if (attempt == 0) { c->combine_left_now = false; c->pair_cap_full = false; }
-    if (attempt == 0) { rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads); if (rc) return rc; }
+    if (attempt == 0) { rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, c->comm.active() ? c->comm.nranks : 1); if (rc) return rc; }
     c->plan_attempt = attempt;                          // (from the third attempt on run_pipeline does not consider the combining extraction at all)
     const std::vector<void *> before = c->pool.snapshot();
     const hsk_stats stats_before = c->stats;

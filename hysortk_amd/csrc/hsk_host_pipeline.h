@@ -10,7 +10,7 @@
 // (src/kmerops.cpp:130-196, exchange_supermer's stage loop); here the unit is a task group so that a
 // sort batch never waits for bytes it does not need.  HSK_OVERLAP=0 selects one exchange up front.
 // ------------------------------------------------------------------------------------------------
-static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads);      // hsk_api.hip
+static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads, int nranks);      // hsk_api.hip
 
 struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; const unsigned short *sub16 = nullptr; };
 
@@ -1150,7 +1150,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     if ((NW == 1 || (NW == 2 && c->cfg.kmer_size >= 40 && c->cfg.kmer_size <= 55)) && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
         const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
         int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;
-        int erc = estimate_plan(c, in[r0].packed, packed_bytes[r0], in[r0].roff, in[r0].rlen, nreads[r0]); if (erc) return erc;
+        int erc = estimate_plan(c, in[r0].packed, packed_bytes[r0], in[r0].roff, in[r0].rlen, nreads[r0], R); if (erc) return erc;
         const bool pays = c->est.valid ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off;
         c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !(NW == 1 ? c->agg_off : c->agg_off_wide);
     }
