@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (N = 1)")
     ap.add_argument("--no-variants", action="store_true", help="skip the legs of the other record shapes and plans (N = 1)")
+    ap.add_argument("--legs", default="", help="comma-separated: run only these of the informational legs (variant names, multi_rank, first_calls); default all")
     ap.add_argument("--error-rate", type=float, default=0.0, help="substitution errors per base in the synthetic reads (informational runs; the headline workload is error-free)")
     ap.add_argument("--ext", type=int, default=0)
     ap.add_argument("--k", type=int, default=31, help="k-mer size (informational runs; the headline metric is K=31)")
@@ -605,6 +606,7 @@ def main():
                 out["host_to_host"] = e2e_host_leg(H, KK, a.ext, a.ntasks, local, genome_len, nreads, seed, max(a.steps, 3))
             except Exception as e:
                 out["host_to_host"] = {"error": str(e)[:300]}
+        only = set(x for x in a.legs.split(",") if x)
         if world == 1 and not a.no_variants:
             G = int(GENOME_PER_GPU * a.scale)
             legs = [
@@ -622,18 +624,20 @@ def main():
             ]
             out["variants"] = []
             for (name, note, vk, vext, plan, Lv, Uv, vg, vn, er, refb) in legs:
+                if only and name not in only:
+                    continue
                 try:
                     out["variants"].append(run_variant(H, local, name, note, vk, vext, plan, Lv, Uv, vg, vn, seed, er, 3, refb))
                 except Exception as e:
                     out["variants"].append({"name": name, "error": str(e)[:300]})
-        if world == 1 and not a.no_variants:
+        if world == 1 and not a.no_variants and (not only or "multi_rank" in only):
             out["multi_rank_path"] = []
             for (mname, mk, mext, mbp) in (("k31_8x5Gbp", 31, 0, 5_000_000_000), ("k51_8x2.5Gbp", 51, 0, 2_500_000_000), ("ext_8x1.25Gbp", 31, 1, 1_250_000_000)):
                 try:
                     out["multi_rank_path"].append(multi_rank_leg(H, local, mname, mk, mext, 8, int(mbp * a.scale), 320, seed + 7))
                 except Exception as e:
                     out["multi_rank_path"].append({"name": mname, "error": str(e)[:300]})
-        if world == 1 and not a.no_variants:
+        if world == 1 and not a.no_variants and (not only or "first_calls" in only):
             try:
                 out["first_calls"] = first_call_leg(H, local, int(GENOME_PER_GPU * a.scale) // 2, nreads // 2, seed + 100)
             except Exception as e:

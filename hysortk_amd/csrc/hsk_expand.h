@@ -44,30 +44,27 @@ struct ExpandPrepArgs {
     u64 ntiles[EXP_PREP_BATCH]; u64 *tile_sum[EXP_PREP_BATCH]; u64 *tile_off[EXP_PREP_BATCH]; int k;
 };
 
-// tile_sum[tile] = {bytes, kmers}
+// tile_sum[tile] = {bytes, kmers}; a wave per tile, a lane eight consecutive lengths (one 8-byte load: a lane per length left the kernel waiting
+// for 64-byte requests, 0.26 ms per 100 M supermers)
+constexpr int EXP_SUM_TILES = EXP_THREADS / WAVE;      // tiles per workgroup
+static_assert(EXP_TILE == 8 * WAVE, "eight supermers per lane");
 __global__ __launch_bounds__(EXP_THREADS) void expand_tilesum_kernel(ExpandPrepArgs a)
 {
-    __shared__ u64 s_red[2 * 4];
     const int ti = blockIdx.y;
-    const u64 tile = blockIdx.x;
+    const u64 tile = (u64)blockIdx.x * EXP_SUM_TILES + (threadIdx.x >> 6);
     if (tile >= a.ntiles[ti]) return;
     const ExpSeg *segs = a.segs[ti]; const u8 *sm_len = a.sm_len[ti];
-    const int sg = seg_of_tile(segs, a.nseg[ti], tile);
-    const ExpSeg seg = segs[sg];
-    const u64 first = (tile - seg.tile_start) * EXP_TILE;
-    u64 nb = 0, nk = 0;
-    for (int i = 0; i < EXP_SPT; ++i) {
-        u64 s = first + (u64)i * EXP_THREADS + threadIdx.x;
-        if (s < seg.n_sup) { u32 len = sm_len[seg.sup_off + s]; nb += (len + 3) >> 2; nk += len - a.k + 1; }
+    const ExpSeg seg = segs[seg_of_tile(segs, a.nseg[ti], tile)];
+    const u64 first = (tile - seg.tile_start) * EXP_TILE + 8u * (u32)lane_id();
+    u32 nb = 0, nk = 0;
+    if (first < seg.n_sup) {
+        const u32 n_ok = seg.n_sup - first < 8 ? (u32)(seg.n_sup - first) : 8u;
+        const u64 l8 = *reinterpret_cast<const u64 *>(sm_len + seg.sup_off + first);      // (unaligned; behind the segment's last length: padding or the next segment)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if ((u32)j < n_ok) { const u32 len = (u32)(l8 >> (8 * j)) & 255u; nb += (len + 3) >> 2; nk += len - (u32)a.k + 1u; }
     }
     for (int o = 32; o > 0; o >>= 1) { nb += __shfl_down(nb, o, WAVE); nk += __shfl_down(nk, o, WAVE); }
-    if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = nb; s_red[2 * (threadIdx.x >> 6) + 1] = nk; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 b = 0, kk = 0;
-        for (int w = 0; w < 4; ++w) { b += s_red[2 * w]; kk += s_red[2 * w + 1]; }
-        a.tile_sum[ti][2 * tile] = b; a.tile_sum[ti][2 * tile + 1] = kk;
-    }
+    if (lane_id() == 0) { a.tile_sum[ti][2 * tile] = nb; a.tile_sum[ti][2 * tile + 1] = nk; }
 }
 
 // one block per (segment, task): tile_off[tile] = {absolute byte offset, k-mer offset relative to task};

@@ -156,11 +156,11 @@ static int build_items_batch(hsk_ctx *c, u32 ntasks, const u32 *tk, const Expand
         t.tile_off = f.x[j].d_tile_off; t.ntiles = jb.ts->ntiles;
     }
     a.vt_cnt = f.vt_cnt; a.vt_cur = f.vt_cur; a.items = f.items; a.subs = f.subs; a.k = c->cfg.kmer_size; a.err = c->d_err;
-    hipLaunchKernelGGL(vt_hist_kernel, dim3((u32)max_tiles, m), dim3(EXP_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(vt_hist_kernel, dim3((u32)std::min<u64>((max_tiles + 3) / 4, 1024), m), dim3(EXP_THREADS), 0, stream, a);
     hipLaunchKernelGGL(vt_scan_kernel, dim3(1), dim3(128), 0, stream, a);
     u32 *h_cnt = (u32 *)((char *)c->pinned + (320u << 10));
     HIPCHK(c, hipMemcpyAsync(h_cnt, f.vt_cnt, 128 * 4, hipMemcpyDeviceToHost, stream));
-    hipLaunchKernelGGL(items_build_kernel, dim3((u32)max_tiles, m), dim3(EXP_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(items_build_kernel, dim3((u32)((max_tiles + IB_TILES - 1) / IB_TILES), m), dim3(EXP_THREADS), 0, stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hsk_sync(c, stream));
     u64 run = 0;

@@ -35,7 +35,7 @@ static int expand_prepare_batch(hsk_ctx *c, int n, const TaskSegs *const *ts, co
         max_tiles = std::max(max_tiles, ts[i]->ntiles); max_seg = std::max(max_seg, nseg);
     }
     if (max_tiles == 0 || !offsets) return HSK_OK;
-    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)max_tiles, n), dim3(EXP_THREADS), 0, stream, pa);
+    hipLaunchKernelGGL(expand_tilesum_kernel, dim3((u32)((max_tiles + EXP_SUM_TILES - 1) / EXP_SUM_TILES), n), dim3(EXP_THREADS), 0, stream, pa);
     hipLaunchKernelGGL(expand_scan_kernel, dim3(max_seg, n), dim3(EXP_THREADS), 0, stream, pa);
     return HSK_OK;
 }
@@ -125,7 +125,7 @@ static int expand_task(hsk_ctx *c, const TaskSegs &ts, const u8 *sm_len, const B
 // travels (pack_group, on the communication stream, overlapped with the sort of the previous group)
 static int pack_store_bytes(hsk_ctx *c, SupermerStore &st, const BaseSource &src, bool run_kernel = true)
 {
-    if (st.sm_boff) { st.base = src; st.group_packed.assign(4096, 1); return HSK_OK; }      // byte-store mode: the placement already wrote them
+    if (st.bytes_done) { st.base = src; st.group_packed.assign(4096, 1); return HSK_OK; }      // byte-store mode: the placement already wrote them
     DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 64);
     st.base = src;
     if (st.tot_sup == 0 || !run_kernel) return HSK_OK;

@@ -31,6 +31,7 @@ struct SupermerStore {
     u8 *sm_len = nullptr; u8 *sm_bytes = nullptr; u64 *sm_gpos = nullptr; u32 *sm_pos = nullptr; int32_t *sm_rid = nullptr;
     u32 *sm_boff = nullptr;       // byte-store mode (place_bytes_kernel): sm_bytes is complete, sm_boff[slot] = offset inside the task's byte run
     void *d_bitems = nullptr; u32 n_bitems = 0; void *bin_aux[4] = {nullptr, nullptr, nullptr, nullptr};      // scan-placed bins: work list + cursor / map / control / chunk owners (released with the store)
+    bool bytes_done = false;      // place_bytes_kernel has written sm_bytes (supermers that travel: without sm_boff -- the receiver scans the lengths anyway)
     unsigned short *sm_sub16 = nullptr;   // several ranks, combining extraction on the owner's side: the top 16 minimizer bits of every supermer (they travel with sm_len)
     u32 *sm_sub = nullptr;        // combining extraction (hsk_combine.h): 32 mixed bits of the supermer's minimizer hash ...
     u64 *sm_item = nullptr;       // ... and the supermer itself (place_items_kernel); sm_len / sm_gpos do not exist in this mode
@@ -406,7 +407,8 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     if (with_sub16) { DALLOC(c, st.sm_sub16, unsigned short *, st.tot_sup * 2 + 64); a.sm_sub16 = st.sm_sub16; }
     if (bytes_mode) {
         DALLOC(c, st.sm_bytes, u8 *, st.tot_bytes + 256);
-        DALLOC(c, st.sm_boff, u32 *, st.tot_sup * 4 + 64);
+        if (!supermers_travel) DALLOC(c, st.sm_boff, u32 *, st.tot_sup * 4 + 64);
+        st.bytes_done = true;
         HIPCHK(c, hipMemsetAsync(st.sm_bytes + st.tot_bytes, 0, 256, c->stream));     // the extraction's windows read a few words past the last supermer
     }
     if ((!bytes_mode && !item_mode) || ext) DALLOC(c, st.sm_gpos, u64 *, st.tot_sup * 8 + 64);      // position mode: bases stay in the packed reads
@@ -427,7 +429,10 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
             if (bytes_mode) {
                 ParseArgs ab = a;
                 ab.place_group = std::max<u32>(1, std::min<u32>(PLACE_BYTES_TILES, PLACE_BYTES_REC / a.rec_cap));
-                hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4 + (ab.sm_sub16 ? PLACE_BYTES_REC * 2 : 0), c->stream, ab);
+                const size_t lds = (size_t)ntasks * 40 + PLACE_BYTES_REC * 8 + PLACE_BYTES_WORDS * 4 + (ab.sm_sub16 ? PLACE_BYTES_REC * 2 : 0);
+                static bool announced = false;
+                if (!announced) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(place_bytes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); announced = true; }
+                hipLaunchKernelGGL(place_bytes_kernel, dim3(j.nblocks), dim3(PLACE_BYTES_THREADS), lds, c->stream, ab);
             } else if (item_mode) {
                 ParseArgs ai = a;
                 ai.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));

@@ -1098,13 +1098,17 @@ __global__ __launch_bounds__(PLACE_ITEM_THREADS) void place_items_kernel(ParseAr
 // task, so a wave instruction covers one contiguous stretch.  gfx950 global stores need no alignment (the kernel-mode
 // driver runs every queue in unaligned-access mode); a word that straddles a cache line is split by the hardware.
 // dynamic LDS: u64 cur[nt], u64 curb[nt], u64 tbase[nt], u64 tc[nt], u32 tpre[nt], u32 pad[nt], u64 srt[PLACE_BYTES_REC], u32 words[...]
-constexpr u32 PLACE_BYTES_REC = 4096;                  // records of one step (rec_cap * place_group)
-constexpr u32 PLACE_BYTES_TILES = 8;                   // tiles per step at most
+// A step takes 8192 records (1024 threads, 16 tiles): with the 320 tasks of eight ranks a (step, task) run is ~25 supermers = 250 bytes (4096 records:
+// half that; measured in DESIGN.md 3.2f).
+constexpr int PLACE_BYTES_THREADS = 1024;
+constexpr u32 PLACE_BYTES_REC = 8192;                  // records of one step (rec_cap * place_group)
+constexpr u32 PLACE_BYTES_TILES = 16;                  // tiles per step at most (a record's tile: 4 bits)
 constexpr u32 PLACE_BYTES_WORDS = PLACE_BYTES_TILES * (PARSE_TILE / 16) + 24;   // their packed words + the overhang of the last supermer (<= 222 bases) + overread
-__global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
+__global__ __launch_bounds__(PLACE_BYTES_THREADS) void place_bytes_kernel(ParseArgs a)
 {
+    constexpr int PARSE_THREADS = PLACE_BYTES_THREADS;      // (this kernel's own width)
     constexpr int RPT = PLACE_BYTES_REC / PARSE_THREADS;
-    __shared__ u32 s_scan[12];
+    __shared__ u32 s_w[16];
     __shared__ u32 s_go[PLACE_BYTES_TILES + 4];
     extern __shared__ __attribute__((aligned(16))) u64 s_cur[];
     const int tid = threadIdx.x;
@@ -1132,10 +1136,13 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
         u32 ng = a.tiles_per_block - t0; if (ng > G) ng = G;
         if (tfirst + ng > tile_end) ng = (u32)(tile_end - tfirst);
         __syncthreads();                                                // previous step done with s_go / s_tc / s_srt / s_words
-        if (tid == 0) {
-            u32 run = 0;
-            for (u32 j = 0; j < ng; ++j) { s_go[j] = run; u32 n = a.tile_nrec[tfirst + j]; run += n < a.rec_cap ? n : a.rec_cap; }
-            for (u32 j = ng; j <= PLACE_BYTES_TILES; ++j) s_go[j] = run;
+        if (tid < WAVE) {                                               // record offsets of the step's tiles (one wave)
+            u32 n = 0;
+            if ((u32)tid < ng) { n = a.tile_nrec[tfirst + tid]; n = n < a.rec_cap ? n : a.rec_cap; }
+            const u32 inc = wave_incl_scan(n);
+            if ((u32)tid < ng) s_go[tid] = inc - n;
+            const u32 tot = __shfl(inc, WAVE - 1);
+            if ((u32)tid >= ng && (u32)tid <= PLACE_BYTES_TILES) s_go[tid] = tot;
         }
         for (u32 t = tid; t < nt; t += PARSE_THREADS) s_tc[t] = 0;
         {   // the packed words of the step's tiles (+ overhang) as big-endian words
@@ -1157,8 +1164,8 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
             const u32 i = x * PARSE_THREADS + tid;
             rec[x] = 0xFFFFFFFFu; got[x] = 0; sb16[x] = 0;
             if (i < total) {
-                u32 j = 0;
-                while (j + 1 < ng && s_go[j + 1] <= i) ++j;
+                u32 j = 0, hi = ng;                                     // the tile of record i: last j with s_go[j] <= i
+                while (hi - j > 1) { const u32 mid = (j + hi) >> 1; if (s_go[mid] <= i) j = mid; else hi = mid; }
                 const u32 r = a.tile_rec[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])];
                 if (a.sm_sub16) sb16[x] = (unsigned short)(a.tile_sub[(tfirst + j) * (u64)a.rec_cap + (i - s_go[j])] >> 16);
                 rec[x] = r | (j << 28);
@@ -1167,13 +1174,14 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
             }
         }
         __syncthreads();
-        {   // exclusive prefix of the per-task record counts
-            u32 c4[4], sum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; c4[j] = t < nt ? (u32)(s_tc[t] >> 32) : 0; sum += c4[j]; }
-            u32 e = block_excl_scan_256<u32>(sum, s_scan, nullptr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const u32 t = tid * 4 + j; if (t < nt) s_tpre[t] = e; e += c4[j]; }
+        {   // exclusive prefix of the per-task record counts (one lane per task)
+            const u32 cnt = (u32)tid < nt ? (u32)(s_tc[tid] >> 32) : 0u;
+            const u32 inc = wave_incl_scan(cnt);
+            if (lane_id() == WAVE - 1) s_w[tid >> 6] = inc;
+            __syncthreads();
+            u32 base = 0;
+            for (int i = 0; i < 16; ++i) if (i < (tid >> 6)) base += s_w[i];
+            if ((u32)tid < nt) s_tpre[tid] = base + inc - cnt;
         }
         __syncthreads();
 #pragma unroll
@@ -1194,7 +1202,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void place_bytes_kernel(ParseArgs a)
             const u32 len = ((r >> 11) & 127u) + (u32)K;
             const u32 nb = (len + 3) >> 2;
             a.sm_len[slot] = (u8)len;
-            a.sm_boff[slot] = (u32)(babs - s_tbase[d]);
+            if (a.sm_boff) a.sm_boff[slot] = (u32)(babs - s_tbase[d]);
             if (a.sm_sub16) a.sm_sub16[slot] = s_sub[i];
             if (a.sm_gpos) a.sm_gpos[slot] = (tfirst + (r >> 28)) * PARSE_TILE + (u64)(r & 2047);
             const u32 bit0 = 2u * ((r >> 28) * (u32)PARSE_TILE + (r & 2047u));
