@@ -441,7 +441,7 @@ __device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base
     const u32 one = inc;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
-        "s_movk_i32 %[p], %[maxp]\n\t"
+        "s_movk_i32 %[p], 1\n\t"
         "s_mov_b64 exec, %[act]\n"
         "0:\n\t"
         "v_lshl_add_u32 %[ka1], %[h], 3, %[k1b]\n\t"
@@ -483,17 +483,17 @@ __device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base
         "s_cbranch_scc0 2f\n\t"
         "s_mov_b64 exec, %[act]\n"
         "4:\n\t"
-        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_add_u32 %[h], %[p], %[h]\n\t"                    // (triangular steps, as agg_count_keys)
         "v_and_b32 %[h], %[mask], %[h]\n\t"
-        "s_sub_u32 %[p], %[p], 1\n\t"
-        "s_cmp_lg_u32 %[p], 0\n\t"
+        "s_add_u32 %[p], %[p], 1\n\t"
+        "s_cmp_lg_u32 %[p], %[maxp]\n\t"
         "s_cbranch_scc1 0b\n"
         "2:\n\t"
         "s_mov_b64 exec, %[save]"
         : [act] "+s"(act), [h] "+v"(h), [tmo] "+s"(tmo), [save] "=&s"(save), [p] "=&s"(p), [spin] "=&s"(spin),
           [cur] "=&v"(cur), [v] "=&v"(v), [ka1] "=&v"(ka1), [ka0] "=&v"(ka0), [ca] "=&v"(ca)
         : [k1b] "s"(k1_base), [k0b] "s"(k0_base), [cb] "s"(cnt_base), [w1] "v"(w1), [w0] "v"(w0), [emp] "v"(empty), [one] "v"(one),
-          [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE)
+          [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE + 1)
         : "vcc", "scc", "memory");
     timed_out |= tmo;
     return act;
@@ -620,7 +620,7 @@ __device__ __forceinline__ u64 agg3_count_keys(u64 act, u32 k2_base, u32 k1_base
     const u32 one = 1u;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
-        "s_movk_i32 %[p], %[maxp]\n\t"
+        "s_movk_i32 %[p], 1\n\t"
         "s_mov_b64 exec, %[act]\n"
         "0:\n\t"
         "v_lshl_add_u32 %[ka2], %[h], 3, %[k2b]\n\t"
@@ -669,17 +669,17 @@ __device__ __forceinline__ u64 agg3_count_keys(u64 act, u32 k2_base, u32 k1_base
         "s_cbranch_scc0 2f\n\t"
         "s_mov_b64 exec, %[act]\n"
         "4:\n\t"
-        "v_add_u32 %[h], 1, %[h]\n\t"
+        "v_add_u32 %[h], %[p], %[h]\n\t"                    // (triangular steps, as agg_count_keys)
         "v_and_b32 %[h], %[mask], %[h]\n\t"
-        "s_sub_u32 %[p], %[p], 1\n\t"
-        "s_cmp_lg_u32 %[p], 0\n\t"
+        "s_add_u32 %[p], %[p], 1\n\t"
+        "s_cmp_lg_u32 %[p], %[maxp]\n\t"
         "s_cbranch_scc1 0b\n"
         "2:\n\t"
         "s_mov_b64 exec, %[save]"
         : [act] "+s"(act), [h] "+v"(h), [tmo] "+s"(tmo), [save] "=&s"(save), [t] "=&s"(t), [p] "=&s"(p), [spin] "=&s"(spin),
           [cur] "=&v"(cur), [v1] "=&v"(v1), [v0] "=&v"(v0), [cv] "=&v"(cv), [ka2] "=&v"(ka2), [ka1] "=&v"(ka1), [ka0] "=&v"(ka0), [ca] "=&v"(ca)
         : [k2b] "s"(k2_base), [k1b] "s"(k1_base), [k0b] "s"(k0_base), [cb] "s"(cnt_base), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0),
-          [emp] "v"(empty), [one] "v"(one), [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE)
+          [emp] "v"(empty), [one] "v"(one), [mask] "n"(MASK), [maxp] "n"(AG_MAX_PROBE + 1)
         : "vcc", "scc", "memory");
     timed_out |= tmo;
     return act;

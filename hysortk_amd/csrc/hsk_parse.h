@@ -588,6 +588,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     __shared__ uint2 s_pend[BINS ? 2 * PARSE_THREADS : 1];                          // scan-placed items: {position | k-mers << 11 | virtual task << 16, minimizer bits} of the supermers whose slots are on their way
     __shared__ __attribute__((aligned(16))) u64 s_hash[8 * SCAN_HSTRIDE]; // hashes of the tile ([i][t] layout); later the minima of the supermer starts
     __shared__ u64 s_last[PARSE_THREADS];                                // window minimum of every lane's last position
+    __shared__ u64 s_bmin[PARSE_THREADS];                                // minimum of every lane's eight hashes (windows of 16 k-mers and more)
     __shared__ __attribute__((aligned(8))) u8 s_v8[PARSE_THREADS];       // valid mask of every lane's 8 positions
     __shared__ __attribute__((aligned(8))) u8 s_bnd8[PARSE_THREADS + 16]; // boundary mask: bit p = a supermer cannot continue across p
     __shared__ u16 s_plist[PARSE_TILE];                                  // positions of the supermer starts, ascending
@@ -716,6 +717,12 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
             }
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) s_hash[i * SCAN_HSTRIDE + tid] = h[i];
+            if (W >= 2 * PARSE_PPT) {                                  // wide windows: the minimum of every lane's eight positions (step 3 takes whole lanes from these)
+                u64 bm = h[0];
+#pragma unroll
+                for (int i = 1; i < PARSE_PPT; ++i) bm = h[i] < bm ? h[i] : bm;
+                s_bmin[tid] = bm;
+            }
             // the W-1 positions behind the tile (windows of the last k-mers): high lanes first
             for (int e = PARSE_THREADS - 1 - tid; e < W - 1; e += PARSE_THREADS) {
                 const int p = PARSE_TILE + e;
@@ -733,8 +740,15 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         u64 mn[PARSE_PPT];
         if (W >= PARSE_PPT) {
             u64 c = h[PARSE_PPT - 1];
+            // the shared middle [p0 + 8, p0 + W - 1]: whole lanes from their block minima (K = 51: 3 + 3 reads instead of 27), the rest position by position
+            const int nfull = (W - PARSE_PPT) / PARSE_PPT;
+            int j = PARSE_PPT;
+            if (nfull > 0 && tid + nfull < PARSE_THREADS) {
+                for (int b = 1; b <= nfull; ++b) { const u64 v = s_bmin[tid + b]; c = v < c ? v : c; }
+                j = PARSE_PPT * (nfull + 1);
+            }
 #pragma unroll 8
-            for (int j = PARSE_PPT; j <= W - 1; ++j) { const u64 v = s_hash[scan_hidx(p0 + j)]; c = v < c ? v : c; }
+            for (; j <= W - 1; ++j) { const u64 v = s_hash[scan_hidx(p0 + j)]; c = v < c ? v : c; }
             mn[PARSE_PPT - 1] = c;
             u64 suf = ~0ULL;
 #pragma unroll
