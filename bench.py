@@ -466,7 +466,8 @@ def main():
                 return {}
         pmc, mix = load_json("pmc.json"), load_json("valu_mix.json")
         try:
-            lib_sha = hashlib.sha256(open(os.path.join(ROOT, "hysortk_amd", "libhsk.so"), "rb").read()).hexdigest()[:16]
+            from hysortk_amd.build import source_sha16
+            lib_sha = source_sha16()                                      # (the sources the running library was built from)
         except Exception:
             lib_sha = None
         pmc_kmers = (pmc.get("workload") or {}).get("kmers_per_step")

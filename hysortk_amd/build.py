@@ -46,5 +46,16 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def source_sha16():
+    """sha256 over the kernel and host sources the library is built from (file names and contents, sorted): the identity of a BUILD that
+    profiles/pmc.json and bench.py agree on -- the binary's own hash depends on where and when the compiler ran"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(SRC_DIR)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode()); h.update(open(os.path.join(SRC_DIR, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

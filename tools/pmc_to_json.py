@@ -14,6 +14,8 @@ from collections import defaultdict
 root, out, steps = sys.argv[1], sys.argv[2], max(int(sys.argv[3]), 1)
 bench_line = sys.argv[4] if len(sys.argv) > 4 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hysortk_amd.build import source_sha16  # noqa: E402
 agg = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -38,7 +40,7 @@ for k in sorted(agg):
 lib = os.path.join(ROOT, "hysortk_amd", "libhsk.so")
 o = {"what": "rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-variants` (full BASELINE configs[1] workload), per step",
      "units": "FETCH_SIZE / WRITE_SIZE in KB; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of a streamed read)",
-     "build_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+     "build_sha16": source_sha16(), "build_sha16_is": "sha256 over hysortk_amd/csrc/*.h, *.hip (hysortk_amd/build.py source_sha16): the sources this run's library was built from",
      "steps_traced": steps, "path_hbm_bytes_per_step": path_bytes, "kernels": kern}
 if bench_line and os.path.exists(bench_line):
     try:
