@@ -515,8 +515,9 @@ def main():
         kernels = [
             kern("scan_kernel", st["scan_ms"], st["scan_launches"], st["scan_bytes"] + nsup * (20.0 if scan_places else 8.0 if item_mode else 4.0), "valu",
                  "minimizer hashes + supermer cuts: bound by VALU issue (MurmurHash3 of every m-mer: six 64-bit multiplies and the xor-shifts, then window minima and supermer cuts); "
-                 "algorithmic bytes = packed reads in + per supermer out: a 4-byte record (instance path), or -- combining extraction -- the 16-byte item + 4 bytes of minimizer bits, placed by the "
-                 "scan itself into (XCD, virtual task) chunk lists (round 4; round 3: 8 bytes of records and a placement kernel): its HBM fraction says nothing about it",
+                 "algorithmic bytes = packed reads in + per supermer out: a 4-byte record (instance path), 8 bytes of record + minimizer bits (combining extraction, the default: place_items_kernel "
+                 "makes the items), or the 16-byte item + 4 bytes of minimizer bits when the scan places them itself (tuning scan_place=1, measured break-even: DESIGN.md 3.2h)" +
+                 (" -- this run: the scan placed the items" if scan_places else "") + "; its HBM fraction says nothing about it",
                  pmc_prefix="scan_kernel", mix_key="scan_kernelILi%dELi17E" % KK if KK in (31, 51) else "scan_kernelILi31ELi17E"),
             kern("expand_scatter2_kernel" if KK <= 32 and not a.ext else "expand_scatter_kernel", st["hist_ms"], st["hist_launches"], st["hist_bytes"] * (1 + 1.1 / rec), "hbm",
                  "k-mer extraction fused with the first scatter pass: reads the supermers (1.1 B per k-mer), writes the keys into chunk-listed digit bins; "
