@@ -12,6 +12,8 @@
 // Errors: C-ABI status codes become std::runtime_error (the reference throws / aborts).
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <iterator>
@@ -21,6 +23,9 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <future>
+#include <functional>
 #include <vector>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -130,37 +135,77 @@ struct MappedFile {
 inline std::shared_ptr<DnaBuffer> read_dna_buffer(const std::string &fasta_fname, MPI_Comm comm)
 {
     const detail::Ranks r = detail::ranks_of(comm);
+    const bool timing = std::getenv("HSK_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hysortk shim] read_dna_buffer: %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<detail::FaiRecord> recs;
     {
-        // (the index of a read set has one line per read: parsed in place, not line by line through string streams -- 6.7 M lines took a second that way)
-        std::ifstream fai(fasta_fname + ".fai", std::ios::binary);
-        if (!fai) throw std::runtime_error("cannot open " + fasta_fname + ".fai");
-        std::string all((std::istreambuf_iterator<char>(fai)), std::istreambuf_iterator<char>());
-        const char *p = all.data(), *end = p + all.size();
-        auto number = [&](size_t &v) -> bool {
-            while (p < end && (*p == '\t' || *p == ' ')) ++p;
-            if (p >= end || *p < '0' || *p > '9') return false;
-            size_t x = 0; while (p < end && *p >= '0' && *p <= '9') x = x * 10 + (size_t)(*p++ - '0');
-            v = x; return true;
+        // The index of a read set has one line per read (6.7 M lines, 160 MB for 1 Gbp of short reads): read in one piece and parsed in place by a
+        // few threads, every thread the lines that START in its share of the bytes (stream iterators took 0.4 s for it, the whole device ingest 0.3)
+        const std::string fn = fasta_fname + ".fai";
+        size_t total = 0;
+        { std::ifstream probe(fn, std::ios::binary | std::ios::ate); if (!probe) throw std::runtime_error("cannot open " + fn); total = (size_t)probe.tellg(); }
+        std::unique_ptr<detail::MappedFile> map;
+        if (total) map.reset(new detail::MappedFile(fn, 0, total));
+        const char *base = total ? map->text() : nullptr;
+        // a line belongs to the thread whose share of the bytes it STARTS in; first the lines are counted, then every thread parses into its place
+        auto first_line = [base, total](size_t lo) -> const char * {
+            if (!lo) return base;
+            const char *nl = static_cast<const char *>(std::memchr(base + lo - 1, '\n', total - lo + 1));
+            return nl ? nl + 1 : base + total;
         };
-        while (p < end) {
-            const char *eol = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p))); if (!eol) eol = end;
-            const char *line_end = eol;
-            while (p < line_end && *p != '\t' && *p != ' ') ++p;                  // the name
-            detail::FaiRecord rec{}; const char *save_end = end; end = line_end;
-            if (number(rec.len) && number(rec.pos) && number(rec.bases)) { if (!number(rec.width)) rec.width = rec.bases + 1; recs.push_back(rec); }
-            end = save_end; p = eol < end ? eol + 1 : end;
+        auto parse_range = [base, total, &first_line](size_t lo, size_t hi, detail::FaiRecord *out) -> size_t {
+            const char *p = first_line(lo), *end = base + total, *stop = base + hi;
+            size_t n = 0;
+            while (p < stop) {
+                const char *eol = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p))); if (!eol) eol = end;
+                const char *q = p;
+                while (q < eol && *q != '\t' && *q != ' ') ++q;                  // the name
+                size_t v[4] = {0, 0, 0, 0}; int nv = 0;
+                while (nv < 4) {
+                    while (q < eol && (*q == '\t' || *q == ' ')) ++q;
+                    if (q >= eol || *q < '0' || *q > '9') break;
+                    size_t x = 0; while (q < eol && *q >= '0' && *q <= '9') x = x * 10 + (size_t)(*q++ - '0');
+                    v[nv++] = x;
+                }
+                if (nv >= 3) { if (out) out[n] = detail::FaiRecord{v[0], v[1], v[2], nv == 4 ? v[3] : v[2] + 1}; ++n; }
+                p = eol < end ? eol + 1 : end;
+            }
+            return n;
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nthr = total < (size_t(4) << 20) ? 1 : std::min<size_t>(hw ? hw : 4, 16);
+        std::vector<size_t> cnt(nthr + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<std::thread> th;
+            auto work = [&](size_t t) {
+                const size_t n = parse_range(total * t / nthr, total * (t + 1) / nthr, pass ? recs.data() + cnt[t] : nullptr);
+                if (!pass) cnt[t + 1] = n;
+            };
+            for (size_t t = 1; t < nthr; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            if (!pass) { for (size_t t = 0; t < nthr; ++t) cnt[t + 1] += cnt[t]; recs.resize(cnt[nthr]); }
         }
     }
-    std::vector<uint64_t> lens(recs.size()), counts(r.size, 0);
-    for (size_t i = 0; i < recs.size(); ++i) lens[i] = recs[i].len;
-    if (r.size > 1) detail::check(hsk_plan_partition_reads(lens.data(), lens.size(), r.size, counts.data()), nullptr, "partition");
-    else counts[0] = recs.size();
+    lap("index parsed");
+    std::vector<uint64_t> counts(r.size, 0);
+    if (r.size > 1) {
+        std::vector<uint64_t> lens(recs.size());
+        for (size_t i = 0; i < recs.size(); ++i) lens[i] = recs[i].len;
+        detail::check(hsk_plan_partition_reads(lens.data(), lens.size(), r.size, counts.data()), nullptr, "partition");
+    } else counts[0] = recs.size();
     size_t first = 0;
     for (int p = 0; p < r.rank; ++p) first += counts[p];
     const size_t mine = counts[r.rank];
     std::vector<size_t> mylens(mine);
-    for (size_t i = 0; i < mine; ++i) mylens[i] = recs[first + i].len;
+    bool small_len = true;
+    for (size_t i = 0; i < mine; ++i) { mylens[i] = recs[first + i].len; if (mylens[i] >> 32) small_len = false; }
     // Files of some size are packed on the GPU (hsk_pack_fasta: the records' text is mapped and uploaded once, one lane per packed byte
     // gathers its four bases across the line breaks, same bytes as DnaSeq's packer incl. the code-4 spill) and come back as ONE copy into
     // the (pinned) DnaBuffer -- the host loop below packs ~50 Mbp/s, the path it feeds counts 60 Gbp/s.  HSK_HOST_INGEST=1 keeps the host loop.
@@ -169,19 +214,40 @@ inline std::shared_ptr<DnaBuffer> read_dna_buffer(const std::string &fasta_fname
         const size_t nl = l.bases ? (l.len + l.bases - 1) / l.bases : 0;
         const size_t span0 = recs[first].pos, span1 = l.len ? l.pos + (l.bases ? (nl - 1) * l.width + (l.len - (nl - 1) * l.bases) : l.len) : l.pos;
         const char *hi = std::getenv("HSK_HOST_INGEST");
-        bool small_len = true; for (size_t i = 0; i < mine; ++i) if (mylens[i] >> 32) small_len = false;
         if (span1 > span0 && span1 - span0 >= (size_t(16) << 20) && small_len && !(hi && atoi(hi) != 0) && hsk_device_count() > 0) {
             hsk_ctx *ctx = detail::context(comm);
+            lap("partition, context");
             detail::MappedFile mf(fasta_fname, span0, span1);
+            lap("file mapped");
             std::vector<uint64_t> pos(mine); std::vector<uint32_t> rl(mine), lb(mine), lw(mine);
-            for (size_t i = 0; i < mine; ++i) { const detail::FaiRecord &q = recs[first + i]; pos[i] = q.pos - span0; rl[i] = (uint32_t)q.len; lb[i] = (uint32_t)q.bases; lw[i] = (uint32_t)q.width; }
+            {
+                const unsigned hw = std::thread::hardware_concurrency();
+                const size_t nthr = mine < (size_t(1) << 20) ? 1 : std::min<size_t>(hw ? hw : 4, 8);
+                auto fill = [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi; ++i) { const detail::FaiRecord &q = recs[first + i]; pos[i] = q.pos - span0; rl[i] = (uint32_t)q.len; lb[i] = (uint32_t)q.bases; lw[i] = (uint32_t)q.width; }
+                };
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < nthr; ++t) th.emplace_back(fill, mine * t / nthr, mine * (t + 1) / nthr);
+                fill(0, mine / nthr);
+                for (auto &x : th) x.join();
+            }
             void *dp = nullptr, *doff = nullptr, *dlen = nullptr; uint64_t pb = 0;
-            detail::check(hsk_pack_fasta(ctx, mf.text(), span1 - span0, pos.data(), rl.data(), lb.data(), lw.data(), mine, &dp, &pb, &doff, &dlen), ctx, "hsk_pack_fasta");
+            lap("record tables");
+            // upload + pack on a second thread while this one allocates the DnaBuffer (pinned: the pages of 250 MB per Gbp take as long to pin as the
+            // text takes to cross the link); the buffer's fill step waits for the pack and takes the bytes in one copy
+            std::future<int> packed = std::async(std::launch::async, [&]() {
+                return hsk_pack_fasta(ctx, mf.text(), span1 - span0, pos.data(), rl.data(), lb.data(), lw.data(), mine, &dp, &pb, &doff, &dlen);
+            });
             std::shared_ptr<DnaBuffer> dbuf;
             try {
-                dbuf = std::make_shared<DnaBuffer>(DnaBuffer::computebufsize(mylens), mylens, [&](uint8_t *dst) { detail::check(hsk_memcpy_d2h(ctx, dst, dp, pb), ctx, "hsk_memcpy_d2h"); });
-            } catch (...) { hsk_synth_free(ctx, dp, doff, dlen); throw; }
+                dbuf = std::make_shared<DnaBuffer>(DnaBuffer::computebufsize(mylens), mylens, [&](uint8_t *dst) {
+                    detail::check(packed.get(), ctx, "hsk_pack_fasta");
+                    lap("uploaded and packed (buffer allocated meanwhile)");
+                    detail::check(hsk_memcpy_d2h(ctx, dst, dp, pb), ctx, "hsk_memcpy_d2h");
+                });
+            } catch (...) { if (packed.valid()) packed.wait(); if (dp) hsk_synth_free(ctx, dp, doff, dlen); throw; }
             hsk_synth_free(ctx, dp, doff, dlen);
+            lap("DnaBuffer built, copied");
             return dbuf;
         }
     }

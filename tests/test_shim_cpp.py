@@ -204,7 +204,7 @@ def test_example_driver_one_gbp_fasta_ingest_on_the_device(tmp_path):
     r = dd.count()
     assert H.histogram_text(r.histo) in so
     dd.free()
-    assert rate >= 1.0, rate                                       # (the host loop: ~0.05 GB/s)
+    assert rate >= 2.0, rate                                       # (measured 3.5 - 3.9 GB/s; the host loop: ~0.05 GB/s)
     # a smaller file through both ingest paths of the shim: identical output
     small = str(tmp_path / "small.fa")
     write(small, 800_000)                                           # 125 MB of text: above the 16 MB limit of the device path
