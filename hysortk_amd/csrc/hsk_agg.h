@@ -60,6 +60,30 @@ struct AggTask {
     // overflowing bin raises the task's AG_FLAG_OVERFLOW instead and the host sends the whole task the long way.
     const u32 *bin_list; const u32 *bin_list_n;
     u32 *ovf_list; u32 *ovf_n;
+    const struct AggLarge *lg;     // bins of very many records counted slice by slice beforehand (agg_large_slice_kernel); null: none
+};
+// ---- bins of very many records ----------------------------------------------------------------------------------------------------
+// A bin far beyond the usual few thousand records is nearly always ONE k-mer seen millions of times (poly-A, the poly-G reads of two-colour
+// sequencers, satellites).  Its records all hit one counter of one workgroup's table, and that workgroup reads them alone: 40 M copies of the
+// all-A 31-mer (5 Gbp with 2 % all-A reads) kept it busy for 108 ms while the rest of the GPU had finished the batch in 10.  Such bins are cut
+// into slices of AGL_SLICE records: agg_large_list_kernel finds them (up to AGL_TABLES per task) and lists their slices, agg_large_slice_kernel
+// counts every slice in an LDS table (a wave whose lanes all hold the same key sends one lane with the sum) and adds the table's few pairs to
+// the bin's table in GLOBAL memory (AGL_TAB slots, atomics); the bin's own workgroup then counts that table's slots instead of the records.
+// More distinct keys than a slice's or the bin's table holds (a large bin of another kind): the bin is marked and counted the old way.
+constexpr u64 AG_LARGE_BIN = 1u << 16;
+constexpr u32 AGL_SLICE = 1u << 15;
+constexpr int AGL_LOG2TAB = 11;
+constexpr u32 AGL_TAB = 1u << AGL_LOG2TAB;
+constexpr u32 AGL_TABLES = 16;
+constexpr int AGL_MAX_PROBE = 64;
+struct AggLarge {
+    u32 *bin_tab;                  // [nbins] 0, or 1 + the bin's table
+    unsigned long long *tkeys;     // [AGL_TABLES][AGL_TAB], AG_EMPTY (two-word keys: word 1)
+    unsigned long long *tkeys0;    // two-word keys: word 0 (AG_EMPTY until the slot's claimer has stored it)
+    u32 *tcnt;                     // [AGL_TABLES][AGL_TAB], 0
+    u32 *tbad;                     // [AGL_TABLES] 1: the bin is counted the old way after all
+    unsigned long long *units;     // {bin << 32 | slice}; room for n / AGL_SLICE + AGL_TABLES + 1
+    u32 *ctl;                      // [0] tables handed out, [1] units listed, [2] ticket of the slice kernel
 };
 // the bin this workgroup works on (false: none) and what to do when it overflows
 __device__ __forceinline__ bool agg_pick_bin(const AggTask &t, u32 nbins, u32 &b)
@@ -162,6 +186,10 @@ __device__ __forceinline__ u64 agg_count_keys(u64 act, u32 key_base, u32 cnt_bas
         : "vcc", "scc", "memory");
     return act;
 }
+
+// (bins of very many records, AggLarge above: a wave first asks whether its lanes all hold the same key and, if so, sends ONE lane with the
+//  sum -- same-address LDS atomics are taken one lane after the other)
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE); return v; }
 
 // Steps 2 and 3 of the aggregation for one bin whose records have been counted into the table {s_key, s_cnt} (CAP slots):
 // compact the distinct keys, order them, filter [L, U], write the entries to the bin's slots, publish the count.
@@ -275,6 +303,85 @@ __device__ unsigned long long g_agg_diag[16];
 #define AG_STAMP(i) do { } while (0)
 #endif
 
+// one thread per bin: a bin of AG_LARGE_BIN records and more gets a global table and its slices are listed
+__global__ __launch_bounds__(AG_THREADS) void agg_large_list_kernel(AggArgs a)
+{
+    const AggTask &t = a.t[blockIdx.y];
+    const u32 b = blockIdx.x * AG_THREADS + threadIdx.x;
+    if (!t.active || !t.lg || b >= a.nbins) return;
+    const u64 n = t.bounds[b + 1] - t.bounds[b];
+    if (n < AG_LARGE_BIN) return;
+    const AggLarge &lg = *t.lg;
+    const u32 ti = atomicAdd(&lg.ctl[0], 1u);
+    if (ti >= AGL_TABLES) return;
+    const u32 ns = (u32)((n + AGL_SLICE - 1) / AGL_SLICE);
+    const u32 u0 = atomicAdd(&lg.ctl[1], ns);           // (fits: the listed bins' slices are at most n / AGL_SLICE + AGL_TABLES)
+    for (u32 j = 0; j < ns; ++j) lg.units[u0 + j] = ((unsigned long long)b << 32) | j;
+    lg.bin_tab[b] = ti + 1u;
+}
+
+// persistent workgroups, one slice per ticket: the slice's records into an LDS table, the table's pairs into the bin's global table
+__global__ __launch_bounds__(AG_THREADS) void agg_large_slice_kernel(AggArgs a)
+{
+    constexpr int LOG2CAP = AG_LOG2CAP_MEDIUM, CAP = 1 << LOG2CAP, PER = CAP / AG_THREADS, UNR = 16;
+    __shared__ u64 s_key[CAP];
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_ctl[2];
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active || !t.lg) return;
+    const AggLarge &lg = *t.lg;
+    const u32 nunits = lg.ctl[1];
+    if (nunits == 0) return;
+    const int tid = threadIdx.x;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_key, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { s_ctl[0] = atomicAdd(&lg.ctl[2], 1u); s_ctl[1] = 0; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { s_key[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
+        __syncthreads();
+        const u32 u = s_ctl[0];
+        if (u >= nunits) break;
+        const unsigned long long un = lg.units[u];
+        const u32 b = (u32)(un >> 32), ti = lg.bin_tab[b] - 1u;
+        const u64 s = t.bounds[b] + (u64)(u32)un * AGL_SLICE, be = t.bounds[b + 1], e = s + AGL_SLICE < be ? s + AGL_SLICE : be;
+        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+            u64 k[UNR];
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) { const u64 idx = i + (u64)x * AG_THREADS; k[x] = idx < e ? t.keys[idx] : AG_EMPTY; }
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) {
+                u64 act = __ballot(k[x] != AG_EMPTY);
+                if (act == 0) continue;                   // (uniform; the active lanes are a prefix of the wave: lane 0 is one of them)
+                u32 h = agg_slot<LOG2CAP>(k[x]), inc = 1u;
+                const u64 k0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(k[x] >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)k[x]);
+                if (__ballot(k[x] == k0) == act) { inc = (u32)__popcll(act); act = 1ULL; }
+                if (agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[x], inc) != 0) s_ctl[1] = 1;      // (uniform)
+            }
+            if (__hip_atomic_load(&s_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+        __syncthreads();
+        if (s_ctl[1]) { if (tid == 0) lg.tbad[ti] = 1u; continue; }      // (more distinct keys than a slice's table takes: not this kind of bin)
+        unsigned long long *gk = lg.tkeys + (u64)ti * AGL_TAB; u32 *gc = lg.tcnt + (u64)ti * AGL_TAB;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u64 kq = s_key[j * AG_THREADS + tid];
+            if (kq == AG_EMPTY) continue;
+            const u32 cq = s_cnt[j * AG_THREADS + tid];
+            u32 h = agg_slot<AGL_LOG2TAB>(kq);
+            bool placed = false;
+            for (int pr = 1; pr <= AGL_MAX_PROBE && !placed; ++pr) {
+                unsigned long long prev = gk[h];
+                if (prev == AG_EMPTY) prev = atomicCAS(&gk[h], (unsigned long long)AG_EMPTY, (unsigned long long)kq);
+                if (prev == AG_EMPTY || prev == kq) { atomicAdd(&gc[h], cq); placed = true; }
+                else h = (h + (u32)pr) & (AGL_TAB - 1u);
+            }
+            if (!placed) lg.tbad[ti] = 1u;
+        }
+    }
+}
+
 // W: the records are {key, count} pairs (AggTask::vals) and a key's counter grows by the pair's count
 template <int LOG2CAP, bool W = false>
 __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
@@ -310,6 +417,18 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
     constexpr int AG_UNROLL = 16;
     typedef __attribute__((address_space(3))) void *LdsPtr;
     const u32 key_lds = (u32)(uintptr_t)(LdsPtr)s_key, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;     // LDS byte addresses of the two arrays
+    const bool large = e - s >= AG_LARGE_BIN;
+    u32 ltab = 0;                                       // 1 + the global table the bin's slices were counted into (agg_large_slice_kernel)
+    if (!W && large && t.lg) { ltab = t.lg->bin_tab[b]; if (ltab && t.lg->tbad[ltab - 1]) ltab = 0; }
+    if (ltab) {
+        const unsigned long long *gk = t.lg->tkeys + (u64)(ltab - 1) * AGL_TAB; const u32 *gc = t.lg->tcnt + (u64)(ltab - 1) * AGL_TAB;
+        for (u32 q = tid; q < AGL_TAB; q += AG_THREADS) {
+            const u64 kq = gk[q];
+            const u64 act = __ballot(kq != AG_EMPTY);
+            u32 h = agg_slot<LOG2CAP>(kq);
+            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, kq, gc[q]) != 0) s_ovf = 1;      // (uniform)
+        }
+    } else
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * AG_UNROLL) {
         u64 k[AG_UNROLL]; u32 wv[W ? AG_UNROLL : 1];
 #pragma unroll
@@ -319,9 +438,14 @@ __global__ __launch_bounds__(AG_THREADS) void agg_finish_kernel(AggArgs a)
         }
 #pragma unroll
         for (int u = 0; u < AG_UNROLL; ++u) {
-            const u64 act = __ballot(k[u] != AG_EMPTY);
+            u64 act = __ballot(k[u] != AG_EMPTY);
             u32 h = agg_slot<LOG2CAP>(k[u]);
-            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u], W ? wv[u] : 1u) != 0) s_ovf = 1;      // (uniform)
+            u32 inc = W ? wv[u] : 1u;
+            if (large && act != 0) {                      // (uniform; the active lanes are a prefix of the wave: lane 0 is one of them)
+                const u64 k0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(k[u] >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)k[u]);
+                if (__ballot(k[u] == k0) == act) { inc = W ? wave_sum_u32(k[u] != AG_EMPTY ? wv[u] : 0u) : (u32)__popcll(act); act = 1ULL; }
+            }
+            if (act != 0 && agg_count_keys<(u32)CAP - 1u>(act, key_lds, cnt_lds, h, k[u], inc) != 0) s_ovf = 1;      // (uniform)
         }
         // a bin with more distinct keys than the table takes (a probe sequence ran past AG_MAX_PROBE slots: with linear probing
         // that starts at a load of ~0.8) gives up here instead of grinding through the rest of its records
@@ -501,6 +625,83 @@ __device__ __forceinline__ u64 agg2_count_keys(u64 act, u32 k1_base, u32 k0_base
 
 __device__ __forceinline__ bool key2_less(u64 a1, u64 a0, u64 b1, u64 b0) { return a1 < b1 || (a1 == b1 && a0 < b0); }
 
+// the same for two-word keys: the slice's table is filled by agg2_count_keys; in the bin's global table a slot is claimed on word 1 and word 0
+// published behind it, a workgroup that finds its word 1 waits for the word 0 (the claimer stores it right after its claim)
+__global__ __launch_bounds__(AG_THREADS) void agg2_large_slice_kernel(AggArgs a)
+{
+    constexpr int LOG2CAP = AG_LOG2CAP_SMALL, CAP = 1 << LOG2CAP, PER = CAP / AG_THREADS, UNR = 8;
+    __shared__ u64 s_k1[CAP];
+    __shared__ u64 s_k0[CAP];
+    __shared__ u32 s_cnt[CAP];
+    __shared__ u32 s_ctl[2];
+    const AggTask &t = a.t[blockIdx.y];
+    if (!t.active || !t.lg) return;
+    const AggLarge &lg = *t.lg;
+    const u32 nunits = lg.ctl[1];
+    if (nunits == 0) return;
+    const int tid = threadIdx.x;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    const u32 k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
+    const ulonglong2 *recs = reinterpret_cast<const ulonglong2 *>(t.keys);       // {word 0, word 1}
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { s_ctl[0] = atomicAdd(&lg.ctl[2], 1u); s_ctl[1] = 0; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { s_k1[j * AG_THREADS + tid] = AG_EMPTY; s_k0[j * AG_THREADS + tid] = AG_EMPTY; s_cnt[j * AG_THREADS + tid] = 0; }
+        __syncthreads();
+        const u32 u = s_ctl[0];
+        if (u >= nunits) break;
+        const unsigned long long un = lg.units[u];
+        const u32 b = (u32)(un >> 32), ti = lg.bin_tab[b] - 1u;
+        const u64 s = t.bounds[b] + (u64)(u32)un * AGL_SLICE, be = t.bounds[b + 1], e = s + AGL_SLICE < be ? s + AGL_SLICE : be;
+        for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
+            ulonglong2 k[UNR];
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) { const u64 idx = i + (u64)x * AG_THREADS; k[x] = idx < e ? recs[idx] : make_ulonglong2(AG_EMPTY, AG_EMPTY); }
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) {
+                const u64 w0 = k[x].x, w1 = k[x].y;
+                u64 act = __ballot(w1 != AG_EMPTY);
+                if (act == 0) continue;                   // (uniform)
+                const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
+                u32 tmo = 0, h = (((u32)(m >> 32) ^ (u32)m) * 0x9E3779B1u) >> (32 - LOG2CAP), inc = 1u;
+                const u64 f1 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w1 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)w1);
+                const u64 f0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)w0);
+                if (__ballot(w1 == f1 && w0 == f0) == act) { inc = (u32)__popcll(act); act = 1ULL; }
+                if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo, inc) != 0 || tmo) s_ctl[1] = 1;      // (uniform)
+            }
+            if (__hip_atomic_load(&s_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+        __syncthreads();
+        if (s_ctl[1]) { if (tid == 0) lg.tbad[ti] = 1u; continue; }
+        unsigned long long *g1 = lg.tkeys + (u64)ti * AGL_TAB, *g0 = lg.tkeys0 + (u64)ti * AGL_TAB; u32 *gc = lg.tcnt + (u64)ti * AGL_TAB;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u64 q1 = s_k1[j * AG_THREADS + tid], q0 = s_k0[j * AG_THREADS + tid];
+            if (q1 == AG_EMPTY) continue;
+            const u32 cq = s_cnt[j * AG_THREADS + tid];
+            const u64 m = q0 ^ (q1 >> 9) ^ (q1 << 21);
+            u32 h = (((u32)(m >> 32) ^ (u32)m) * 0x9E3779B1u) >> (32 - AGL_LOG2TAB);
+            bool placed = false;
+            for (int pr = 1; pr <= AGL_MAX_PROBE && !placed; ++pr) {
+                unsigned long long prev = __hip_atomic_load(&g1[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev == AG_EMPTY) {
+                    prev = atomicCAS(&g1[h], (unsigned long long)AG_EMPTY, (unsigned long long)q1);
+                    if (prev == AG_EMPTY) { __hip_atomic_store(&g0[h], (unsigned long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&gc[h], cq); placed = true; break; }
+                }
+                if (prev == q1) {
+                    unsigned long long v0 = AG_EMPTY; u32 spins = 0;
+                    while ((v0 = __hip_atomic_load(&g0[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == AG_EMPTY && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+                    if (v0 == q0) { atomicAdd(&gc[h], cq); placed = true; break; }
+                    if (v0 == AG_EMPTY) break;            // (a word 0 that never came: cannot happen; the bin is counted the old way)
+                }
+                h = (h + (u32)pr) & (AGL_TAB - 1u);
+            }
+            if (!placed) lg.tbad[ti] = 1u;
+        }
+    }
+}
+
 template <int LOG2CAP, bool W = false>      // W: the records are {k-mer, count} pairs (AggTask::vals), the table adds the counts up (combining extraction, two-word keys)
 __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 {
@@ -527,7 +728,21 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
     constexpr int UNR = 8;
     typedef __attribute__((address_space(3))) void *LdsPtr;
     const u32 k1_lds = (u32)(uintptr_t)(LdsPtr)s_k1, k0_lds = (u32)(uintptr_t)(LdsPtr)s_k0, cnt_lds = (u32)(uintptr_t)(LdsPtr)s_cnt;
+    const bool large = e - s >= AG_LARGE_BIN;
     const ulonglong2 *recs = reinterpret_cast<const ulonglong2 *>(t.keys);       // {word 0, word 1}
+    u32 ltab = 0;                                       // 1 + the global table the bin's slices were counted into (agg2_large_slice_kernel)
+    if (!W && large && t.lg) { ltab = t.lg->bin_tab[b]; if (ltab && t.lg->tbad[ltab - 1]) ltab = 0; }
+    if (ltab) {
+        const unsigned long long *g1 = t.lg->tkeys + (u64)(ltab - 1) * AGL_TAB, *g0 = t.lg->tkeys0 + (u64)(ltab - 1) * AGL_TAB; const u32 *gc = t.lg->tcnt + (u64)(ltab - 1) * AGL_TAB;
+        for (u32 q = tid; q < AGL_TAB; q += AG_THREADS) {
+            const u64 w1 = g1[q], w0 = g0[q];
+            const u64 act = __ballot(w1 != AG_EMPTY);
+            if (act == 0) continue;                       // (uniform)
+            const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
+            u32 tmo = 0, h = (((u32)(m >> 32) ^ (u32)m) * 0x9E3779B1u) >> (32 - LOG2CAP);
+            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo, gc[q]) != 0 || tmo) s_ovf = 1;      // (uniform)
+        }
+    } else
     for (u64 i = s + tid; i < e; i += (u64)AG_THREADS * UNR) {
         ulonglong2 k[UNR]; u32 wt[UNR];
 #pragma unroll
@@ -535,12 +750,17 @@ __global__ __launch_bounds__(AG_THREADS) void agg2_finish_kernel(AggArgs a)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const u64 w0 = k[u].x, w1 = k[u].y;
-            const u64 act = __ballot(w1 != AG_EMPTY);
+            u64 act = __ballot(w1 != AG_EMPTY);
             if (act == 0) continue;                       // (uniform)
             const u64 m = w0 ^ (w1 >> 9) ^ (w1 << 21);
             const u32 x = (u32)(m >> 32) ^ (u32)m;
-            u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - LOG2CAP);
-            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo, wt[u]) != 0 || tmo) s_ovf = 1;      // (uniform)
+            u32 tmo = 0, h = (x * 0x9E3779B1u) >> (32 - LOG2CAP), inc = wt[u];
+            if (large) {                                  // (uniform; one k-mer in all lanes of the wave: one lane with the sum, as in agg_finish_kernel)
+                const u64 f1 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w1 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)w1);
+                const u64 f0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)w0);
+                if (__ballot(w1 == f1 && w0 == f0) == act) { inc = wave_sum_u32(w1 != AG_EMPTY ? wt[u] : 0u); act = 1ULL; }
+            }
+            if (agg2_count_keys<(u32)CAP - 1u>(act, k1_lds, k0_lds, cnt_lds, h, w1, w0, tmo, inc) != 0 || tmo) s_ovf = 1;      // (uniform)
         }
         if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }

@@ -57,7 +57,15 @@ struct BucketSortArgs {
     u32 vt_shift;              // minimizer bits the virtual tasks have consumed
     u32 *err;                  // sticky error word (bit 64: an item list whose virtual task does not fit its task's buckets: nothing is written)
     ulonglong2 *recs;          // out: the items, tasks back to back, buckets ascending inside a task
+    uint2 *units;              // out (bucket_units_kernel): the work units of the combining extraction, {first item, end} inside the task
+    const u64 *unit_off;       // [ntasks] first unit of every task in `units`
+    u32 *nunits;               // [ntasks] out: units of every task
 };
+// A work unit of the combining extraction is a bucket, or -- a minimizer that very many supermers share: homopolymers, satellites -- a slice of
+// CB_UNIT items of one: the slices of a bucket go to different workgroups, every one counts into a table of its own and the finish adds
+// their pairs up (as it does for a bucket whose table ran over).  Measured on 5 Gbp with 2 % of the reads replaced by all-A reads (one
+// bucket of 10 M items, counted by ONE workgroup while the other 1279 had long finished): extraction 114 instead of 19 ms.
+constexpr u32 CB_UNIT = 8192;
 // bucket of an item inside its task = top lg bits of sub = {virtual task bits, local bits}
 struct BucketMap { u32 lg, lgl, gbase; };
 __device__ __forceinline__ BucketMap bucket_map(const BucketSortArgs &a, const BucketItem &it)
@@ -131,6 +139,29 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(BucketSortArgs a)
     u32 run = base + inc - sum;
     for (u32 i = lo; i < lo + per && i < nb; ++i) { const u32 c = g[i]; g[i] = run; cu[i] = run; run += c; }
     if (threadIdx.x == 0) g[nb] = tot;
+}
+
+// one workgroup per task, after bucket_scan_kernel: the buckets' offsets -> the unit list (empty buckets make no unit)
+__global__ __launch_bounds__(1024) void bucket_units_kernel(BucketSortArgs a)
+{
+    __shared__ u32 s_w[16];
+    const u32 t = blockIdx.x, nb = 1u << a.log2nb[t];
+    const u32 *g = a.off + (u64)t * a.stride;
+    uint2 *un = a.units + a.unit_off[t];
+    const u32 per = (nb + 1023u) / 1024u;
+    const u32 lo = threadIdx.x * per;
+    u32 sum = 0;
+    for (u32 i = lo; i < lo + per && i < nb; ++i) sum += (g[i + 1] - g[i] + CB_UNIT - 1u) / CB_UNIT;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(sum);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) { const u32 s = s_w[i]; if (i < w) base += s; tot += s; }
+    u32 run = base + inc - sum;
+    for (u32 i = lo; i < lo + per && i < nb; ++i)
+        for (u32 r0 = g[i], r1 = g[i + 1]; r0 < r1; r0 += CB_UNIT) un[run++] = make_uint2(r0, r1 - r0 > CB_UNIT ? r0 + CB_UNIT : r1);
+    if (threadIdx.x == 0) a.nunits[t] = tot;
 }
 
 __global__ __launch_bounds__(CS_THREADS) void bucket_scatter_kernel(BucketSortArgs a)
@@ -365,7 +396,8 @@ static_assert(CB_CAP <= (XS_SPAN - 1) * XsCfg<1>::CHUNK, "a dump's reservation t
 
 struct CombineTask {
     const ulonglong2 *recs;    // the task's items in bucket order (place_items_kernel's two words)
-    const u32 *boff;           // [nb + 1] first item of every bucket
+    const uint2 *units;        // work units {first item, end}: a bucket or a slice of a large one (bucket_units_kernel)
+    const u32 *nunits;         // their number (device memory)
     u32 nb;                    // buckets (0: no task on this XCD)
     u32 vmax;
     u32 cap_chunks;            // chunks the pair stores hold; the one behind them takes what does not fit (error bit 512: the host runs the call again with stores
@@ -391,6 +423,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a)
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
     const CombineTask &t = a.t[xcc];
     if (t.nb == 0) return;
+    const u32 nunits = *t.nunits;
     const int k = KT ? KT : a.k;
     const int low = 64 - 2 * k;
     const u64 lastmask = ~0ULL << low;
@@ -468,8 +501,9 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a)
         if (tid == 0) s_flag[0] = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         xs_barrier();
         const u32 b = s_flag[0];
-        if (b >= t.nb) break;
-        const u32 r0 = t.boff[b], r1 = t.boff[b + 1];
+        if (b >= nunits) break;
+        const uint2 un = t.units[b];
+        const u32 r0 = un.x, r1 = un.y;
         ulonglong2 nxt = make_ulonglong2(0, 0);
         if (r0 + (u32)tid < r1) nxt = t.recs[r0 + (u32)tid];
         for (u32 base = r0; base < r1; base += CB_THREADS) {
@@ -581,6 +615,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine2_kernel(CombineArgs a)
     const u32 xcc = __builtin_amdgcn_s_getreg(XCC_ID_GETREG) & 7u;
     const CombineTask &t = a.t[xcc];
     if (t.nb == 0) return;
+    const u32 nunits = *t.nunits;
     const int k = KT ? KT : a.k;                       // 33 .. 59
     const u64 lastmask = ~0ULL << (128 - 2 * k);       // the bases of word 1
     const u32 sh0 = (u32)a.shift0 - 32u, sh1 = (u32)a.shift1 - 32u, dm0 = (1u << a.bits0) - 1u;
@@ -654,8 +689,9 @@ __global__ __launch_bounds__(CB_THREADS) void combine2_kernel(CombineArgs a)
         if (tid == 0) s_flag[0] = __hip_atomic_fetch_add(&t.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         xs_barrier();
         const u32 b = s_flag[0];
-        if (b >= t.nb) break;
-        const u32 r0 = t.boff[b], r1 = t.boff[b + 1];
+        if (b >= nunits) break;
+        const uint2 un = t.units[b];
+        const u32 r0 = un.x, r1 = un.y;
         ulonglong2 nxt = make_ulonglong2(0, 0);
         if (r0 + (u32)tid < r1) nxt = t.recs[r0 + (u32)tid];
         for (u32 base = r0; base < r1; base += CB_THREADS) {

@@ -57,13 +57,15 @@ static int bins_to_store(hsk_ctx *c, ScanBins &b, SupermerStore &st, u32 nvt, u3
 // the supermer items of the owned tasks in bucket order
 struct BucketOrder {
     ulonglong2 *recs = nullptr; u32 *off = nullptr, *cur = nullptr, *d_log2nb = nullptr; u64 *d_out_base = nullptr; BucketItem *d_items = nullptr;
+    uint2 *units = nullptr; u64 *d_unit_off = nullptr; u32 *d_nunits = nullptr;      // the work units of the combining extraction (bucket_units_kernel)
     u32 stride = 0;
-    std::vector<u32> log2nb; std::vector<u64> out_base;
+    std::vector<u32> log2nb; std::vector<u64> out_base, unit_off;
     bool active = false;
 };
 static void bucket_release(hsk_ctx *c, BucketOrder &bo)
 {
     c->pool.release(bo.recs); c->pool.release(bo.off); c->pool.release(bo.cur); c->pool.release(bo.d_log2nb); c->pool.release(bo.d_out_base); c->pool.release(bo.d_items);
+    c->pool.release(bo.units); c->pool.release(bo.d_unit_off); c->pool.release(bo.d_nunits);
     bo = BucketOrder();
 }
 
@@ -71,9 +73,9 @@ static void bucket_release(hsk_ctx *c, BucketOrder &bo)
 static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs> &segs, const std::vector<u32> &tasks, const BaseSource &src, u32 vt_shift, BucketOrder &bo)
 {
     bo = BucketOrder();
-    bo.log2nb.assign(ntasks, 0); bo.out_base.assign(ntasks, 0);
+    bo.log2nb.assign(ntasks, 0); bo.out_base.assign(ntasks, 0); bo.unit_off.assign(ntasks, 0);
     std::vector<BucketItem> items;
-    u64 run = 0; u32 maxlg = 0;
+    u64 run = 0, urun = 0; u32 maxlg = 0;
     const u64 target = combine_bucket_kmers();
     for (u32 t : tasks) {
         if (t == ~0u) continue;
@@ -87,6 +89,7 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
         while (lg < (u32)CS_MAX_LOG2NB && lg < (u32)CS_MAX_LOCAL + vt_shift && (segs[t].nkmers >> lg) > target) ++lg;
         bo.log2nb[t] = lg; maxlg = std::max(maxlg, lg);
         bo.out_base[t] = run; run += nsup;
+        bo.unit_off[t] = urun; urun += (1ULL << lg) + nsup / CB_UNIT + 1;      // (a bucket makes at most one unit more than it has whole slices)
     }
     const bool dev_list = src.bitems != nullptr;             // scan-placed bins: the work list is on the device already (one item per chunk)
     if (dev_list ? src.n_bitems == 0 : items.empty()) return HSK_OK;
@@ -98,6 +101,9 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
     DALLOC(c, bo.d_log2nb, u32 *, (size_t)ntasks * 4);
     DALLOC(c, bo.d_out_base, u64 *, (size_t)ntasks * 8);
     if (!dev_list) DALLOC(c, bo.d_items, BucketItem *, items.size() * sizeof(BucketItem));
+    DALLOC(c, bo.units, uint2 *, urun * 8 + 64); DALLOC(c, bo.d_unit_off, u64 *, (size_t)ntasks * 8); DALLOC(c, bo.d_nunits, u32 *, (size_t)ntasks * 4);
+    HIPCHK(c, hipMemsetAsync(bo.d_nunits, 0, (size_t)ntasks * 4, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bo.d_unit_off, bo.unit_off.data(), (size_t)ntasks * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(bo.off, 0, (size_t)ntasks * bo.stride * 4, c->stream));
     HIPCHK(c, hipMemcpyAsync(bo.d_log2nb, bo.log2nb.data(), (size_t)ntasks * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(bo.d_out_base, bo.out_base.data(), (size_t)ntasks * 8, hipMemcpyHostToDevice, c->stream));
@@ -106,10 +112,12 @@ static int bucket_order_tasks(hsk_ctx *c, u32 ntasks, const std::vector<TaskSegs
     BucketSortArgs a; memset(&a, 0, sizeof a);
     a.items = dev_list ? reinterpret_cast<const BucketItem *>(src.bitems) : bo.d_items; a.sm_sub = src.sub; a.sm_item = reinterpret_cast<const ulonglong2 *>(src.item); a.off = bo.off; a.cur = bo.cur; a.log2nb = bo.d_log2nb; a.out_base = bo.d_out_base;
     a.stride = bo.stride; a.recs = bo.recs; a.vt_shift = vt_shift; a.err = c->d_err;
+    a.units = bo.units; a.unit_off = bo.d_unit_off; a.nunits = bo.d_nunits;
     const bool profile = (c->cfg.flags & HSK_FLAG_PROFILE) != 0;
     EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 8; ep.keys = run; (void)hipEventRecord(ep.a, c->stream); }
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(nwork), dim3(CS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(ntasks), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(bucket_units_kernel, dim3(ntasks), dim3(1024), 0, c->stream, a);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nwork), dim3(CS_THREADS), 0, c->stream, a);
     if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
     HIPCHK(c, hipGetLastError());
@@ -221,7 +229,7 @@ static int combine_batch(hsk_ctx *c, const u32 *tk, const BatchTask *bt, u64 *co
         t.ghist = ghist[i] + 256; t.tile_src = sb.d_tile_src[i];
         t.n = ~0ULL; t.n_out = sb.d_nout + i; t.gbase = sb.d_gbase + (size_t)i * 256; t.ntiles_out = sb.d_ntiles + i;
         CombineTask &q = ca.t[i];
-        q.recs = bo.recs + bo.out_base[tid]; q.boff = bo.off + (size_t)tid * bo.stride; q.nb = 1u << bo.log2nb[tid]; q.vmax = t.vmax;
+        q.recs = bo.recs + bo.out_base[tid]; q.units = bo.units + bo.unit_off[tid]; q.nunits = bo.d_nunits + tid; q.nb = 1u << bo.log2nb[tid]; q.vmax = t.vmax;
         q.cap_chunks = (u32)(scatter_store_keys(pair_cap, CH) / CH);
         q.chunks = t.chunks; q.vchunks = t.vchunks; q.cursor = t.cursor; q.map = t.map; q.ctl = t.ctl; q.ghist = t.ghist;
         ntot += n;

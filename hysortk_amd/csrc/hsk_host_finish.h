@@ -196,6 +196,7 @@ struct AggPending {
     AggArgs a;
     u64 *d_bounds = nullptr, *d_cnt = nullptr, *d_off = nullptr; u32 *d_flags = nullptr;     // d_flags: {flags[8], maxd[8], overflow-list lengths [2][8]}
     u32 *d_list[2] = {nullptr, nullptr};                                    // [AG_BATCH][nbins] overflowing bins, ping-pong between the rungs
+    char *d_large = nullptr;                                                // bins of very many records (hsk_agg.h: AggLarge): the tasks' structs, tables and slice lists
     bool own_scratch[AG_BATCH] = {false};
     bool big = false; int first_cap = AG_LOG2CAP_SMALL;
     bool weighted = false;                              // the records are {key, count} pairs (combining extraction): counts are added, no long way
@@ -316,6 +317,32 @@ static int agg_stage1(hsk_ctx *c, const BatchTask *bt, int K, int prefix_bits, i
         }
     }
     hipLaunchKernelGGL(bin_bounds_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    if constexpr (NW <= 2) if (!weighted && !p.big && tune("agg_large", 1) != 0 && nmax >= AG_LARGE_BIN && (NW == 1 || a.top_bits == 0 || a.top_bits == 16)) {
+        // bins of very many records (one k-mer seen millions of times): found, cut into slices and counted by many workgroups before the ladder
+        // starts (hsk_agg.h: AggLarge); without such bins the two launches end at once
+        size_t off[AG_BATCH][7], total = (sizeof(AggLarge) * AG_BATCH + 255) / 256 * 256;
+        for (int i = 0; i < AG_BATCH; ++i) {
+            const size_t sz[7] = {(size_t)nbins * 4, (size_t)AGL_TABLES * AGL_TAB * 8, (size_t)AGL_TABLES * AGL_TAB * 4, 256, (size_t)(bt[i].n / AGL_SLICE + AGL_TABLES + 1) * 8, 256,
+                                  NW == 2 ? (size_t)AGL_TABLES * AGL_TAB * 8 : 0};
+            for (int q = 0; q < 7; ++q) { off[i][q] = total; total += (sz[q] + 255) / 256 * 256; }
+        }
+        DALLOC(c, p.d_large, char *, total + 64);
+        HIPCHK(c, hipMemsetAsync(p.d_large, 0, total, c->stream));
+        AggLarge *h_lg = (AggLarge *)((char *)c->pinned + (512u << 10) + (size_t)slot * 1024);
+        for (int i = 0; i < AG_BATCH; ++i) {
+            HIPCHK(c, hipMemsetAsync(p.d_large + off[i][1], 0xFF, (size_t)AGL_TABLES * AGL_TAB * 8, c->stream));
+            if (NW == 2) HIPCHK(c, hipMemsetAsync(p.d_large + off[i][6], 0xFF, (size_t)AGL_TABLES * AGL_TAB * 8, c->stream));
+            AggLarge &g = h_lg[i];
+            g.tkeys0 = NW == 2 ? (unsigned long long *)(p.d_large + off[i][6]) : nullptr;
+            g.bin_tab = (u32 *)(p.d_large + off[i][0]); g.tkeys = (unsigned long long *)(p.d_large + off[i][1]); g.tcnt = (u32 *)(p.d_large + off[i][2]);
+            g.tbad = (u32 *)(p.d_large + off[i][3]); g.units = (unsigned long long *)(p.d_large + off[i][4]); g.ctl = (u32 *)(p.d_large + off[i][5]);
+            a.t[i].lg = (const AggLarge *)p.d_large + i;
+        }
+        HIPCHK(c, hipMemcpyAsync(p.d_large, h_lg, sizeof(AggLarge) * AG_BATCH, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(agg_large_list_kernel, dim3(nbins / AG_THREADS + 1, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        if (NW == 1) hipLaunchKernelGGL(agg_large_slice_kernel, dim3(160, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL(agg2_large_slice_kernel, dim3(160, AG_BATCH), dim3(AG_THREADS), 0, c->stream, a);
+    }
     // First table: what the bins of the previous batches needed (hsk_ctx::agg_first_cap: error-free reads at ~30x stay on 1024
     // slots, reads with ~1 % errors move to 2048 after their first batch); bins of 6144 records and more on average (tasks far
     // above 2^28 k-mers) start on the large table.  Two-word keys: small / large only.
@@ -486,7 +513,7 @@ static int agg_stage2(hsk_ctx *c, AggPending &p, u64 *d_histo, u32 histo_len, Ta
     // no wait here: the scratch (the batch's idle ping-pong buffers, or pool blocks) is next touched by work that is
     // enqueued on this stream after the compaction
     for (int i = 0; i < AG_BATCH; ++i) if (p.own_scratch[i]) c->pool.release(a.t[i].scratch);
-    c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_off); c->pool.release(p.d_flags); c->pool.release(p.d_list[0]); c->pool.release(p.d_list[1]);
+    c->pool.release(p.d_bounds); c->pool.release(p.d_cnt); c->pool.release(p.d_off); c->pool.release(p.d_flags); c->pool.release(p.d_list[0]); c->pool.release(p.d_list[1]); c->pool.release(p.d_large);
     p.active = false;
     return rc;
 }

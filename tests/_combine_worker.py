@@ -27,6 +27,12 @@ def run_spec(spec):
     n = spec["nreads"]
     packed = np.empty(nb, np.uint8); off = np.empty(n, np.uint64); lens = np.empty(n, np.uint32)
     ctx.d2h_into(packed, dp, nb); ctx.d2h_into(off, do, n * 8); ctx.d2h_into(lens, dl, n * 4)
+    if spec.get("poly_a_pct"):
+        # a share of the reads replaced by all-A reads: ONE k-mer, ONE minimizer bucket for all of them ("host" / "pinned" calls only)
+        rng = np.random.default_rng(spec["seed"] + 1)
+        view = packed.reshape(n, (spec["read_len"] + 3) // 4)
+        view[rng.choice(n, int(n * spec["poly_a_pct"] / 100), replace=False)] = 0
+        assert all(h in ("host", "pinned") for h in spec["calls"])
     pinned = None
     for how in spec["calls"]:
         ctx.stats(reset=True)

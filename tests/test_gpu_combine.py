@@ -15,7 +15,9 @@ BASE = dict(K=31, M=17, L=2, U=200, ntasks=16, genome=1500000, read_len=150, nre
 
 def run(spec, env):
     """one context with the tuning `env` spells (old environment-variable names, folded by util.tuning), one result dict per call"""
-    return W.run_spec(dict(spec, tuning=util.tuning(env)))
+    extra = spec.get("tuning_extra")
+    tun = util.tuning(env)
+    return W.run_spec(dict(spec, tuning=(tun + "," + extra if tun else extra) if extra else tun))
 
 
 @pytest.fixture(scope="module")
@@ -249,3 +251,29 @@ def test_pair_stores_that_run_over_are_enlarged_not_abandoned():
     r = run(BASE, {"HSK_COMBINE_MIN_BYTES": "0", "HSK_PAIR_CAP_RECORDS": "100000"})[0]
     assert r["combine_launches"] > 0 and r["instance_extractions"] == 0
     assert (r["digest"], r["entries"]) == (ref["digest"], ref["entries"])
+
+
+@pytest.mark.parametrize("K,U", [(31, 65535), (31, 200), (51, 65535)])
+def test_a_minimizer_that_very_many_supermers_share_is_cut_into_work_units(K, U):
+    """5 % of the reads are all-A reads (homopolymers, satellites: ONE k-mer and ONE minimizer bucket hold 6 % of all k-mer instances -- 20 000
+    reads x 120 k-mers = 150 000 items in one bucket of the order).  The bucket is counted as slices of CB_UNIT = 8192 items by different
+    workgroups whose pairs the weighted finish adds up: same list as the instance path, the all-A k-mer's count (U = 65535: capped by the
+    16-bit count as in the reference; U = 200: filtered) included; the plan's sketch takes a run of one k-mer as one insert."""
+    spec = dict(BASE, K=K, U=U, L=2, poly_a_pct=5.0, calls=["pinned", "host"], ntasks=8)
+    a = run(spec, {"HSK_COMBINE": "0"})
+    b = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})
+    assert all(x["combine_launches"] == 0 for x in a) and all(x["combine_launches"] > 0 and x["instance_extractions"] == 0 for x in b)
+    assert len({(x["digest"], x["entries"]) for x in a + b}) == 1 and a[0]["entries"] > 100000
+
+
+@pytest.mark.parametrize("K", [31, 51])
+def test_a_bin_of_very_many_records_is_counted_in_slices(K):
+    """The instance path on reads of which 5 % are all-A reads: the all-A 31-mer's 2.4 M records share ONE prefix bin of one task.  The bin is cut
+    into slices that many workgroups count into a table in global memory (hsk_agg.h: AggLarge), its own workgroup counts that table: same list
+    as with the slices switched off (agg_large=0) and as the combining extraction."""
+    spec = dict(BASE, K=K, U=65535, L=2, poly_a_pct=5.0, calls=["pinned"], ntasks=8)
+    a = run(spec, {"HSK_COMBINE": "0"})[0]
+    b = run(dict(spec, tuning_extra="agg_large=0"), {"HSK_COMBINE": "0"})[0]
+    c_ = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
+    assert a["combine_launches"] == 0 and b["combine_launches"] == 0 and c_["combine_launches"] > 0
+    assert (a["digest"], a["entries"]) == (b["digest"], b["entries"]) == (c_["digest"], c_["entries"]) and a["entries"] > 100000
