@@ -402,7 +402,7 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
     bool bytes_mode = !item_mode && j.fast && place_bytes_enabled(supermers_travel) && a.rec_cap <= PLACE_BYTES_REC;
     for (u32 t = 0; t < ntasks && bytes_mode; ++t) if (st.task_tot[3 * t + 1] >= (1ULL << 32)) bytes_mode = false;     // 32-bit offsets inside a task's run
     // several ranks with the combining extraction planned (c->combine_now): the supermers' minimizer bits go into the store as well
-    const bool with_sub16 = bytes_mode && supermers_travel && c->combine_now && a.tile_sub && !ext && !skip;
+    const bool with_sub16 = bytes_mode && supermers_travel && c->combine_now && a.tile_sub && !ext;      // (heavy-hitter tasks are skipped by the kernel itself: their k-mers travel as lists)
     a.sm_sub16 = nullptr;
     if (with_sub16) { DALLOC(c, st.sm_sub16, unsigned short *, st.tot_sup * 2 + 64); a.sm_sub16 = st.sm_sub16; }
     if (bytes_mode) {

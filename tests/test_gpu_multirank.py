@@ -125,7 +125,7 @@ def test_rccl_binding_selftest():
         c.comm_selftest()
 
 
-@pytest.mark.parametrize("K", [31, 51, 35, 77])
+@pytest.mark.parametrize("K", [31, 51, 35, 77, -31, -51])
 @pytest.mark.parametrize("R,ntasks", [(2, 24), (3, 24), (4, 32), (2, 56), (8, 128)])
 def test_loopback_heavy_hitter_tasks(R, ntasks, K):
     """K = 31 / 51 / 35 / 77: one-, two- (with and without the prefix plan) and three-word keys (ScatteredKmerList is generic
@@ -135,6 +135,10 @@ def test_loopback_heavy_hitter_tasks(R, ntasks, K):
     import hysortk_amd as H
     from hysortk_amd import synth
     from oracle import hsk_oracle as O
+    # K < 0: the same with the combining extraction planned on the owners' side (combine_min_bytes=0): the heavy tasks travel as lists, every
+    # other task as supermers with their minimizer bits, and the owners build the items
+    tuning = "combine_min_bytes=0,plan_sample=0" if K < 0 else None
+    K = abs(K)
     rng = np.random.default_rng(5)
     seqs = synth.reads(80000, 150, 6000, 31)
     unit = "ACGGTCATTGCA"
@@ -145,10 +149,11 @@ def test_loopback_heavy_hitter_tasks(R, ntasks, K):
     parts = _split(H, seqs, R)
     if K != 31 and (R, ntasks) not in ((2, 24), (4, 32)):
         pytest.skip("the wider keys take two of the rank / task layouts")
-    with H.Context(K=K, M=17, L=2, U=65535, ntasks=ntasks) as c:
+    with H.Context(K=K, M=17, L=2, U=65535, ntasks=ntasks, tuning=tuning) as c:
         res, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in parts])
         st = c.stats()
     assert st["heavy_tasks"] > 0, st
+    assert (st["combine_pairs"] > 0) == (tuning is not None), st
     packed, off, lens = O.pack_reads(seqs)
     total = 0
     for r in range(R):
