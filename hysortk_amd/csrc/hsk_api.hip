@@ -956,7 +956,7 @@ static int synth_reads_impl(hsk_ctx *c, uint64_t genome_len, uint32_t read_len, 
     hipLaunchKernelGGL(synth_genome_kernel, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, c->stream, gw, nwords, seed);
     const u64 seed2 = splitmix64(seed ^ 0xabcdef12345ULL);
     const u32 err_thresh = (u32)std::min<double>(error_rate * 4294967296.0, 4294967295.0);
-    if (bytes) hipLaunchKernelGGL(synth_reads_kernel, dim3((u32)((bytes + 255) / 256)), dim3(256), 0, c->stream, gw, genome_len, read_len, nreads, seed2 + first_read, pk, err_thresh);
+    if (bytes) hipLaunchKernelGGL(synth_reads_kernel, dim3((u32)std::min<u64>((bytes + 255) / 256, 1u << 22)), dim3(256), 0, c->stream, gw, genome_len, read_len, nreads, seed2 + first_read, pk, err_thresh);
     hipLaunchKernelGGL(synth_index_kernel, dim3((u32)((nreads + 256) / 256)), dim3(256), 0, c->stream, roff, rlen, nreads, read_len);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

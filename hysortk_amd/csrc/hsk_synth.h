@@ -22,8 +22,8 @@ __device__ __forceinline__ u32 genome_base(const u64 *gw, u64 i) { return (u32)(
 __global__ void synth_reads_kernel(const u64 *gw, u64 genome_len, u32 read_len, u64 nreads, u64 seed2, u8 *packed, u32 err_thresh = 0)
 {
     const u32 nb = (read_len + 3) >> 2;
-    const u64 byte = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (byte >= nreads * nb) return;
+    // (a grid of one lane per byte ends at 2^32 lanes = 17 Gbp: the lanes stride)
+    for (u64 byte = (u64)blockIdx.x * blockDim.x + threadIdx.x; byte < nreads * nb; byte += (u64)gridDim.x * blockDim.x) {
     const u64 r = byte / nb;
     const u32 jb = (u32)(byte - r * nb);
     const u64 h = splitmix64(seed2 + r);
@@ -41,6 +41,7 @@ __global__ void synth_reads_kernel(const u64 *gw, u64 genome_len, u32 read_len, 
         out |= base << (6 - 2 * b);
     }
     packed[byte] = (u8)out;
+    }
 }
 
 __global__ void synth_index_kernel(u64 *roff, u32 *rlen, u64 nreads, u32 read_len)
