@@ -539,6 +539,8 @@ extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packe
     *stage = packed_bytes;
     HIPCHK(c, hipMemcpyAsync(roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
     int rc = dispatch_pipeline(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, rid_base, out);
+    if (timing_enabled()) fprintf(stderr, "[hsk] device pool: %.2f GB live, %.2f GB cached (mapped %.2f GB), peak live %.2f GB\n", c->pool.bytes_live / 1e9, c->pool.bytes_cached / 1e9,
+                                  (c->pool.bytes_live + c->pool.bytes_cached) / 1e9, c->pool.peak / 1e9);
     c->pool.release(roff);
     return rc;
 }

@@ -259,6 +259,7 @@ struct ProcExtra {
     bool force_batch = false;                              // every task through the batch kernels (partial batches padded)
     const std::vector<HeavyIn> *heavy_in = nullptr;        // merged and filtered here (they have no supermers)
     u32 vt_shift = 0;                                      // item-mode store: minimizer bits the parse's virtual tasks have consumed (a segment's virtual task: ExpSeg::byte_off)
+    SupermerStore *items_store = nullptr;                  // item-mode store of one GPU: its items go back to the pool as soon as the bucket order has read them
 };
 
 // Everything after the supermers of the owned tasks are in place: per task expand, sort, count; then the
@@ -376,6 +377,21 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         if (batch) for (int sl = 0; sl < nslot; ++sl) DALLOC(c, d_ghist_slot[sl], u64 *, (size_t)XCD_BATCH * MAX_PASSES * 256 * 8);
         return HSK_OK;
     };
+    // The bucket order of ALL owned tasks comes before the sort buffers are allocated: once its scatter is enqueued nobody reads the item store
+    // again, and its 21 GB (10 Gbp) go back to the pool: the call's peak of live device memory 68 -> 46 GB (HSK_TIMING prints the pool's state;
+    // what the pool has MAPPED stays at 89 GB -- it hands a cached block only to requests of nearly its size -- and that, mapped for the first
+    // time, is what a process's first call pays for).
+    if (combine && !fed_combine) {
+        pt.begin(PH_EXTRACT);
+        int rc = bucket_order_tasks(c, ntasks, segs, mine, x_src, ex ? ex->vt_shift : 0, border); if (rc) return rc;
+        pt.end(PH_EXTRACT);
+        if (!border.active) { c->combine_veto = true; return retry_plan("no bucket order"); }
+        if (ex && ex->items_store) {                      // (stream-ordered reuse: every later user of these blocks is enqueued behind the scatter)
+            SupermerStore &is = *ex->items_store;
+            c->pool.release(is.sm_item); is.sm_item = nullptr; c->pool.release(is.sm_sub); is.sm_sub = nullptr;
+            c->pool.release(is.d_bitems); is.d_bitems = nullptr; is.n_bitems = 0; for (void *&q : is.bin_aux) { c->pool.release(q); q = nullptr; }
+        }
+    }
     {
         int arc = alloc_sort_buffers();
         if (!arc && feeder && test_fail(c, "sortbuf")) arc = fail(c, HSK_ERR_OOM, "sort buffers (injected)");
@@ -598,12 +614,6 @@ static int process_rank(hsk_ctx *c, u32 ntasks, const std::vector<int32_t> &owne
         }
         return HSK_OK;
     };
-    if (combine && !fed_combine) {
-        pt.begin(PH_EXTRACT);
-        int rc = bucket_order_tasks(c, ntasks, segs, mine, x_src, ex ? ex->vt_shift : 0, border); if (rc) return rc;
-        pt.end(PH_EXTRACT);
-        if (!border.active) { c->combine_veto = true; return retry_plan("no bucket order"); }
-    }
     u64 comb_pairs = 0, comb_kmers = 0;                   // pairs the combining extraction has written / k-mers they stand for (this call)
     size_t pos = 0;
     const size_t nbatch = batch ? mine.size() / XCD_BATCH : 0;
@@ -1105,7 +1115,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
         for (auto &to : hlists) free_task_out(c, to);
     }
     pt.end(PH_EXCH);
-    ProcExtra ex; ex.heavy_in = &hin; ex.vt_shift = vts;
+    ProcExtra ex; ex.heavy_in = &hin; ex.vt_shift = vts; if (nranks == 1 && st.sm_item) ex.items_store = &st;
     const std::vector<void *> before_rank = (fed && c->comm.active()) ? c->pool.snapshot() : std::vector<void *>();
     int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
     if (fed && feeder.live) {
