@@ -43,6 +43,7 @@
 
 using namespace hsk;
 
+#include "hsk_pool.h"
 #include "hsk_host_ctx.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -142,6 +143,7 @@ extern "C" int hsk_init(const hsk_config *cfg, hsk_ctx **out)
     c->cfg.tuning = nullptr;                                      // (the caller's string is not kept)
     g_tune = &c->tune;
     memset(&c->stats, 0, sizeof c->stats);
+    c->pool.be_malloc = pool_hip_malloc; c->pool.be_free = pool_hip_free;
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HSK_ERR_HIP; }
@@ -540,7 +542,7 @@ extern "C" int hsk_count_device(hsk_ctx *c, const void *d_packed, uint64_t packe
     HIPCHK(c, hipMemcpyAsync(roff + nreads, stage, 8, hipMemcpyHostToDevice, c->stream));
     int rc = dispatch_pipeline(c, (const u8 *)d_packed, packed_bytes, roff, (const u32 *)d_len, nreads, rid_base, out);
     if (timing_enabled()) fprintf(stderr, "[hsk] device pool: %.2f GB live, %.2f GB cached (mapped %.2f GB), peak live %.2f GB\n", c->pool.bytes_live / 1e9, c->pool.bytes_cached / 1e9,
-                                  (c->pool.bytes_live + c->pool.bytes_cached) / 1e9, c->pool.peak / 1e9);
+                                  c->pool.bytes_mapped() / 1e9, c->pool.peak / 1e9);
     c->pool.release(roff);
     return rc;
 }

@@ -5,61 +5,9 @@
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-struct DevPool {
-    // freed blocks are kept and reused (hipMalloc/hipFree of multi-GB buffers costs milliseconds
-    // and synchronises the device); exact-fit-or-slightly-larger reuse, trimmed on OOM/destroy.
-    std::multimap<size_t, void *> free_blocks;
-    std::map<void *, size_t> live;
-    size_t bytes_live = 0, bytes_cached = 0, peak = 0;
-    void *alloc(size_t bytes)
-    {
-        if (bytes == 0) bytes = 256;
-        bytes = (bytes + 255) & ~(size_t)255;
-        auto it = free_blocks.lower_bound(bytes);
-        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
-            void *p = it->second; size_t sz = it->first;
-            free_blocks.erase(it); bytes_cached -= sz;
-            live[p] = sz; bytes_live += sz; peak = std::max(peak, bytes_live);
-            return p;
-        }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            trim();
-            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        }
-        live[p] = bytes; bytes_live += bytes; peak = std::max(peak, bytes_live);
-        return p;
-    }
-    void release(void *p)
-    {
-        if (!p) return;
-        auto it = live.find(p);
-        if (it == live.end()) return;
-        free_blocks.insert({it->second, p}); bytes_cached += it->second; bytes_live -= it->second;
-        live.erase(it);
-    }
-    void trim()
-    {
-        for (auto &kv : free_blocks) (void)hipFree(kv.second);
-        free_blocks.clear(); bytes_cached = 0;
-    }
-    void destroy()
-    {
-        trim();
-        for (auto &kv : live) (void)hipFree(kv.first);
-        live.clear(); bytes_live = 0;
-    }
-    // Error paths return early (DALLOC / HIPCHK) without releasing what the call had allocated so far: the entry points take
-    // a snapshot of the live blocks and, when the call fails, hand everything allocated since back to the pool.
-    std::vector<void *> snapshot() const { std::vector<void *> v; v.reserve(live.size()); for (auto &kv : live) v.push_back(kv.first); return v; }
-    void release_all_but(const std::vector<void *> &keep)        // keep: sorted (map order)
-    {
-        std::vector<void *> drop;
-        for (auto &kv : live) if (!std::binary_search(keep.begin(), keep.end(), kv.first)) drop.push_back(kv.first);
-        for (void *p : drop) release(p);
-    }
-};
+// (the device memory pool: hsk_pool.h -- segments of the regions hipMalloc returned, best fit with split and coalesce)
+static int pool_hip_malloc(void **p, size_t n) { if (hipMalloc(p, n) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return 1; } return 0; }
+static int pool_hip_free(void *p) { return hipFree(p) == hipSuccess ? 0 : 1; }
 
 // pinned host memory for results (hipHostMalloc of gigabytes takes longer than counting them: freed result blocks are kept)
 struct HostPool {
