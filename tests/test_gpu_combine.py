@@ -149,6 +149,8 @@ def test_first_call_on_clean_deep_reads_takes_the_combining_extraction(how):
 def test_first_call_never_starts_a_plan_the_input_does_not_pay_for(spec, why, how):
     """A real client calls kmer_count() once (reference src/hysortk.cpp:36-96): the FIRST call on a fresh context must already take the
     instance path for inputs with too few copies per k-mer -- combine_kernel is never launched -- and give the same list."""
+    if how == "pinned" and spec.get("error_rate") == 0.75:
+        pytest.skip("uniform reads (as many entries as k-mers: 12 s per case) once, from device memory")
     sp = dict(BIG, calls=[how], **spec)
     r = run(sp, {})[0]
     ref = run(dict(sp, calls=["device"]), {"HSK_COMBINE": "0", "HSK_PLAN_SAMPLE": "0"})[0]
