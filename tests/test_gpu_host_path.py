@@ -109,31 +109,39 @@ def test_pinned_input_with_gaps_between_reads():
 @pytest.mark.parametrize("K,EXT", [(31, 0), (51, 0), (31, 1)])
 def test_slab_ingest_equals_reads_in_place(K, EXT):
     """Pinned input above 32 MB: the packed reads arrive as DMA copies slab by slab while the scan hashes the slabs before
-    (HSK_H2D_SLABS=8 by default, 3 here as well; the last slab is short and a read straddles every slab edge); =0: the scan reads
-    the host buffer in place as in round 2.  Same list, same histogram, and equal to the pageable path.  Subprocesses: the
-    switch is read once."""
-    import subprocess, sys, os
+    (h2d_slabs: 16 by default, 3 and 8 here as well; the last slab is short and a read straddles every slab edge); =0: the scan reads
+    the host buffer in place as in round 2.  Same list, same histogram, and equal to the pageable path.  One context per setting, in this
+    process (the switches are per-context tuning names since round 4; rounds 2 - 3 started a process per setting)."""
+    import hashlib
+    import hysortk_amd as H
+    from hysortk_amd import synth
     from tests import util
-    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import hysortk_amd as H\n"
-            "from hysortk_amd import synth\n"
-            "n = (1 << 20) + 77777\n"
-            "packed, off, lens = synth.packed_reads(2000000, 150, n, 21)\n"
-            "pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)\n"
-            "pp[:] = packed; po[:] = off; pl[:] = lens\n"
-            "c = H.Context(K=%d, M=17, L=2, U=200, EXT=%d, ntasks=16)\n"
-            "for src in ((pp, po, pl), (packed, off, lens), (pp, po, pl)):\n"
-            "    r = c.count(src)\n"
-            "    pay = b'' if r.pos is None else np.sort(r.pos.astype(np.uint64) | (r.rid.astype(np.uint64) << np.uint64(32))).tobytes()\n"
-            "    print(hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes() + pay).hexdigest(), len(r))\n") % (util.ROOT, K, EXT)
+    n = (1 << 20) + 77777
+    packed, off, lens = synth.packed_reads(2000000, 150, n, 21)
+    pp, po, pl = H.pinned_empty(packed.size, np.uint8), H.pinned_empty(off.size, np.uint64), H.pinned_empty(lens.size, np.uint32)
+    pp[:] = packed; po[:] = off; pl[:] = lens
     outs = []
-    # ({}: ingest, scan and placement as one pipeline, the store laid out [slab][task]; HSK_INGEST_PIPELINE=0: slab ingest, one placement;
+    # ({}: ingest, scan and placement as one pipeline, the store laid out [slab][task]; ingest_pipeline=0: slab ingest, one placement;
     #  a record capacity of 300 makes some tile overflow: both fall back to the general parse kernels with the reads already in HBM)
     envs = ({}, {"HSK_H2D_SLABS": "3"}, {"HSK_H2D_SLABS": "0"}, {"HSK_H2D_SLABS": "8", "HSK_PARSE_REC_CAP": "300"}, {"HSK_INGEST_PIPELINE": "0"},
             {"HSK_INGEST_PIPELINE": "0", "HSK_PARSE_REC_CAP": "300"})
     if EXT:
         envs = envs[:1] + envs[2:3]                              # (payloads take the slab ingest without the placement pipeline: default and in-place suffice)
-    for env in envs:
-        outs += [l.split() for l in subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **util.tune_env(env))).decode().strip().splitlines()]
+    try:
+        for env in envs:
+            with H.Context(K=K, M=17, L=2, U=200, EXT=EXT, ntasks=16, tuning=util.tuning(env)) as c:
+                for src in ((pp, po, pl), (packed, off, lens), (pp, po, pl)):
+                    r = c.count(src)
+                    pay = b""
+                    if r.pos is not None:                    # (the payloads of a k-mer come in any order: an order-independent digest per list)
+                        x = r.pos.astype(np.uint64) | (r.rid.astype(np.uint64) << np.uint64(32))
+                        with np.errstate(over="ignore"):
+                            pay = np.array([(x * np.uint64(0x9E3779B97F4A7C15)).sum(dtype=np.uint64), np.bitwise_xor.reduce(x), x.size], dtype=np.uint64).tobytes()
+                    outs.append((hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes() + pay).hexdigest(), len(r)))
+                    del r
+    finally:
+        for x in (pp, po, pl):
+            H.pinned_free(x)
     assert len(outs) == 3 * len(envs) and len({o[0] for o in outs}) == 1, outs
     assert int(outs[0][1]) > 100000
 
