@@ -7,10 +7,11 @@ import hysortk_amd as H
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 pcts = [float(x) for x in sys.argv[2:]] or [0.0, 0.5, 2.0]
+EXT = int(os.environ.get("SKEW_EXT", "0"))
 KK = int(os.environ.get("SKEW_K", "31")); PLAN = os.environ.get("SKEW_PLAN") or None; RANKS = int(os.environ.get("SKEW_RANKS", "1"))
 RL = 150
 G = int(312_500_000 * scale); NR = G * 32 // RL
-ctx = H.Context(K=KK, M=17, L=15, U=40, ntasks=0 if RANKS == 1 else 40 * RANKS, profile=True, keep_device=True, plan=PLAN)
+ctx = H.Context(K=KK, M=17, L=15, U=40, EXT=EXT, ntasks=0 if RANKS == 1 else 40 * RANKS, profile=True, keep_device=True, plan=PLAN)
 dp, nb, do, dl = ctx.synth_reads(G, RL, NR, 7)
 packed = H.pinned_empty(nb, np.uint8); ctx.d2h_into(packed, dp, nb)
 off = H.pinned_empty(NR, np.uint64); lens = H.pinned_empty(NR, np.uint32)
