@@ -157,6 +157,7 @@ static void bins_args(hsk_ctx *, ParseArgs &a, const ScanBins &b) { a.bins = b.d
 // the store takes the bins over: items and minimizer bits where they are, the bucket order's work list from the chunk lists
 static int bins_to_store(hsk_ctx *c, ScanBins &b, SupermerStore &st, u32 nvt, u32 vt_shift, hipStream_t stream);
 
+constexpr u64 SLAB_HEAD = 4096;                    // bytes at the start of an ingest slab that the scan of the slab before it reads (>= (PARSE_WORDS - 128) * 4 + the prefetch's reach)
 struct ParseJob {
     ParseArgs a; u32 nblocks = 0, ntasks = 0; bool fast = false, empty = true;
     const u64 *d_roff = nullptr; u64 nreads = 0; int64_t rid_base = 0;
@@ -272,17 +273,22 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             // the parse takes about as long as the transfer (a kernel reading the host buffer in place gets ~40 GB/s out of the link,
             // the DMA engine ~55).
             EvList evs(c);
-            std::vector<hipEvent_t> landed(a.nslabs);
+            std::vector<hipEvent_t> landed(a.nslabs), head(a.nslabs);      // (head: the first SLAB_HEAD bytes of a slab -- all the scan of the slab before it needs of it)
             EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, c->d2h_stream); }
             for (u32 sl = 0; sl < a.nslabs; ++sl) {
                 const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
-                if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, c->d2h_stream));
+                const u64 bh = std::min<u64>(b0 + SLAB_HEAD, b1);
+                if (bh > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, bh - b0, hipMemcpyHostToDevice, c->d2h_stream));
+                head[sl] = evs.get();
+                HIPCHK(c, hipEventRecord(head[sl], c->d2h_stream));
+                if (b1 > bh) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + bh, h2d_src + bh, b1 - bh, hipMemcpyHostToDevice, c->d2h_stream));
                 landed[sl] = evs.get();
                 HIPCHK(c, hipEventRecord(landed[sl], c->d2h_stream));
             }
             if (profile) { (void)hipEventRecord(hp.b, c->d2h_stream); c->ev_pending.push_back(hp); }
             for (u32 sl = 0; sl < a.nslabs; ++sl) {
-                HIPCHK(c, hipStreamWaitEvent(c->stream, landed[std::min(sl + 1, a.nslabs - 1)], 0));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, landed[sl], 0));
+                if (sl + 1 < a.nslabs) HIPCHK(c, hipStreamWaitEvent(c->stream, head[sl + 1], 0));
                 a.slab = sl;
                 launch_scan();
             }
@@ -520,11 +526,18 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     hipEvent_t ready = evs.get();                                          // the small buffers above are set up; the second stream may start
     HIPCHK(c, hipEventRecord(ready, sA));
     HIPCHK(c, hipStreamWaitEvent(sB, ready, 0));
-    std::vector<hipEvent_t> landed(nsl), scanned(nsl);
+    // A slab's scan reaches PARSE_WORDS - 128 words into the NEXT slab (the windows of its last k-mers), not further: every slab's first
+    // SLAB_HEAD bytes travel as a copy of their own with an event (`head`), and the scan of slab s waits for slab s and for the head of slab
+    // s + 1 -- not for all of slab s + 1 (the first scan started after two slabs, 5.6 ms into the call; now after one)
+    std::vector<hipEvent_t> landed(nsl), head(nsl), scanned(nsl);
     EvPair hp{}; if (profile) { hp.a = ev_get(c); hp.b = ev_get(c); hp.kind = 5; (void)hipEventRecord(hp.a, sC); }
     for (u32 sl = 0; sl < nsl; ++sl) {
         const u64 b0 = std::min<u64>((u64)sl * a.slab_tiles * (PARSE_TILE / 4), packed_bytes), b1 = std::min<u64>(((u64)sl + 1) * a.slab_tiles * (PARSE_TILE / 4), packed_bytes);
-        if (b1 > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, b1 - b0, hipMemcpyHostToDevice, sC));
+        const u64 bh = std::min<u64>(b0 + SLAB_HEAD, b1);
+        if (bh > b0) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + b0, h2d_src + b0, bh - b0, hipMemcpyHostToDevice, sC));
+        head[sl] = evs.get();
+        HIPCHK(c, hipEventRecord(head[sl], sC));
+        if (b1 > bh) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed) + bh, h2d_src + bh, b1 - bh, hipMemcpyHostToDevice, sC));
         landed[sl] = evs.get();
         HIPCHK(c, hipEventRecord(landed[sl], sC));
     }
@@ -534,7 +547,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
                    pp.a = ev_get(c); pp.b = ev_get(c); pp.kind = 4; (void)hipEventRecord(pp.a, sB); }
     const bool scan_generic = tune("scan_generic", 0) != 0;
     for (u32 sl = 0; sl < nsl; ++sl) {
-        HIPCHK(c, hipStreamWaitEvent(sA, landed[std::min(sl + 1, nsl - 1)], 0));
+        HIPCHK(c, hipStreamWaitEvent(sA, landed[sl], 0));
+        if (sl + 1 < nsl) HIPCHK(c, hipStreamWaitEvent(sA, head[sl + 1], 0));
         a.slab = sl; a.blk_cnt = d_blk_cnt + (size_t)sl * mat * 3;
         if (a.bins) {
             if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
