@@ -1079,3 +1079,29 @@ def test_output_text_formatted_on_device(H, O, K, tmp_path):
     g = open(tmp_path / "g" / "0.out", "rb").read()
     h = open(tmp_path / "h" / "0.out", "rb").read()
     assert g == h and g.count(b"\n") == len(kl)
+
+
+def test_eighty_gbp_on_one_gpu(H):
+    """The whole input of BASELINE configs[2] (80 Gbp: 6.4e10 31-mers, 304 tasks) in ONE call on one GPU, unfiltered, the 2.5e9-entry list
+    left in HBM (205 GB of the 288 GB live at the peak).  Size-independent properties: total_kmers, the count histogram adds up to the number
+    of k-mers and to the number of entries, the entries are the genome's distinct positions (bar a handful of chance repeats), and a second
+    call gives the same histogram."""
+    G, RL = 2_500_000_000, 150
+    NR = G * 32 // RL
+    total = NR * (RL - 31 + 1)
+    with H.Context(K=31, M=17, L=1, U=65535, ntasks=0, keep_device=True) as c:
+        try:
+            dp, nb, do, dl = c.synth_reads(G, RL, NR, 424242)
+        except H.HskError as e:
+            pytest.skip("no room for 20 GB of synthetic reads: %s" % e)
+        hs = []
+        for _ in range(2):
+            r = c.count_device(dp, nb, do, dl, NR)
+            h = np.asarray(r.histo, dtype=np.uint64)
+            assert int(r.info["total_kmers"]) == total
+            assert int((h * np.arange(h.size, dtype=np.uint64)).sum(dtype=np.uint64)) == total and int(h.sum(dtype=np.uint64)) == int(r.info["n"])
+            assert abs(int(r.info["n"]) - (G - 31 + 1)) < 1000
+            hs.append(h.copy())
+            del r
+        assert np.array_equal(hs[0], hs[1])
+        c.synth_free(dp, do, dl)
