@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (N = 1)")
     ap.add_argument("--no-variants", action="store_true", help="skip the legs of the other record shapes and plans (N = 1)")
-    ap.add_argument("--legs", default="", help="comma-separated: run only these of the informational legs (variant names, multi_rank, first_calls); default all")
+    ap.add_argument("--legs", default="", help="comma-separated: run only these of the informational legs (variant names, multi_rank, large, first_calls); default all")
     ap.add_argument("--error-rate", type=float, default=0.0, help="substitution errors per base in the synthetic reads (informational runs; the headline workload is error-free)")
     ap.add_argument("--ext", type=int, default=0)
     ap.add_argument("--k", type=int, default=31, help="k-mer size (informational runs; the headline metric is K=31)")
@@ -265,6 +265,31 @@ def run_variant(H, local, name, note, KK, ext, plan, Lv, Uv, genome_len, nreads,
         out["reference_algorithm_frac_of_hbm_peak"] = out["reference_algorithm_GBs"] / HBM_PEAK_GBS
         out["reference_algorithm_bytes_per_kmer"] = ref_bytes_per_kmer
     return out
+
+
+def large_input_leg(H, local, gbp, seed):
+    """The whole input of BASELINE configs[2] (80 Gbp: what the 8-GPU configuration counts) in ONE call on ONE GPU, same L / U as the headline, the
+    list left in HBM: what 288 GB of HBM hold.  One untimed call (the pools grow), two timed ones."""
+    G = int(gbp * 1e9) // COVERAGE
+    NR = G * COVERAGE // READ_LEN
+    ctx = H.Context(K=K, M=M, L=L, U=U, device=local, profile=True, keep_device=True)
+    dp, nb, do, dl = ctx.synth_reads(G, READ_LEN, NR, seed)
+    r = ctx.count_device(dp, nb, do, dl, NR)
+    del r
+    ts, info = [], None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = ctx.count_device(dp, nb, do, dl, NR)
+        ts.append(time.perf_counter() - t0)
+        info = dict(r.info)
+        del r
+    ctx.synth_free(dp, do, dl)
+    ctx.close()
+    nk = NR * (READ_LEN - K + 1)
+    dt = sum(ts) / len(ts)
+    return {"name": "configs2_input_on_one_gpu", "what": "%.0f Gbp of reads (BASELINE configs[2]'s whole input) in one hsk_count_device call on one GPU" % gbp, "bases": NR * READ_LEN,
+            "packed_bytes": int(nb), "kmers": nk, "value": nk / dt, "unit": "k-mers/s", "ms_per_call": dt * 1e3, "entries": info.get("n"), "ntasks": info["ntasks"],
+            "phases_ms": {k_: round(v, 2) for k_, v in info.items() if k_.startswith("ms_")}}
 
 
 def first_call_leg(H, local, genome_len, nreads, seed):
@@ -639,6 +664,11 @@ def main():
                     out["multi_rank_path"].append(multi_rank_leg(H, local, mname, mk, mext, 8, int(mbp * a.scale), 320, seed + 7))
                 except Exception as e:
                     out["multi_rank_path"].append({"name": mname, "error": str(e)[:300]})
+        if world == 1 and not a.no_variants and a.scale == 1.0 and (not only or "large" in only):
+            try:
+                out["large_input"] = large_input_leg(H, local, 80.0, seed + 200)
+            except Exception as e:
+                out["large_input"] = {"error": str(e)[:300]}
         if world == 1 and not a.no_variants and (not only or "first_calls" in only):
             try:
                 out["first_calls"] = first_call_leg(H, local, int(GENOME_PER_GPU * a.scale) // 2, nreads // 2, seed + 100)

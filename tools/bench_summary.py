@@ -17,6 +17,12 @@ for v in d.get("variants", []):
     print("  variant %-15s %s" % (v["name"], {k: (round(v[k], 3) if isinstance(v[k], float) else v[k]) for k in ("value", "ms_per_step", "first_call_ms", "first_call_device_ms", "first_call_combine_launches", "entries", "error", "reference_algorithm_frac_of_hbm_peak") if k in v}), (v.get("scatter_pass") or {}).get("GBs"))
 for f in (d.get("first_calls") or []) if isinstance(d.get("first_calls"), list) else [d.get("first_calls")]:
     print("  first call", f if not isinstance(f, dict) or "input" not in f else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in f.items() if k in ("input", "after_other_input_ms", "steady_ms", "ratio", "combine_launches")})
+for m in d.get("multi_rank_path") or []:
+    if "error" in m: print("  multi_rank", m); continue
+    print("  multi_rank %-16s %5.1f ms per rank (device), %5.1f G k-mers/s per GPU outside the wire, combine launches %s" % (m["name"], m["per_rank_device_ms"]["mean"], m["per_gpu_rate_from_device_ms"] / 1e9, m.get("combine_launches")))
+if d.get("large_input"):
+    li = d["large_input"]
+    print("  large_input", li if "error" in li else "%s: %.1f G k-mers/s, %.0f ms per call, %d tasks, %d entries" % (li["what"], li["value"] / 1e9, li["ms_per_call"], li["ntasks"], li["entries"]))
 c = d.get("cpu_baseline", {})
 print("cpu", {k: c.get(k) for k in ("kind", "value", "cores", "seconds", "entries", "error")}, c.get("sample_check"))
 for l in c.get("layouts", []) or []:
