@@ -38,7 +38,7 @@ class Stats(C.Structure):
         ("hist_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("hist_ms", C.c_double),
         ("fused_tasks", C.c_int64), ("redone_tasks", C.c_int64),
         ("agg_launches", C.c_uint64), ("agg_bytes", C.c_uint64), ("agg_ms", C.c_double),
-        ("agg_retried_tasks", C.c_int64), ("parse_fallbacks", C.c_int64), ("heavy_tasks", C.c_int64), ("onepass_misses", C.c_int64),
+        ("agg_retried_tasks", C.c_int64), ("parse_fallbacks", C.c_int64), ("heavy_tasks", C.c_int64), ("dropped_kmers", C.c_int64),
         ("scan_launches", C.c_uint64), ("scan_bytes", C.c_uint64), ("scan_ms", C.c_double),
         ("place_launches", C.c_uint64), ("place_supermers", C.c_uint64), ("place_ms", C.c_double),
         ("host_syncs", C.c_uint64), ("host_waits_covered", C.c_uint64), ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),

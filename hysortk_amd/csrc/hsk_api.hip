@@ -248,8 +248,10 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     const bool enabled = tune("plan_sample", 1) != 0;
     constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 64ULL << 20;
     // who would use it: one-word keys without payload on one GPU (combining extraction or not, first table, aggregation or not)
-    if (!enabled || c->nw > 2 || c->cfg.kmer_size >= 64 || c->cfg.extension || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
-    if (c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT)) return HSK_OK;         // nothing to choose
+    if (!enabled || c->cfg.kmer_size >= 64 || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
+    // (payloads, three-word keys, pinned plans: nothing to choose -- the sketch still says which k-mers are certain to be dropped, `valid` stays false)
+    const bool plan_wanted = c->nw <= 2 && !c->cfg.extension && !(c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
+    if (!plan_wanted && (nranks > 1 || c->cfg.kmer_size > 57)) return HSK_OK;
     const auto t0 = std::chrono::steady_clock::now();
     u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);      // (10 Gbp: 40 MB of reads, ~4 M chosen k-mer instances: 1.2 ms of kernels)
     u64 lost = 0, n1 = 0, n2 = 0, n3 = 0, ds = 0, ns = 0, s_bytes = 0;
@@ -275,15 +277,16 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
         const u64 nthreads = (ea.positions + EST_SPAN - 1) / EST_SPAN;
         hipLaunchKernelGGL(estimate_insert_kernel, dim3((u32)((nthreads + EST_THREADS - 1) / EST_THREADS)), dim3(EST_THREADS), 0, c->stream, ea);
         hipLaunchKernelGGL(estimate_hist_kernel, dim3((u32)std::min<u64>(cap / EST_THREADS, 4096)), dim3(EST_THREADS), 0, c->stream, ea);
-        HIPCHK(c, hipMemcpyAsync(h_out, d_out, 48, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_out, d_out, 64, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
         release();                                                          // (stream-ordered reuse: the kernels above are done)
         lost = h_out[0]; n1 = h_out[1]; n2 = h_out[2]; n3 = h_out[3]; ds = h_out[4]; ns = h_out[5];
+        c->est.homo_at = h_out[6]; c->est.homo_cg = h_out[7];
         // shallow data (coverage below ~3): too few tripletons in 1/64 of the reads to tell the depth -- once more on sixteen times as many
         if (round == 0 && !lost && n2 >= 16 && n3 < 256 && want * 16 <= packed_bytes / 2 && want * 16 <= (512ULL << 20)) { want *= 16; continue; }
         break;
     }
-    if (lost || ns < (1u << 14)) return HSK_OK;                            // (no estimate)
+    if (lost || ns < (1u << 14) || !plan_wanted) return HSK_OK;            // (no estimate)
     PlanEstimate &e = c->est;
     // several ranks: the reads are dealt to the ranks, so this rank's sample is that much thinner a slice of the WHOLE input's depth (a rank of eight
     // that holds 4-fold coverage of its own counts 32-fold k-mers after the exchange)
@@ -314,7 +317,18 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
 {
     int rc;
     if (attempt == 0) { c->combine_left_now = false; c->pair_cap_full = false; }
-    if (attempt == 0) { rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, c->comm.active() ? c->comm.nranks : 1); if (rc) return rc; }
+    if (attempt == 0) {
+        rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, c->comm.active() ? c->comm.nranks : 1); if (rc) return rc;
+        // A k-mer with more than U copies inside the sample alone cannot be in the result: the scan leaves the instances of the all-A / all-C k-mer out
+        // where they are that many (poly-A, the poly-G reads of two-colour sequencers: one bucket, one bin, one task several times the others' size).
+        // One GPU (ranks would have to agree, and a rank whose parse falls back could not follow); from 2^16 copies on (below that nothing is gained).
+        c->drop_mask_now = 0;
+        const u64 dmin = std::max<u64>((u64)std::max(c->cfg.upper_freq, 0), 1ULL << 16);
+        if (!c->comm.active() && tune("drop_certain", 1) != 0 && c->cfg.kmer_size <= 57 && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M)
+            c->drop_mask_now = (c->est.homo_at > dmin ? 1u : 0u) | (c->est.homo_cg > dmin ? 2u : 0u);
+        if (c->drop_mask_now && timing_enabled()) fprintf(stderr, "[hsk] certain drops: the sample holds %llu copies of the all-A and %llu of the all-C k-mer (U = %d): mask %u\n",
+                                                           (unsigned long long)c->est.homo_at, (unsigned long long)c->est.homo_cg, c->cfg.upper_freq, c->drop_mask_now);
+    }
     c->plan_attempt = attempt;                          // (from the third attempt on run_pipeline does not consider the combining extraction at all)
     const std::vector<void *> before = c->pool.snapshot();
     const hsk_stats stats_before = c->stats;

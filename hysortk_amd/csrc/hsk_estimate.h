@@ -26,7 +26,8 @@ struct EstimateArgs {
     u64 positions;                                                       // 4 x sample bytes
     int k;
     unsigned long long *keys; u32 *cnts; u64 cap_mask;                   // table: key + 1 (0 = empty), count
-    unsigned long long *out;                                             // [0] inserts that found no slot, [1..3] n1 n2 n3, [4] distinct, [5] instances
+    unsigned long long *out;                                             // [0] inserts that found no slot, [1..3] n1 n2 n3, [4] distinct, [5] instances,
+                                                                         // [6] instances of the all-A k-mer (A or T runs), [7] of the all-C k-mer (C or G runs): EXACT counts inside the sample
 };
 
 __device__ __forceinline__ u64 est_find_read(const u64 *roff, u64 nreads, u64 byte)
@@ -51,6 +52,18 @@ __device__ __forceinline__ u32 est_insert(const EstimateArgs &a, u64 key, u32 co
     return 1;
 }
 
+// The two k-mers a read set can hold millions of times -- poly-A / poly-T tails and the poly-G reads of two-colour sequencers (canonical: all-A and
+// all-C) -- are counted EXACTLY inside the sample, whatever the hash slice: a k-mer with more than U copies in the sample alone is certain to be
+// dropped from the result, and the scan may leave its instances out (scan_kernel<.., DROP>).  lowmask: the bits of the k-mer's low word (K <= 32:
+// of the k-mer), hi: its high word (two-word k-mers; its mask is the caller's hmask passed as lowmask of the high word -- see the callers).
+__device__ __forceinline__ void est_homopolymer(const EstimateArgs &a, u64 hi, u64 lo, u64 mask_of_top, u32 copies)
+{
+    const bool wide = a.k > 32;
+    const u64 c_lo = wide ? 0x5555555555555555ULL : (0x5555555555555555ULL & mask_of_top), c_hi = wide ? (0x5555555555555555ULL & mask_of_top) : 0ULL;
+    if (hi == 0 && lo == 0) atomicAdd(&a.out[6], (unsigned long long)copies);
+    else if (hi == c_hi && lo == c_lo) atomicAdd(&a.out[7], (unsigned long long)copies);
+}
+
 // two-word k-mers (32 < K < 64): both strands rolled as {hi, lo} of a right-aligned 2K-bit number, the smaller one folded to 64 bits
 __device__ __forceinline__ void estimate_insert_wide(const EstimateArgs &a, u64 p0, u64 p1)
 {
@@ -73,10 +86,10 @@ __device__ __forceinline__ void estimate_insert_wide(const EstimateArgs &a, u64 
         const bool rc_less = rh < fh || (rh == fh && rl < fl);
         const u64 kh = rc_less ? rh : fh, kl = rc_less ? rl : fl;
         if (run && kh == run_h && kl == run_l) { ++run; continue; }      // (runs of one k-mer as one insert, as below)
-        if (run) lost += est_insert(a, (run_l ^ fmix64(run_h + 0x632be59bd9b4e019ULL)) & ~(1ULL << 63), run);      // (fingerprint; bit 63 cleared so that key + 1 never wraps to the empty marker)
+        if (run) { lost += est_insert(a, (run_l ^ fmix64(run_h + 0x632be59bd9b4e019ULL)) & ~(1ULL << 63), run); est_homopolymer(a, run_h, run_l, hmask, run); }      // (fingerprint; bit 63 cleared so that key + 1 never wraps to the empty marker)
         run_h = kh; run_l = kl; run = 1;
     }
-    if (run) lost += est_insert(a, (run_l ^ fmix64(run_h + 0x632be59bd9b4e019ULL)) & ~(1ULL << 63), run);
+    if (run) { lost += est_insert(a, (run_l ^ fmix64(run_h + 0x632be59bd9b4e019ULL)) & ~(1ULL << 63), run); est_homopolymer(a, run_h, run_l, hmask, run); }
     if (lost) atomicAdd(&a.out[0], (unsigned long long)lost);
 }
 
@@ -109,10 +122,10 @@ __global__ __launch_bounds__(EST_THREADS) void estimate_insert_kernel(EstimateAr
         //  that k-mer the whole sketch: 36 ms instead of 1.2)
         const u64 key = rc < fw ? rc : fw;
         if (run && key == run_key) { ++run; continue; }
-        if (run) lost += est_insert(a, run_key, run);
+        if (run) { lost += est_insert(a, run_key, run); est_homopolymer(a, 0, run_key, kmask, run); }
         run_key = key; run = 1;
     }
-    if (run) lost += est_insert(a, run_key, run);
+    if (run) { lost += est_insert(a, run_key, run); est_homopolymer(a, 0, run_key, kmask, run); }
     if (lost) atomicAdd(&a.out[0], (unsigned long long)lost);
 }
 

@@ -61,6 +61,7 @@ struct PlanEstimate {
     double lambda_sample = 0;          // mean copies per genomic k-mer inside the sample
     double fraction = 0;               // sample bytes / input bytes
     u64 sample_kmers = 0, n1 = 0, n2 = 0, n3 = 0, distinct_sample = 0;
+    u64 homo_at = 0, homo_cg = 0;      // exact copies of the all-A / all-C k-mer inside the sample (valid even where `valid` is not: payloads, wide keys)
     double ms = 0;                     // host wall clock of the estimate
 };
 
@@ -128,6 +129,8 @@ struct hsk_ctx {
     // to 64: a look costs the call ~2 x, reads with errors should not pay that every eighth call); back to 8 once a call has gone through
     int combine_off_period = 8, combine_good_calls = 0;
     bool combine_left_now = false;     // ... during THIS call (binding for the attempts that follow, whatever the estimate said)
+    u32 drop_mask_now = 0;             // this call: bit 0 / 1 = the all-A / all-C k-mer has more than U copies inside the sample alone, the scan leaves its instances out
+    u64 dropped_now = 0;               // ... and how many it left out (they count as k-mers of the input: hsk_result::total_kmers)
     void leave_combine() { combine_left_now = true; combine_off_period = combine_good_calls ? 8 : std::min(combine_off_period * 2, 64); combine_good_calls = 0; combine_off = true; combine_off_calls = 0; }
     bool item_mode_now = false;        // ... on ONE GPU: the store holds items (several ranks: byte runs + minimizer bits, items built by the owners)
     u32 vt_shift = 0;                  // this call's parse splits every task into 1 << vt_shift virtual tasks (combining extraction)

@@ -164,6 +164,7 @@ struct ParseJob {
     u64 *d_blk_cnt = nullptr; u16 *d_dest_cache = nullptr; u32 *d_tile_rec = nullptr, *d_tile_nrec = nullptr, *d_overflow = nullptr;
     u32 *d_tile_r0 = nullptr;     // EXTENSION: first read of every tile (hint for the (pos, rid) lookup)
     u32 *d_tile_sub = nullptr;    // combining extraction: minimizer bits of every record
+    unsigned long long *d_dropped = nullptr;      // scan_kernel<.., DROP>: positions left out (hsk_ctx::drop_mask_now)
     ScanBins bins;                // ... or no records at all: scan_kernel places the items itself
     std::vector<u64> task_tot;    // [ntasks][3] supermers, bytes, kmers of this rank
 };
@@ -172,6 +173,7 @@ static void parse_release(hsk_ctx *c, ParseJob &j)
 {
     c->pool.release(j.d_blk_cnt); c->pool.release(j.d_dest_cache); c->pool.release(j.d_tile_rec); c->pool.release(j.d_tile_nrec); c->pool.release(j.d_overflow);
     c->pool.release(j.d_tile_r0); j.d_tile_r0 = nullptr; c->pool.release(j.d_tile_sub); j.d_tile_sub = nullptr;
+    c->pool.release(j.d_dropped); j.d_dropped = nullptr;
     bins_release(c, j.bins);
     j.d_blk_cnt = nullptr; j.d_dest_cache = nullptr; j.d_tile_rec = j.d_tile_nrec = j.d_overflow = nullptr;
 }
@@ -258,8 +260,12 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         if (c->zc_src) { a.packed = c->zc_src; a.packed_copy = (u32 *)const_cast<u8 *>(d_packed); }      // ingest fused into the scan
         EvPair ep{}; if (profile) { ep.a = ev_get(c); ep.b = ev_get(c); ep.kind = 3; ep.bytes = packed_bytes; (void)hipEventRecord(ep.a, c->stream); }
         const bool scan_generic = tune("scan_generic", 0) != 0;      // (tests: the default (k, m) through the generic instance)
+        c->dropped_now = 0;
+        a.drop_mask = bins ? 0u : c->drop_mask_now;
+        if (a.drop_mask) { DALLOC(c, j.d_dropped, unsigned long long *, 256); HIPCHK(c, hipMemsetAsync(j.d_dropped, 0, 8, c->stream)); a.dropped = j.d_dropped; }
         auto launch_scan = [&]() {
-            if (a.bins) {
+            if (a.drop_mask) hipLaunchKernelGGL((scan_kernel<0, 0, false, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+            else if (a.bins) {
                 if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
                 else hipLaunchKernelGGL((scan_kernel<0, 0, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
             }
@@ -300,8 +306,10 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         HIPCHK(c, hipMemcpyAsync(h_ovf, j.d_overflow, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
         if (j.bins.items) HIPCHK(c, hipMemcpyAsync(h_ovf + 2, j.bins.ctl, 4, hipMemcpyDeviceToHost, c->stream));
+        if (j.d_dropped) HIPCHK(c, hipMemcpyAsync(h_ovf + 4, j.d_dropped, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
+        if (j.d_dropped) c->dropped_now = *(const unsigned long long *)(h_ovf + 4);
         if (j.bins.items) j.bins.nchunks = std::min(h_ovf[2], j.bins.cap);
         bool gaps = c->roff_bad; c->roff_bad = false;
         if (c->roff_check.valid() && !c->roff_check.get()) gaps = true;
@@ -332,6 +340,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return retry_plan("a tile beyond the record capacity"); }      // (the general kernels know no virtual tasks: the call again, without them)
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
+            c->dropped_now = 0;                                       // (the general kernels count every position again, the certain drops included: they are filtered at the end as ever)
             if (a.nslabs > 1) {                                       // the general kernels know one tile range per workgroup
                 ParseArgs b = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
                 b.blk_cnt = a.blk_cnt; b.rec_cap = a.rec_cap; b.place_group = a.place_group;
@@ -496,6 +505,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     if (!bins && c->combine_now && a.rec_cap <= PLACE_ITEM_REC) DALLOC(c, d_tile_sub, u32 *, (size_t)a.ntiles * a.rec_cap * 4 + 64);
     if (bins) { int brc = bins_alloc(c, sbins, ntasks, packed_bytes, nreads, c->cfg.kmer_size - c->cfg.minimizer_size + 1, c->stream); if (brc) return brc; }
     u64 *d_ps; DALLOC(c, d_ps, u64 *, (size_t)PS_SEGS * ntasks * 3 * 8);
+    unsigned long long *d_dropped = nullptr;                                // scan_kernel<.., DROP>: positions left out (hsk_ctx::drop_mask_now)
     // the store holds at most rec_cap supermers per tile (a tile beyond that falls back); its real size is known when the last slab is in
     const u64 cap_sup = a.ntiles * (u64)a.rec_cap;
     st = SupermerStore();
@@ -505,7 +515,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     else { DALLOC(c, st.sm_len, u8 *, cap_sup + 64); DALLOC(c, st.sm_gpos, u64 *, cap_sup * 8 + 64); }
     auto release_all = [&]() {
         bins_release(c, sbins);
-        c->pool.release(d_tile_sub); c->pool.release(d_ps);
+        c->pool.release(d_tile_sub); c->pool.release(d_ps); c->pool.release(d_dropped);
         c->pool.release(d_blk_cnt); c->pool.release(d_blk_base); c->pool.release(d_tot); c->pool.release(d_task_base); c->pool.release(d_run);
         c->pool.release(d_order); c->pool.release(d_tile_rec); c->pool.release(d_tile_nrec); c->pool.release(d_overflow);
     };
@@ -522,6 +532,9 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     a.tile_sub = d_tile_sub; a.sm_sub = st.sm_sub; a.sm_item = st.sm_item;
     if (d_tile_sub) a.place_group = std::max<u32>(1, std::min<u32>(PLACE_ITEM_TILES, PLACE_ITEM_REC / a.rec_cap));
     if (bins) bins_args(c, a, sbins);
+    c->dropped_now = 0;
+    a.drop_mask = bins ? 0u : c->drop_mask_now;
+    if (a.drop_mask) { DALLOC(c, d_dropped, unsigned long long *, 256); HIPCHK(c, hipMemsetAsync(d_dropped, 0, 8, sA)); a.dropped = d_dropped; }
     EvList evs(c);
     hipEvent_t ready = evs.get();                                          // the small buffers above are set up; the second stream may start
     HIPCHK(c, hipEventRecord(ready, sA));
@@ -550,7 +563,8 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
         HIPCHK(c, hipStreamWaitEvent(sA, landed[sl], 0));
         if (sl + 1 < nsl) HIPCHK(c, hipStreamWaitEvent(sA, head[sl + 1], 0));
         a.slab = sl; a.blk_cnt = d_blk_cnt + (size_t)sl * mat * 3;
-        if (a.bins) {
+        if (a.drop_mask) hipLaunchKernelGGL((scan_kernel<0, 0, false, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
+        else if (a.bins) {
             if (a.k == 31 && a.m == 17 && !scan_generic) hipLaunchKernelGGL((scan_kernel<31, 17, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
             else hipLaunchKernelGGL((scan_kernel<0, 0, true>), dim3(nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, sA, a);
         }
@@ -576,6 +590,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     HIPCHK(c, hipMemcpyAsync(h_flags, d_overflow, 4, hipMemcpyDeviceToHost, sB));
     HIPCHK(c, hipMemcpyAsync(h_flags + 1, c->d_err, 4, hipMemcpyDeviceToHost, sB));
     if (bins) HIPCHK(c, hipMemcpyAsync(h_flags + 2, sbins.ctl, 4, hipMemcpyDeviceToHost, sB));
+    if (d_dropped) HIPCHK(c, hipMemcpyAsync(h_flags + 4, d_dropped, 8, hipMemcpyDeviceToHost, sB));      // (sB is behind every scan: placed / scanned events)
     HIPCHK(c, hipMemcpyAsync(staged ? h_tot : tot.data(), d_tot, (size_t)nsl * ntasks * 24, hipMemcpyDeviceToHost, sB));
     hipEvent_t placed = evs.get();
     HIPCHK(c, hipEventRecord(placed, sB));
@@ -588,6 +603,7 @@ static int parse_ingest_pipelined(hsk_ctx *c, const u8 *h2d_src, const u8 *d_pac
     if (c->index_unchecked && (h_flags[1] & 32u)) fallback = true;          // (parse_count reports it)
     if (bins && (h_flags[1] & (2u | 128u | 256u))) { fallback = true; (void)hipMemsetAsync(c->d_err, 0, 4, sA); }      // the chunk store or a bin's map ran out (run_pipeline: the call again, without virtual tasks)
     if (fallback) { HIPCHK(c, hsk_sync(c, sA)); release_all(); free_store(c, st); return PARSE_FALLBACK; }
+    if (d_dropped) c->dropped_now = *(const unsigned long long *)(h_flags + 4);
     if (bins) {
         sbins.nchunks = std::min(h_flags[2], sbins.cap);
         int brc = bins_to_store(c, sbins, st, ntasks, c->vt_shift, sA); if (brc) { release_all(); return brc; }      // (main stream: behind the `placed` wait above)

@@ -1118,6 +1118,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     ProcExtra ex; ex.heavy_in = &hin; ex.vt_shift = vts; if (nranks == 1 && st.sm_item) ex.items_store = &st;
     const std::vector<void *> before_rank = (fed && c->comm.active()) ? c->pool.snapshot() : std::vector<void *>();
     int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
+    if (rc == HSK_OK && c->dropped_now) { out->total_kmers += c->dropped_now; c->stats.dropped_kmers += (int64_t)c->dropped_now; }      // (the instances the scan left out are k-mers of the input all the same)
     if (fed && feeder.live) {
         // Leaving together, part two (part one: the all-reduces with status up to the first task group).  A rank whose count failed
         // while the groups were travelling has kept its side of the exchange going (drain_after_failure); now the ranks tell each
@@ -1156,7 +1157,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     for (int r = 1; r < R; ++r) rid_base[r] = rid_base[r - 1] + (int64_t)nreads[r - 1];      // MPI_Exscan of the read counts
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
     // the plan, as run_pipeline chooses it with several ranks: the sketch of a rank's reads (here: of the first virtual rank that has some)
-    c->combine_now = false; c->item_mode_now = false; c->vt_shift = 0; c->combine_left_now = false;
+    c->combine_now = false; c->item_mode_now = false; c->vt_shift = 0; c->combine_left_now = false; c->drop_mask_now = 0; c->dropped_now = 0;
     if ((NW == 1 || (NW == 2 && c->cfg.kmer_size >= 40 && c->cfg.kmer_size <= 55)) && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
         const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
         int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;

@@ -106,6 +106,9 @@ struct ParseArgs {
     const u64 *task_base3;     // [ntasks][3] slot / byte / k-mer base of every task (parse_scan_kernel)
     u32 *packed_copy;          // optional (scan_kernel): `packed` is pinned HOST memory read in place over PCIe; every tile's words are
                                // also written here (HBM, packed_bytes + 64), so the ingest is fused into the one pass that hashes the reads
+    u32 drop_mask;             // scan_kernel<.., DROP>: bit 0 / 1 = positions whose k-mer is an A or T / a C or G homopolymer hold no k-mer (its count inside the
+                               // plan's sample alone exceeds U: it cannot be in the result, hsk_api.hip dispatch_pipeline)
+    unsigned long long *dropped;   // ... and how many positions that were (they stay k-mers of the input)
 };
 
 enum ParseMode { PARSE_COUNT = 0, PARSE_EMIT = 1, PARSE_DUMP = 2 };
@@ -581,7 +584,7 @@ __device__ unsigned long long g_scan_diag[16];
 #endif
 // KT, MT: k and m as compile-time constants (0: taken from the arguments).  The reference fixes both at compile time
 // (KMER_SIZE, MINIMIZER_SIZE); here the default pair gets its own instance: shifts, masks and the window loop fold.
-template <int KT, int MT, bool BINS = false>      // BINS: the items of the combining extraction are placed by this kernel (ParseArgs::bins) instead of records being written
+template <int KT, int MT, bool BINS = false, bool DROP = false>      // BINS: the items of the combining extraction are placed by this kernel (ParseArgs::bins) instead of records being written; DROP: ParseArgs::drop_mask (an instance of its own: the others keep their registers)
 __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 {
     __shared__ u32 s_words2[BINS ? 2 : 1][PARSE_WORDS];                             // the tile's packed words (+ halo); two buffers: the items of a tile are stored while the NEXT tile is hashed (bins)
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     const u32 maxk = a.item_maxk ? a.item_maxk : 16u;
     const u32 xcc_nvt = BINS ? (__builtin_amdgcn_s_getreg(PARSE_XCC_GETREG) & 7u) * a.ntasks : 0u;      // first bin of this workgroup's XCD
     u32 pf0 = 0, pf1 = 0, pf2 = 0; bool pf_have = false;      // prefetched: lanes < PARSE_RWIN {read offset, length}, the next PARSE_WORDS lanes one tile word each
+    u32 ndrop = 0;                                            // (DROP) positions this lane has left out
 
 #ifdef HSK_DIAG
     unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0};
@@ -801,6 +805,22 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
                 vmask |= (cnt_hi <= 0 ? 0u : (cnt_hi >= 4 ? 0xFu : ((1u << (u32)cnt_hi) - 1u))) << 4;
             }
         }
+        if constexpr (DROP) {
+            // positions whose k-mer is a homopolymer of a base in drop_mask: the 64 bases from this lane's first position hold the k-mers of all
+            // eight (K <= 57); a k-mer of one base b is the pattern b b b ... over its 2 K bits
+            const u64 d0 = bits64_be32(s_words, 16u * (u32)tid), d1 = bits64_be32(s_words, 16u * (u32)tid + 64u);
+            u32 dm = 0;
+#pragma unroll
+            for (int i = 0; i < PARSE_PPT; ++i) {
+                const u64 hi = i ? ((d0 << (2 * i)) | (d1 >> (64 - 2 * i))) : d0, lo = d1 << (2 * i);
+                const u32 b = (u32)(hi >> 62);
+                const u64 pat = ((b & 1u) ? 0x5555555555555555ULL : 0ULL) | ((b & 2u) ? 0xAAAAAAAAAAAAAAAAULL : 0ULL);
+                const bool same = K <= 32 ? ((hi ^ pat) >> (64 - 2 * K)) == 0 : (hi == pat && ((lo ^ pat) >> (128 - 2 * K)) == 0);
+                if (same && ((a.drop_mask >> ((b == 1u || b == 2u) ? 1 : 0)) & 1u)) dm |= 1u << i;
+            }
+            ndrop += (u32)__popc(vmask & dm);
+            vmask &= ~dm;
+        }
         s_last[tid] = mn[PARSE_PPT - 1];
         s_v8[tid] = (u8)vmask;
         lds_barrier();
@@ -906,6 +926,11 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
     if (tid == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_scan_diag[q], dacc[q]); atomicAdd(&g_scan_diag[8], dacc[5]); }
 #endif
     if (BINS) complete_pending(s_words2[BINS ? (wsel ^ 1u) : 0u]);              // the last tile's items (its words: the buffer the loop used last)
+    if constexpr (DROP) {
+        u32 v = ndrop;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+        if (lane_id() == 0 && v) atomicAdd(a.dropped, (unsigned long long)v);
+    }
     for (u32 t = tid; t < a.ntasks; t += PARSE_THREADS) {
         u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
         const u64 pk = s_cur[2 * t];

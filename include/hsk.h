@@ -133,7 +133,8 @@ typedef struct {
     int64_t  agg_retried_tasks;   /* tasks that needed the large hash table (a bin with many distinct keys) */
     int64_t  parse_fallbacks;     /* parses that left the fast path (a tile with more supermers than the record capacity) */
     int64_t  heavy_tasks;         /* heavy-hitter tasks this rank pre-aggregated and shipped as k-mer lists (multi-GPU) */
-    int64_t  onepass_misses;      /* always 0 (the one-pass experiment of rounds 1-2 is gone; the field keeps the struct layout) */
+    int64_t  dropped_kmers;       /* k-mer instances the scan left out because their k-mer -- the all-A or the all-C k-mer -- has more than U copies inside the
+                                     plan's sample alone and so cannot be in the result (round 4; the field was `onepass_misses`, always 0, before) */
     /* --- ABI 2 --- */
     uint64_t scan_launches;       /* scan_kernel (minimizers + supermer records): launches, packed read bytes, duration */
     uint64_t scan_bytes;

@@ -16,13 +16,21 @@ import hysortk_amd as H  # noqa: E402
 
 
 def digest(r):
-    return hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes()).hexdigest()
+    h = hashlib.sha256(r.kmers.tobytes() + r.cnt.tobytes() + r.task_off.tobytes() + r.histo.tobytes())
+    if r.pos is not None and len(r.cnt):               # EXTENSION: the payloads of a k-mer come in any order, and the arrays may hold the payloads of filtered
+        # k-mers between the slices of the kept ones: an order-independent sum over every kept k-mer's own slice [payload_off[i], + cnt[i])
+        x = r.pos.astype(np.uint64) | (r.rid.astype(np.uint64) << np.uint64(32))
+        with np.errstate(over="ignore"):
+            cs = np.concatenate((np.zeros(1, np.uint64), np.cumsum(x * np.uint64(0x9E3779B97F4A7C15), dtype=np.uint64)))
+            o = r.payload_off[:len(r.cnt)].astype(np.int64)
+            h.update((cs[o + r.cnt.astype(np.int64)] - cs[o]).tobytes())
+    return h.hexdigest()
 
 
 def run_spec(spec):
     """counts one synthetic input on a context of its own; returns one dict per call (tests/test_gpu_combine.py calls this in process)"""
     out = []
-    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], ntasks=spec["ntasks"], profile=True, plan=spec.get("plan"), tuning=spec.get("tuning"))
+    ctx = H.Context(K=spec["K"], M=spec["M"], L=spec["L"], U=spec["U"], EXT=spec.get("EXT", 0), ntasks=spec["ntasks"], profile=True, plan=spec.get("plan"), tuning=spec.get("tuning"))
     dp, nb, do, dl = ctx.synth_reads(spec["genome"], spec["read_len"], spec["nreads"], spec["seed"], error_rate=spec.get("error_rate", 0.0))
     n = spec["nreads"]
     packed = np.empty(nb, np.uint8); off = np.empty(n, np.uint64); lens = np.empty(n, np.uint32)
@@ -66,7 +74,8 @@ def run_spec(spec):
         st = ctx.stats(reset=True)
         out.append({"how": how, "digest": digest(r), "entries": len(r), "total_kmers": int(r.info["total_kmers"]),
                           "combine_launches": int(st["combine_launches"]), "combine_pairs": int(st["combine_pairs"]), "combine_kmers": int(st["combine_kmers"]),
-                          "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"])})
+                          "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"]),
+                          "dropped_kmers": int(st.get("dropped_kmers", 0))})
     if spec.get("dump"):
         np.savez(spec["dump"], kmers=r.kmers, cnt=r.cnt, task_off=r.task_off, packed=packed, off=off, lens=lens)
     if pinned is not None:

@@ -279,3 +279,16 @@ def test_a_bin_of_very_many_records_is_counted_in_slices(K):
     c_ = run(spec, {"HSK_COMBINE_MIN_BYTES": "0"})[0]
     assert a["combine_launches"] == 0 and b["combine_launches"] == 0 and c_["combine_launches"] > 0
     assert (a["digest"], a["entries"]) == (b["digest"], b["entries"]) == (c_["digest"], c_["entries"]) and a["entries"] > 100000
+
+
+@pytest.mark.parametrize("K,EXT,U", [(31, 0, 40), (51, 0, 40), (31, 1, 40), (31, 0, 65535)])
+def test_kmers_that_are_certain_to_be_dropped_are_left_out_by_the_scan(K, EXT, U):
+    """5 % all-A reads in an input the plan's sketch looks at (68 MB of packed reads): the sample alone holds more than U (and more than 2^16) copies
+    of the all-A k-mer, so it cannot be in the result and the scan clears the positions that hold it from its valid mask (scan_kernel<.., DROP>:
+    no supermers, no records, no bucket or bin of millions, no task several times the others' size).  Same list -- and with EXTENSION the same
+    payloads -- as with drop_certain=0; total_kmers still counts the instances; U = 65535: the sample's 110 000 copies are certain as well."""
+    spec = dict(BIG, K=K, EXT=EXT, L=2, U=U, poly_a_pct=5.0, calls=["pinned"])
+    a = run(spec, {})[0]
+    b = run(dict(spec, tuning_extra="drop_certain=0"), {})[0]
+    assert a["dropped_kmers"] == int(1800000 * 0.05) * (150 - K + 1) and b["dropped_kmers"] == 0
+    assert (a["digest"], a["entries"], a["total_kmers"]) == (b["digest"], b["entries"], b["total_kmers"]) and a["entries"] > 100000
