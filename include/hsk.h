@@ -102,7 +102,8 @@ typedef struct {
     uint64_t histo_len;
     void     *entries_dev;    /* device copy when HSK_FLAG_KEEP_DEVICE (owned by the ctx) */
     /* --- measurements of this call --- */
-    uint64_t total_kmers;     /* k-mers extracted on this rank (after the exchange) */
+    uint64_t total_kmers;     /* k-mers of this rank's tasks (after the exchange), incl. the instances the scan left out as certain to be dropped
+                                 (hsk_stats::dropped_kmers) */
     uint64_t total_supermers;
     uint64_t total_supermer_bytes;
     double   ms_total;        /* device time of the whole path (HIP events) */
