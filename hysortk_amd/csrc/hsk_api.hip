@@ -251,7 +251,7 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     if (!enabled || c->cfg.kmer_size >= 64 || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
     // (payloads, three-word keys, pinned plans: nothing to choose -- the sketch still says which k-mers are certain to be dropped, `valid` stays false)
     const bool plan_wanted = c->nw <= 2 && !c->cfg.extension && !(c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
-    if (!plan_wanted && (nranks > 1 || c->cfg.kmer_size > 57)) return HSK_OK;
+    if (!plan_wanted && c->cfg.kmer_size > 57) return HSK_OK;
     const auto t0 = std::chrono::steady_clock::now();
     u64 want = std::min<u64>(std::max<u64>(packed_bytes / 64, MIN_SAMPLE), MAX_SAMPLE);      // (10 Gbp: 40 MB of reads, ~4 M chosen k-mer instances: 1.2 ms of kernels)
     u64 lost = 0, n1 = 0, n2 = 0, n3 = 0, ds = 0, ns = 0, s_bytes = 0;
@@ -312,6 +312,14 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     return HSK_OK;
 }
 
+// which homopolymer k-mers this call's sketch has found more than U (and at least 2^16) copies of: bit 0 all-A, bit 1 all-C
+static u32 certain_drop_mask(hsk_ctx *c)
+{
+    if (tune("drop_certain", 1) == 0 || c->cfg.kmer_size > 57 || !parse_fast_enabled() || c->cfg.minimizer_size > SCAN_MAX_M) return 0;
+    const u64 dmin = std::max<u64>((u64)std::max(c->cfg.upper_freq, 0), 1ULL << 16);
+    return (c->est.homo_at > dmin ? 1u : 0u) | (c->est.homo_cg > dmin ? 2u : 0u);
+}
+
 static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads,
                              int64_t rid_base, hsk_result *out, int attempt = 0)
 {
@@ -321,11 +329,9 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
         rc = estimate_plan(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, c->comm.active() ? c->comm.nranks : 1); if (rc) return rc;
         // A k-mer with more than U copies inside the sample alone cannot be in the result: the scan leaves the instances of the all-A / all-C k-mer out
         // where they are that many (poly-A, the poly-G reads of two-colour sequencers: one bucket, one bin, one task several times the others' size).
-        // One GPU (ranks would have to agree, and a rank whose parse falls back could not follow); from 2^16 copies on (below that nothing is gained).
-        c->drop_mask_now = 0;
-        const u64 dmin = std::max<u64>((u64)std::max(c->cfg.upper_freq, 0), 1ULL << 16);
-        if (!c->comm.active() && tune("drop_certain", 1) != 0 && c->cfg.kmer_size <= 57 && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M)
-            c->drop_mask_now = (c->est.homo_at > dmin ? 1u : 0u) | (c->est.homo_cg > dmin ? 2u : 0u);
+        // From 2^16 copies on (below that nothing is gained).  Several ranks: a rank that is certain is right for all of them -- run_pipeline ORs the
+        // ranks' masks in the plan's all-reduce; the general parse kernels honour the mask as well, so a rank whose parse falls back stays consistent.
+        c->drop_mask_now = certain_drop_mask(c);
         if (c->drop_mask_now && timing_enabled()) fprintf(stderr, "[hsk] certain drops: the sample holds %llu copies of the all-A and %llu of the all-C k-mer (U = %d): mask %u\n",
                                                            (unsigned long long)c->est.homo_at, (unsigned long long)c->est.homo_cg, c->cfg.upper_freq, c->drop_mask_now);
     }

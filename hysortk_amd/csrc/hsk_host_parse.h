@@ -340,7 +340,7 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         if (*h_ovf && c->vt_shift) { c->pool.release(d_task_tot); c->combine_veto = true; return retry_plan("a tile beyond the record capacity"); }      // (the general kernels know no virtual tasks: the call again, without them)
         if (*h_ovf) {                                                // a tile with more supermers than the record capacity
             j.fast = false; c->stats.parse_fallbacks++;
-            c->dropped_now = 0;                                       // (the general kernels count every position again, the certain drops included: they are filtered at the end as ever)
+            c->dropped_now = 0;                                       // (the general kernels count again; they honour the same mask: several ranks stay consistent)
             if (a.nslabs > 1) {                                       // the general kernels know one tile range per workgroup
                 ParseArgs b = make_parse_args(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, ntasks, &j.nblocks);
                 b.blk_cnt = a.blk_cnt; b.rec_cap = a.rec_cap; b.place_group = a.place_group;
@@ -360,11 +360,18 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
         // task id per base position, kept from COUNT to EMIT (2 B x 4 x packed_bytes); optional: without it EMIT re-hashes
         j.d_dest_cache = (u16 *)c->pool.alloc((size_t)a.ntiles * PARSE_TILE * 2);
         a.dest_cache = j.d_dest_cache;
+        a.drop_mask = c->drop_mask_now;                               // (a fresh ParseArgs after a slab fallback has lost it)
+        if (a.drop_mask) {
+            if (!j.d_dropped) DALLOC(c, j.d_dropped, unsigned long long *, 256);
+            HIPCHK(c, hipMemsetAsync(j.d_dropped, 0, 8, c->stream)); a.dropped = j.d_dropped;
+        }
         hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        if (a.drop_mask) HIPCHK(c, hipMemcpyAsync(h_ovf + 4, j.d_dropped, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(j.task_tot.data(), d_task_tot, (size_t)ntasks * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
+        if (a.drop_mask) c->dropped_now = *(const unsigned long long *)(h_ovf + 4);
         // (hsk_count derives the read index only for the fast parse; should a derived index ever arrive here with its verdict still open, a
         //  wrong guess must not be counted: the call fails instead of trusting lengths and offsets nobody has confirmed)
         if (c->roff_check.valid() && !c->roff_check.get()) { c->pool.release(d_task_tot); return fail(c, HSK_ERR_INTERNAL, "derived read index reached the general parse unverified and does not match the caller's"); }

@@ -11,6 +11,7 @@
 // sort batch never waits for bytes it does not need.  HSK_OVERLAP=0 selects one exchange up front.
 // ------------------------------------------------------------------------------------------------
 static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u64 *d_roff, const u32 *d_rlen, u64 nreads, int nranks);      // hsk_api.hip
+static u32 certain_drop_mask(hsk_ctx *c);                                                                                                          // hsk_api.hip
 
 struct TaskInput { const u8 *len; BaseSource src; const u32 *pos; const int32_t *rid; const unsigned short *sub16 = nullptr; };
 
@@ -899,10 +900,12 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     if (c->comm.active()) {
         // every rank must use the same task count (the maximum of the local proposals) and the same plan (the combining extraction only if
         // every rank's own estimate says its input pays for it: the minimizer bits either travel from all ranks or from none)
-        u64 v[2] = {c->cfg.ntasks ? 0ULL : (u64)ntasks, c->combine_now ? 0ULL : 1ULL};
-        int rc = c->comm.allreduce_max_u64(v, 2, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks, plan) failed: %d", rc);
+        // ... and the certain drops: a rank whose own sample holds more than U copies of a homopolymer k-mer is right for all ranks (OR of the masks)
+        u64 v[4] = {c->cfg.ntasks ? 0ULL : (u64)ntasks, c->combine_now ? 0ULL : 1ULL, (u64)(c->drop_mask_now & 1u), (u64)((c->drop_mask_now >> 1) & 1u)};
+        int rc = c->comm.allreduce_max_u64(v, 4, c->stream, c->pool); if (rc) return fail(c, HSK_ERR_COMM, "allreduce(ntasks, plan) failed: %d", rc);
         if (!c->cfg.ntasks) ntasks = (u32)v[0];
         if (v[1]) c->combine_now = false;
+        c->drop_mask_now = (v[2] ? 1u : 0u) | (v[3] ? 2u : 0u);
     }
     out->ntasks = (int32_t)ntasks;
     // (at most 768 virtual tasks: the item placement's LDS holds 16 bytes for each beside its 16384 records; more real tasks than that: the instance path)
@@ -1158,16 +1161,21 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     std::vector<u32> order(ntasks); for (u32 t = 0; t < ntasks; ++t) order[t] = t;
     // the plan, as run_pipeline chooses it with several ranks: the sketch of a rank's reads (here: of the first virtual rank that has some)
     c->combine_now = false; c->item_mode_now = false; c->vt_shift = 0; c->combine_left_now = false; c->drop_mask_now = 0; c->dropped_now = 0;
-    if ((NW == 1 || (NW == 2 && c->cfg.kmer_size >= 40 && c->cfg.kmer_size <= 55)) && R > 1 && !ext && combine_enabled() && parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true)) {
+    const bool scan_ok = parse_fast_enabled() && c->cfg.minimizer_size <= SCAN_MAX_M;
+    const bool plan_cond = (NW == 1 || (NW == 2 && c->cfg.kmer_size >= 40 && c->cfg.kmer_size <= 55)) && R > 1 && !ext && combine_enabled() && scan_ok && c->xcd_batch_ok && overlap_enabled() && place_bytes_enabled(true);
+    if (R > 1 && (plan_cond || (scan_ok && c->cfg.kmer_size <= 57))) {          // (without a plan to choose, the sketch still says which k-mers are certain to be dropped)
         const u64 combine_min = (u64)tune("combine_min_bytes", 64LL << 20);
         int r0 = 0; while (r0 + 1 < R && nreads[r0] == 0) ++r0;
         int erc = estimate_plan(c, in[r0].packed, packed_bytes[r0], in[r0].roff, in[r0].rlen, nreads[r0], R); if (erc) return erc;
-        const bool pays = c->est.valid ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off;
-        c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !(NW == 1 ? c->agg_off : c->agg_off_wide);
+        c->drop_mask_now = certain_drop_mask(c);              // (a rank that is certain is right for all: the virtual ranks share the first one's)
+        if (plan_cond) {
+            const bool pays = c->est.valid ? c->est.distinct_per_kmer * c->est_bias * (double)combine_ratio() <= 1.0 : !c->combine_off;
+            c->combine_now = pays && tot_bytes / (u64)R >= combine_min && !(NW == 1 ? c->agg_off : c->agg_off_wide);
+        }
     }
-    struct PlanReset { hsk_ctx *c; ~PlanReset() { c->combine_now = false; c->est.valid = false; } } plan_reset{c};
+    struct PlanReset { hsk_ctx *c; ~PlanReset() { c->combine_now = false; c->est.valid = false; c->drop_mask_now = 0; } } plan_reset{c};
     // 1. hash every rank's reads once (parse_count), sum the task sizes, dispatch
-    std::vector<u64> bytes(ntasks, 0);
+    std::vector<u64> bytes(ntasks, 0), dropped(R, 0);
     std::vector<ParseJob> jobs(R);
     auto release_jobs = [&]() { for (auto &j : jobs) parse_release(c, j); };
     // per-rank device time of the parse (hash + count, then placement + byte store): outs[r].ms_parse
@@ -1178,6 +1186,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     for (int r = 0; r < R; ++r) {
         (void)hipEventRecord(e0[r], c->stream);
         int rc = parse_count(c, in[r].packed, packed_bytes[r], in[r].roff, in[r].rlen, nreads[r], rid_base[r], ntasks, jobs[r]);
+        dropped[r] = c->dropped_now;
         (void)hipEventRecord(e1[r], c->stream);
         if (rc) { release_jobs(); return rc; }
         for (u32 t = 0; t < ntasks; ++t) bytes[t] += jobs[r].task_tot[3 * t + 1] + jobs[r].task_tot[3 * t] * (ext ? 9 : 1);
@@ -1268,6 +1277,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             PhaseTimer pt(c);
             ProcExtra ex; ex.heavy_in = &hin[r];
             rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r], &ex);
+            if (rc_all == HSK_OK) { outs[r].total_kmers += dropped[r]; c->stats.dropped_kmers += (int64_t)dropped[r]; }
             if (rc_all == HSK_OK) { outs[r].ms_parse = parse_ms(r); outs[r].ms_total = outs[r].ms_parse + outs[r].ms_exchange + outs[r].ms_extract + outs[r].ms_sort + outs[r].ms_count + outs[r].ms_d2h; }
         }
         for (int r = 0; r < R; ++r) free_store(c, st[r]);

@@ -171,6 +171,23 @@ __device__ __forceinline__ u64 wide_mmer_hash(const u32 *s_words, u32 p, int M)
     return murmur64_words<MW>(c.w);
 }
 
+// ParseArgs::drop_mask: which of a lane's eight positions hold a k-mer that is a homopolymer of a base in the mask (bit 0: A or T, bit 1: C or G).
+// The 64 bases from the lane's first position hold the k-mers of all eight (K <= 57); a k-mer of one base b is the pattern b b b ... over its 2 K bits.
+__device__ __forceinline__ u32 homopolymer_positions(const u32 *s_words, int tid, int K, u32 drop_mask)
+{
+    const u64 d0 = bits64_be32(s_words, 16u * (u32)tid), d1 = bits64_be32(s_words, 16u * (u32)tid + 64u);
+    u32 dm = 0;
+#pragma unroll
+    for (int i = 0; i < PARSE_PPT; ++i) {
+        const u64 hi = i ? ((d0 << (2 * i)) | (d1 >> (64 - 2 * i))) : d0, lo = d1 << (2 * i);
+        const u32 b = (u32)(hi >> 62);
+        const u64 pat = ((b & 1u) ? 0x5555555555555555ULL : 0ULL) | ((b & 2u) ? 0xAAAAAAAAAAAAAAAAULL : 0ULL);
+        const bool same = K <= 32 ? ((hi ^ pat) >> (64 - 2 * K)) == 0 : (hi == pat && ((lo ^ pat) >> (128 - 2 * K)) == 0);
+        if (same && ((drop_mask >> ((b == 1u || b == 2u) ? 1 : 0)) & 1u)) dm |= 1u << i;
+    }
+    return dm;
+}
+
 template <int MODE, bool EXT>
 __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
 {
@@ -184,6 +201,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
     __shared__ u32 s_scan[12];               // [0..8) block-scan scratch, [8] records in this tile (48 B keeps the dynamic base 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) u64 s_cur[]; // 16 B per task: COUNT {supermers<<40|k-mers, bytes}; EMIT {slot cursor, u32 tile count, u32 tile prefix}
 
+    u32 ndrop = 0;                           // (COUNT, ParseArgs::drop_mask) positions this lane has left out
     const int tid = threadIdx.x;
     const int K = a.k, M = a.m, W = K - M + 1;
     const u64 total_pos = a.packed_bytes * 4;
@@ -309,6 +327,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
             auto rel = [&](u64 x) -> int { return x >= gbase + (u64)HUGE ? HUGE : (x < gbase ? ((gbase - x) >= (u64)HUGE ? -HUGE : -(int)(gbase - x)) : (int)(x - gbase)); };
             int rend_r = rel(rend), nxt_r = rel(nxt);
             const int total_r = rel(total_pos);
+            const u32 dmk = (a.drop_mask && K <= 57) ? homopolymer_positions(s_words, tid, K, a.drop_mask) : 0u;      // (k-mers certain to be dropped: as scan_kernel<.., DROP>)
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 const int g = p0 + i;
@@ -318,7 +337,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
                     else { rend = rstart + a.rlen[r]; nxt = (r + 1 < a.nreads) ? a.roff[r + 1] * 4 : ~0ULL; }
                     rend_r = rel(rend); nxt_r = rel(nxt);
                 }
-                const bool valid = (g < total_r) && (g + K <= rend_r);
+                bool valid = (g < total_r) && (g + K <= rend_r);
+                if (valid && ((dmk >> i) & 1u)) { valid = false; if (MODE == PARSE_COUNT) ++ndrop; }
                 const u32 d = fastmod64(mn[i], a.fm);
                 s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
             }
@@ -410,6 +430,11 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
             u64 *o = a.blk_cnt + ((u64)blockIdx.x * a.ntasks + t) * 3;
             const u64 pk = s_cur[2 * t];
             o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
+        }
+        if (a.drop_mask && a.dropped) {
+            u32 v = ndrop;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+            if (lane_id() == 0 && v) atomicAdd(a.dropped, (unsigned long long)v);
         }
     }
 }
@@ -808,16 +833,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
         if constexpr (DROP) {
             // positions whose k-mer is a homopolymer of a base in drop_mask: the 64 bases from this lane's first position hold the k-mers of all
             // eight (K <= 57); a k-mer of one base b is the pattern b b b ... over its 2 K bits
-            const u64 d0 = bits64_be32(s_words, 16u * (u32)tid), d1 = bits64_be32(s_words, 16u * (u32)tid + 64u);
-            u32 dm = 0;
-#pragma unroll
-            for (int i = 0; i < PARSE_PPT; ++i) {
-                const u64 hi = i ? ((d0 << (2 * i)) | (d1 >> (64 - 2 * i))) : d0, lo = d1 << (2 * i);
-                const u32 b = (u32)(hi >> 62);
-                const u64 pat = ((b & 1u) ? 0x5555555555555555ULL : 0ULL) | ((b & 2u) ? 0xAAAAAAAAAAAAAAAAULL : 0ULL);
-                const bool same = K <= 32 ? ((hi ^ pat) >> (64 - 2 * K)) == 0 : (hi == pat && ((lo ^ pat) >> (128 - 2 * K)) == 0);
-                if (same && ((a.drop_mask >> ((b == 1u || b == 2u) ? 1 : 0)) & 1u)) dm |= 1u << i;
-            }
+            const u32 dm = homopolymer_positions(s_words, tid, K, a.drop_mask);
             ndrop += (u32)__popc(vmask & dm);
             vmask &= ~dm;
         }
@@ -946,6 +962,9 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void scan_kernel(ParseArgs a)
 // dynamic LDS: u64 cur[ntasks], u32 tcnt[ntasks], u32 tpre[ntasks], u32 srt[PLACE_MAX_REC]
 __global__ __launch_bounds__(PARSE_THREADS) void place_kernel(ParseArgs a)
 {
+    // pipelined ingest (place_one): the placement of a slab is launched before the host has seen the scan's verdict.  A tile beyond the record
+    // capacity means that the supermers counted (all of them) may exceed the store (rec_cap per tile): nothing is placed, the host falls back.
+    if (a.place_one && a.overflow && *(const volatile u32 *)a.overflow) return;
     constexpr int RPT = PLACE_MAX_REC / PARSE_THREADS;                 // records per thread and step at most
     __shared__ u32 s_scan[12];
     __shared__ u32 s_go[20];                                            // record offsets of the tiles of the step (+ total)
@@ -1032,6 +1051,9 @@ constexpr u32 PLACE_ITEM_TILES = PLACE_ITEM_REC / 512; // tiles per step at most
 constexpr u32 PLACE_ITEM_WORDS = PLACE_ITEM_TILES * (PARSE_TILE / 16) + 8;      // their packed words + the reach of the last supermer's second word
 __global__ __launch_bounds__(PLACE_ITEM_THREADS) void place_items_kernel(ParseArgs a)
 {
+    // pipelined ingest (place_one): the placement of a slab is launched before the host has seen the scan's verdict.  A tile beyond the record
+    // capacity means that the supermers counted (all of them) may exceed the store (rec_cap per tile): nothing is placed, the host falls back.
+    if (a.place_one && a.overflow && *(const volatile u32 *)a.overflow) return;
     constexpr int RPT = PLACE_ITEM_REC / PLACE_ITEM_THREADS;
     constexpr int T = PLACE_ITEM_THREADS;
     __shared__ u32 s_w[16];

@@ -40,17 +40,20 @@ def run_spec(spec):
         rng = np.random.default_rng(spec["seed"] + 1)
         view = packed.reshape(n, (spec["read_len"] + 3) // 4)
         view[rng.choice(n, int(n * spec["poly_a_pct"] / 100), replace=False)] = 0
-        assert all(h in ("host", "pinned") for h in spec["calls"])
+        assert all(h in ("host", "pinned") or h.startswith("hostloop:") for h in spec["calls"])
     pinned = None
     for how in spec["calls"]:
         ctx.stats(reset=True)
-        if how.startswith("loopback:"):
+        if how.startswith("loopback:") or how.startswith("hostloop:"):
             # R virtual ranks over the same reads, split evenly (hsk_count_loopback_device): one line per call, digest over the ranks' lists in rank order
             R = int(how.split(":")[1])
             per = n // R
             nbr = (spec["read_len"] + 3) // 4
-            reads = [(dp.value + r * per * nbr, per * nbr, do, dl, per) for r in range(R)]      # (fixed-length reads: every rank's offsets start at 0 again -- the same array serves)
-            res, owner = ctx.count_loopback_device(reads)
+            if how.startswith("hostloop:"):                # the host's arrays (with the all-A reads, if any): hsk_count_loopback
+                res, owner = ctx.count_loopback([(packed[r * per * nbr:(r + 1) * per * nbr], off[:per], lens[:per]) for r in range(R)])
+            else:
+                reads = [(dp.value + r * per * nbr, per * nbr, do, dl, per) for r in range(R)]      # (fixed-length reads: every rank's offsets start at 0 again -- the same array serves)
+                res, owner = ctx.count_loopback_device(reads)
             st = ctx.stats(reset=True)
             h = hashlib.sha256()
             ent = 0
@@ -60,7 +63,8 @@ def run_spec(spec):
                 h.update(kl.kmers[a:b].tobytes()); h.update(kl.cnt[a:b].tobytes()); ent += b - a
             out.append({"how": how, "digest": h.hexdigest(), "entries": ent, "total_kmers": int(sum(k.info["total_kmers"] for k in res)),
                               "combine_launches": int(st["combine_launches"]), "combine_pairs": int(st["combine_pairs"]), "combine_kmers": int(st["combine_kmers"]),
-                              "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"])})
+                              "instance_extractions": int(st["hist_launches"]), "fused_tasks": int(st["fused_tasks"]), "redone_tasks": int(st["redone_tasks"]),
+                              "dropped_kmers": int(st.get("dropped_kmers", 0))})
             continue
         if how == "device":
             r = ctx.count_device(dp, nb, do, dl, n)
