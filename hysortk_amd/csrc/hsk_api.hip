@@ -248,7 +248,7 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
     const bool enabled = tune("plan_sample", 1) != 0;
     constexpr u64 MIN_INPUT = 32ULL << 20, MIN_SAMPLE = 4ULL << 20, MAX_SAMPLE = 64ULL << 20;
     // who would use it: one-word keys without payload on one GPU (combining extraction or not, first table, aggregation or not)
-    if (!enabled || c->cfg.kmer_size >= 64 || packed_bytes < MIN_INPUT || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
+    if (!enabled || c->cfg.kmer_size >= 64 || packed_bytes < (u64)tune("plan_min_input", (long long)MIN_INPUT) || nreads < 4096) return HSK_OK;       // (several ranks: every rank sketches its own reads, run_pipeline makes them agree)
     // (payloads, three-word keys, pinned plans: nothing to choose -- the sketch still says which k-mers are certain to be dropped, `valid` stays false)
     const bool plan_wanted = c->nw <= 2 && !c->cfg.extension && !(c->cfg.flags & (HSK_FLAG_NO_AGGREGATION | HSK_FLAG_FULL_SORT));
     if (!plan_wanted && c->cfg.kmer_size > 57) return HSK_OK;
@@ -268,7 +268,7 @@ static int estimate_plan(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const
         HIPCHK(c, hipMemcpyAsync(h_out + 8, d_out + 8, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hsk_sync(c, c->stream));
         const u64 s_reads = h_out[8]; s_bytes = h_out[9];
-        if (s_reads < 2048 || s_bytes < MIN_SAMPLE / 2 || s_bytes > packed_bytes || s_bytes > want + (1u << 20)) { release(); return HSK_OK; }      // (very long reads, a strange index: no estimate, the context's memory decides)
+        if (s_reads < 2048 || s_bytes < std::min<u64>(MIN_SAMPLE / 2, (u64)tune("plan_min_input", (long long)MIN_INPUT)) || s_bytes > packed_bytes || s_bytes > want + (1u << 20)) { release(); return HSK_OK; }      // (very long reads, a strange index: no estimate, the context's memory decides)
         // host input: the sample's bytes first (the main run copies them again with its first slab)
         if (c->h2d_src || c->zc_src) HIPCHK(c, hipMemcpyAsync(const_cast<u8 *>(d_packed), c->h2d_src ? c->h2d_src : c->zc_src, s_bytes, hipMemcpyDefault, c->stream));
         EstimateArgs ea; memset(&ea, 0, sizeof ea);

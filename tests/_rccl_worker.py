@@ -45,7 +45,7 @@ def main():
     res = ctx.count(dna, rid_base=rid_base)                                # (after a failure: same context, same communicator)
     st = ctx.stats()
     out = dict(kmers=res.kmers, cnt=res.cnt, task_off=res.task_off, histo=res.histo, heavy=np.array([st["heavy_tasks"]]), combine_pairs=np.array([st["combine_pairs"]]),
-               total_kmers=np.array([res.info["total_kmers"]]))
+               dropped=np.array([st["dropped_kmers"]]), total_kmers=np.array([res.info["total_kmers"]]))
     if failure is not None:
         out.update(fail_code=np.array([failure["code"]]), fail_seconds=np.array([failure["seconds"]]), fail_msg=np.array([failure["msg"]]))
     if spec["EXT"]:

@@ -202,3 +202,37 @@ def test_two_ranks_owner_side_combining_extraction(tmp_path, world):
     for r in range(world):
         assert int(got[r]["combine_pairs"][0]) > 0, r                       # (pairs were written: combine_kernel ran on this rank's tasks)
         assert np.array_equal(got[r]["task_off"], want[r].task_off) and np.array_equal(got[r]["kmers"], want[r].kmers) and np.array_equal(got[r]["cnt"], want[r].cnt), r
+
+
+def test_two_ranks_agree_on_the_certain_drops(tmp_path):
+    """Only rank 0's reads hold the all-A reads (700 x 120 copies of the all-A k-mer: more than U and more than 2^16 inside its sketch's sample);
+    rank 1's sketch sees none.  The masks are ORed in the plan's all-reduce (run_pipeline), so rank 1 -- which owns the all-A k-mer's task or
+    not -- leaves them out as well; the lists equal the ones without the drops, total_kmers still counts the instances."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    cfg = dict(K=31, M=17, L=1, U=65535, EXT=0, ntasks=48)
+    seqs = ["A" * 150] * 700 + list(synth.reads(300000, 150, 40000, 29))
+    reads_json = str(tmp_path / "reads.json")
+    json.dump(seqs, open(reads_json, "w"))
+    spec = dict(cfg, reads=reads_json, out=str(tmp_path / "rank%d.npz"))
+    got = _run_ranks(2, spec, tmp_path, 29690, {"HSK_PLAN_MIN_INPUT": "1"})
+    with H.Context(tuning="drop_certain=0", **cfg) as c:
+        want, owner = c.count_loopback([H.DnaBuffer.from_sequences(p) for p in _split(H, seqs, 2)])
+    assert int(got[0]["dropped"][0]) == 700 * 120 and int(got[1]["dropped"][0]) == 0
+    # (the all-A task is smaller without its 84 000 instances, so the dispatcher may hand the tasks out differently: task by task, whoever owns it)
+    def task_list(lists, t, get):
+        for x in lists:
+            to = get(x, "task_off")
+            a, b = int(to[t]), int(to[t + 1])
+            if b > a:
+                return get(x, "kmers")[a:b], get(x, "cnt")[a:b]
+        return None
+    n = 0
+    for t in range(len(owner)):
+        g, w = task_list(got, t, lambda x, k: x[k]), task_list(want, t, lambda x, k: getattr(x, k))
+        assert (g is None) == (w is None), t
+        if g is not None:
+            assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), t
+            n += len(g[1])
+    assert n == sum(len(w) for w in want) > 100000
+    assert sum(int(g["total_kmers"][0]) for g in got) == sum(int(w.info["total_kmers"]) for w in want) == len(seqs) * 120
