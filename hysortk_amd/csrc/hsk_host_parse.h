@@ -365,7 +365,8 @@ static int parse_count(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const u
             if (!j.d_dropped) DALLOC(c, j.d_dropped, unsigned long long *, 256);
             HIPCHK(c, hipMemsetAsync(j.d_dropped, 0, 8, c->stream)); a.dropped = j.d_dropped;
         }
-        hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        if (a.drop_mask) hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else hipLaunchKernelGGL((parse_kernel<PARSE_COUNT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         hipLaunchKernelGGL(task_totals_kernel, dim3(1), dim3(HSK_MAX_TASKS), 0, c->stream, j.d_blk_cnt, j.nblocks, ntasks, d_task_tot);
         HIPCHK(c, hipMemcpyAsync(h_ovf + 1, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
         if (a.drop_mask) HIPCHK(c, hipMemcpyAsync(h_ovf + 4, j.d_dropped, 8, hipMemcpyDeviceToHost, c->stream));
@@ -463,6 +464,7 @@ static int parse_place(hsk_ctx *c, ParseJob &j, const std::vector<u32> &order, S
             if (profile) { (void)hipEventRecord(ep.b, c->stream); c->ev_pending.push_back(ep); }
         }
         else if (a.dest_cache) hipLaunchKernelGGL(emit_kernel, dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
+        else if (a.drop_mask) hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false, true>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         else hipLaunchKernelGGL((parse_kernel<PARSE_EMIT, false>), dim3(j.nblocks), dim3(PARSE_THREADS), (size_t)ntasks * 16, c->stream, a);
         if (ext) hipLaunchKernelGGL(resolve_pos_rid_kernel, dim3((u32)std::min<u64>((st.tot_sup + 255) / 256, 8192)), dim3(256), 0, c->stream,
                                     st.sm_gpos, st.tot_sup, j.d_roff, j.nreads, j.rid_base, st.sm_pos, st.sm_rid, (const u32 *)j.d_tile_r0, a.ntiles);

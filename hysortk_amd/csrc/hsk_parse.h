@@ -188,7 +188,7 @@ __device__ __forceinline__ u32 homopolymer_positions(const u32 *s_words, int tid
     return dm;
 }
 
-template <int MODE, bool EXT>
+template <int MODE, bool EXT, bool DROP = false>      // (DROP: ParseArgs::drop_mask is honoured -- instances of their own, the others keep their registers)
 __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
 {
     __shared__ u32 s_words[PARSE_WORDS];
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
             auto rel = [&](u64 x) -> int { return x >= gbase + (u64)HUGE ? HUGE : (x < gbase ? ((gbase - x) >= (u64)HUGE ? -HUGE : -(int)(gbase - x)) : (int)(x - gbase)); };
             int rend_r = rel(rend), nxt_r = rel(nxt);
             const int total_r = rel(total_pos);
-            const u32 dmk = (a.drop_mask && K <= 57) ? homopolymer_positions(s_words, tid, K, a.drop_mask) : 0u;      // (k-mers certain to be dropped: as scan_kernel<.., DROP>)
+            u32 dmk = 0;                                               // (k-mers certain to be dropped: as scan_kernel<.., DROP>)
+            if constexpr (DROP) dmk = homopolymer_positions(s_words, tid, K, a.drop_mask);
 #pragma unroll
             for (int i = 0; i < PARSE_PPT; ++i) {
                 const int g = p0 + i;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
                     rend_r = rel(rend); nxt_r = rel(nxt);
                 }
                 bool valid = (g < total_r) && (g + K <= rend_r);
-                if (valid && ((dmk >> i) & 1u)) { valid = false; if (MODE == PARSE_COUNT) ++ndrop; }
+                if (DROP && valid && ((dmk >> i) & 1u)) { valid = false; if (MODE == PARSE_COUNT) ++ndrop; }
                 const u32 d = fastmod64(mn[i], a.fm);
                 s_dest[p0 + i] = valid ? (u16)d : (u16)0xFFFF;
             }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 4) void parse_kernel(ParseArgs a)
             const u64 pk = s_cur[2 * t];
             o[0] = pk >> 40; o[1] = s_cur[2 * t + 1]; o[2] = pk & ((1ULL << 40) - 1);
         }
-        if (a.drop_mask && a.dropped) {
+        if (DROP && a.dropped) {
             u32 v = ndrop;
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
             if (lane_id() == 0 && v) atomicAdd(a.dropped, (unsigned long long)v);
