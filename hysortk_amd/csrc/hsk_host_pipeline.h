@@ -927,6 +927,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     // ---- parse ------------------------------------------------------------------------------------
     SupermerStore st;
     std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<u64> heavy_kmers(ntasks, 0);             // k-mer instances of a heavy task over all ranks (they travel as lists: its owner counts them into total_kmers)
     std::vector<TaskOut> hlists;                         // this rank's {k-mer, count} lists of the heavy tasks
     std::vector<HeavyIn> hin;                            // heavy tasks this rank owns: the lists of all ranks
     bool any_heavy = false;
@@ -981,7 +982,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
                 rc = together(cm.allreduce_with_status(kg, RCCL_SUM, local_rc != 0, c->stream, c->pool), "task k-mers");
                 if (rc) { parse_release(c, job); return rc; }
                 plan_classify(kg.data(), (int)ntasks, c->cfg.unbalanced_ratio, types.data());
-                for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+                for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; heavy_kmers[t] = kg[t]; }
             }
             if (any_heavy) {
                 std::vector<u8> failed(ntasks, 0);
@@ -1122,6 +1123,7 @@ static int run_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, const 
     const std::vector<void *> before_rank = (fed && c->comm.active()) ? c->pool.snapshot() : std::vector<void *>();
     int rc = process_rank<NW>(c, ntasks, owner, rank, segs, x_len, x_src, x_pos, x_rid, out, rp, pt, true, fed ? &feeder : nullptr, &ex);
     if (rc == HSK_OK && c->dropped_now) { out->total_kmers += c->dropped_now; c->stats.dropped_kmers += (int64_t)c->dropped_now; }      // (the instances the scan left out are k-mers of the input all the same)
+    if (rc == HSK_OK && nranks > 1) for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t] && owner[t] == rank) out->total_kmers += heavy_kmers[t];      // (they arrived as lists, not as supermers)
     if (fed && feeder.live) {
         // Leaving together, part two (part one: the all-reduces with status up to the first task group).  A rank whose count failed
         // while the groups were travelling has kept its side of the exchange going (drain_after_failure); now the ranks tell each
@@ -1193,6 +1195,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
     }
     // 1b. heavy-hitter tasks: classify on the global k-mer counts, every rank pre-aggregates its share
     std::vector<u8> is_heavy(ntasks, 0);
+    std::vector<u64> heavy_kmers(ntasks, 0);             // k-mer instances of a heavy task over all ranks: its owner counts them into total_kmers
     std::vector<std::vector<TaskOut>> hlists(R);
     auto free_hlists = [&]() { for (auto &v : hlists) for (auto &to : v) free_task_out(c, to); };
     bool any_heavy = false;
@@ -1200,7 +1203,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
         std::vector<u64> kg(ntasks, 0); std::vector<int32_t> types(ntasks, 0);
         for (int r = 0; r < R; ++r) for (u32 t = 0; t < ntasks; ++t) kg[t] += jobs[r].task_tot[3 * t + 2];
         plan_classify(kg.data(), (int)ntasks, c->cfg.unbalanced_ratio, types.data());
-        for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; }
+        for (u32 t = 0; t < ntasks; ++t) if (types[t] == 1) { is_heavy[t] = 1; any_heavy = true; heavy_kmers[t] = kg[t]; }
     }
     if (any_heavy) {
         std::vector<u8> bad(ntasks, 0);
@@ -1278,6 +1281,7 @@ static int run_loopback(hsk_ctx *c, int R, const DevInput *in, const u64 *packed
             ProcExtra ex; ex.heavy_in = &hin[r];
             rc_all = process_rank<NW>(c, ntasks, owner, r, segs[r], nullptr, BaseSource(), nullptr, nullptr, &outs[r], rp, pt, false, &fd[r], &ex);
             if (rc_all == HSK_OK) { outs[r].total_kmers += dropped[r]; c->stats.dropped_kmers += (int64_t)dropped[r]; }
+            if (rc_all == HSK_OK) for (u32 t = 0; t < ntasks; ++t) if (is_heavy[t] && owner[t] == r) outs[r].total_kmers += heavy_kmers[t];      // (they arrived as lists, not as supermers)
             if (rc_all == HSK_OK) { outs[r].ms_parse = parse_ms(r); outs[r].ms_total = outs[r].ms_parse + outs[r].ms_exchange + outs[r].ms_extract + outs[r].ms_sort + outs[r].ms_count + outs[r].ms_d2h; }
         }
         for (int r = 0; r < R; ++r) free_store(c, st[r]);

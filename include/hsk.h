@@ -102,8 +102,9 @@ typedef struct {
     uint64_t histo_len;
     void     *entries_dev;    /* device copy when HSK_FLAG_KEEP_DEVICE (owned by the ctx) */
     /* --- measurements of this call --- */
-    uint64_t total_kmers;     /* k-mers of this rank's tasks (after the exchange), incl. the instances the scan left out as certain to be dropped
-                                 (hsk_stats::dropped_kmers) */
+    uint64_t total_kmers;     /* k-mer instances of this rank's tasks (after the exchange; a heavy-hitter task's, which arrive as lists, incl.),
+                                 plus the instances this rank's scan left out as certain to be dropped (hsk_stats::dropped_kmers): over the
+                                 ranks they add up to the k-mers of the input */
     uint64_t total_supermers;
     uint64_t total_supermer_bytes;
     double   ms_total;        /* device time of the whole path (HIP events) */

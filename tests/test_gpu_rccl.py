@@ -117,6 +117,7 @@ def test_two_ranks_over_rccl(case, tmp_path):
                 assert sorted(zip(g["rid"][a:b].tolist(), g["pos"][a:b].tolist())) == sorted(zip(wr.tolist(), wp.tolist())), (case, r, i)
     if case.startswith("heavy"):
         assert st["heavy_tasks"] > 0 and sum(int(g["heavy"][0]) for g in got) > 0
+    assert sum(int(g["total_kmers"][0]) for g in got) == sum(len(s_) - cfg["K"] + 1 for s_ in seqs if len(s_) >= cfg["K"])      # (heavy tasks' instances included)
     if case == "golden_k31":
         lines = []
         for g in got:

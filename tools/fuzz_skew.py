@@ -71,6 +71,8 @@ for seed in range(first, first + nseeds):
         ctx.close()
     ok = res[0][:3] == res[1][:3]
     fails += not ok
+    if not ok:
+        print("     entries %d / %d, total_kmers %d / %d, digests %s" % (res[0][1], res[1][1], res[0][2], res[1][2], "equal" if res[0][0] == res[1][0] else "differ"))
     print("%s seed %d K=%d EXT=%d L=%d U=%d RL=%d reads=%d cov=%.0f ntasks=%d ranks=%d rec_cap=%d homopolymers %s di %.0f%%: entries %d, dropped %d, %.0f ms against %.0f ms" %
           ("OK  " if ok else "FAIL", seed, K, EXT, L, U, RL, n, n * RL / G, ntasks, R, cap, {k: v for k, v in shares.items() if v}, di, res[0][1], res[0][3], res[0][4] * 1e3, res[1][4] * 1e3), flush=True)
 print("failures:", fails)
