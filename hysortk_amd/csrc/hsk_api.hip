@@ -360,6 +360,7 @@ static int dispatch_pipeline(hsk_ctx *c, const u8 *d_packed, u64 packed_bytes, c
         return dispatch_pipeline(c, d_packed, packed_bytes, d_roff, d_rlen, nreads, rid_base, out, attempt + 1);
     }
     c->plan_attempt = 0; c->est.valid = false;
+    c->drop_mask_now = 0; c->dropped_now = 0;            // (the hsk_stage_* entry points parse without a plan: nothing of this call's may stay behind)
     return rc;
 }
 

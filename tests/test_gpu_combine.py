@@ -323,3 +323,19 @@ def test_certain_drops_through_the_general_parse_on_one_gpu():
     # (round 4 found a fault here: with most tiles beyond the capacity the supermers counted exceed the pipelined ingest's store -- its placement
     #  kernels, launched before the host sees the scan's verdict, now place nothing once a tile has overflowed)
     assert (c_["digest"], c_["entries"], c_["total_kmers"]) == (b["digest"], b["entries"], b["total_kmers"])
+
+
+def test_the_certain_drops_of_a_call_do_not_outlive_it():
+    """A call that left the all-A k-mer out, then the stage entry points on the same context (they parse without a sketch): every instance of the
+    all-A k-mer is there again -- the call's mask and count are cleared when it returns."""
+    import hysortk_amd as H
+    from hysortk_amd import synth
+    seqs = ["A" * 150] * 700 + list(synth.reads(200000, 150, 20000, 41))
+    dna = H.DnaBuffer.from_sequences(seqs)
+    with H.Context(K=31, M=17, L=2, U=40, ntasks=5, profile=True, tuning="plan_min_input=1") as c:
+        r = c.count(dna)
+        assert int(c.stats()["dropped_kmers"]) == 700 * 120 and int(r.info["total_kmers"]) == len(seqs) * 120
+        n = sum(len(c.stage_task_kmers(dna, t)[0]) for t in range(5))
+        assert n == len(seqs) * 120
+        r2 = c.count(dna)
+        assert int(r2.info["total_kmers"]) == len(seqs) * 120 and np.array_equal(r2.kmers, r.kmers) and np.array_equal(r2.cnt, r.cnt)
