@@ -163,3 +163,24 @@ def test_paradis_order_rebuilds_the_reference_raw_vector_k51():
     perm = H.paradis_order(r.keys, r.cnt, r.task_off)
     assert [raduls[i] for i in perm] == [g[0] for g in gold]
     assert r.cnt[perm].tolist() == [g[1] for g in gold]
+
+
+def test_every_tuning_name_the_library_reads_is_documented():
+    """hsk_config::tuning names (tune("...") in hysortk_amd/csrc) against INTEGRATION.md section 5: a switch nobody can find is a switch nobody can use."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(util.ROOT, "hysortk_amd", "csrc", "*")):
+        names |= set(re.findall(r'tune\("([a-z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(util.ROOT, "INTEGRATION.md")).read()
+    assert len(names) > 30
+    assert sorted(n for n in names if "`%s`" % n not in doc and "`%s=" % n not in doc) == []
+
+
+def test_scripts_compile():
+    """bench.py, __graft_entry__.py and everything under tools/ at least parse (they run on the GPU box only)."""
+    files = [os.path.join(util.ROOT, "bench.py"), os.path.join(util.ROOT, "__graft_entry__.py")]
+    for d, _, fs in os.walk(os.path.join(util.ROOT, "tools")):
+        files += [os.path.join(d, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        compile(open(f).read(), f, "exec")
