@@ -6,7 +6,7 @@
 # 2. PMC passes, one counter set each, kernel trace only (1 step + 1 warm-up, full scale):   -> <tag>_pmc.json (+ pmc.json, the one bench.py reads)
 #      FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES | SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 #                                                                                               | SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-# 3. tools/exp/mulrate                                                                        -> <tag>_valu_rates.txt
+# 3. tools/exp/mulrate                                                                        -> <tag>_valu_rates.txt; tools/valu_floor.py -> valu_mix.json
 # 4. the full bench line (reads the pmc.json of step 2)                                       -> <tag>_bench.json
 export TMPDIR=/tmp
 TAG=${1:-r04}
@@ -32,6 +32,9 @@ python3 tools/pmc_to_json.py $OUT/pmc $P/${TAG}_pmc.json 2 $OUT/pmc_p1.json > $O
 cp $P/${TAG}_pmc.json $R/profiles/pmc.json
 cat $OUT/pmc_summary.txt
 [ -x tools/exp/mulrate ] && ./tools/exp/mulrate > $P/${TAG}_valu_rates.txt 2>&1
+# the kernels' static mix priced with THIS run's rates, before the bench line that quotes it (30 s of hipcc -S; round 4 computed it beforehand
+# from the previous run's rates: 0.5 % apart)
+python3 tools/valu_floor.py $P/${TAG}_valu_rates.txt profiles/valu_mix.json > $OUT/valu_mix.txt 2>&1 && cp profiles/valu_mix.json $P/valu_mix.json
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cp $OUT/bench.json $P/${TAG}_bench.json
 python3 tools/bench_summary.py $OUT/bench.json
