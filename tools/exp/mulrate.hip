@@ -8,16 +8,16 @@
 #include <cstdint>
 #include <cstring>
 #define REP8(x) x x x x x x x x
-enum { ADDXOR, ADD3, MUL_LO, MUL_HI, MAD64, MUL24, SH64, LSHLADD64, CMP64_CND, SH32, ALIGNBIT, BFE, ANDOR, PERM, CNDMASK, BFREV, MINU32, CMP32_CND, DPP_MOV, DPP_ADD, MOV, LSHL_OR, XOR3ISH, ADDC64, ANDOR2, SUB, LSHLADD32, CMP_ONLY, CMP_CND2, CMP_CND4, CND_SGPR, CMP64_CND2, MOV64, READLANE, NOT, OR3, BITOP3, FFBL, MBCNT, SHL32, SHR32, MIN64EMU, CMP_CND3_SGPR, CMP_CND3_SPACED, NMODES };
+enum { ADDXOR, ADD3, MUL_LO, MUL_HI, MAD64, MUL24, SH64, LSHLADD64, CMP64_CND, SH32, ALIGNBIT, BFE, ANDOR, PERM, CNDMASK, BFREV, MINU32, CMP32_CND, DPP_MOV, DPP_ADD, MOV, LSHL_OR, XOR3ISH, ADDC64, ANDOR2, SUB, LSHLADD32, CMP_ONLY, CMP_CND2, CMP_CND4, CND_SGPR, CMP64_CND2, MOV64, READLANE, NOT, OR3, BITOP3, FFBL, MBCNT, SHL32, SHR32, MIN64EMU, CMP_CND3_SGPR, CMP_CND3_SPACED, MIN_F64, NMODES };
 static const char *names[NMODES] = {"v_add_u32 / v_xor_b32", "v_add3_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24", "v_lshlrev_b64 / v_lshrrev_b64",
     "v_lshl_add_u64", "v_cmp_lt_u64 + v_cndmask_b32", "v_lshlrev_b32 / v_lshrrev_b32", "v_alignbit_b32", "v_bfe_u32", "v_and_or_b32", "v_perm_b32", "v_cndmask_b32 (vcc fixed)",
     "v_bfrev_b32", "v_min_u32", "v_cmp_lt_u32 + v_cndmask_b32", "v_mov_b32 dpp row_shr:1", "v_add_u32 dpp row_shr:1", "v_mov_b32", "v_lshl_or_b32", "v_xad_u32", "v_add_co_u32 + v_addc_co_u32",
     "v_and_b32 / v_or_b32", "v_sub_u32", "v_lshl_add_u32", "v_cmp_lt_u32 (vcc) alone", "v_cmp_lt_u32 + 2 v_cndmask_b32", "v_cmp_lt_u32 + 3 v_cndmask_b32 (vcc)", "v_cndmask_b32_e64 (sgpr mask fixed)", "v_cmp_lt_u64 + 2 v_cndmask_b32 (64-bit min)",
-    "v_mov_b64", "v_readlane_b32 / v_writelane_b32", "v_not_b32", "v_or3_b32", "v_bitop3_b32", "v_ffbl_b32", "v_mbcnt_lo + v_mbcnt_hi", "v_lshlrev_b32 alone", "v_lshrrev_b32 alone", "64-bit min as sub/subb + 2 cndmask (per 4)", "v_cmp_lt_u32_e64 s[20:21] + 3 v_cndmask_b32_e64", "v_cmp_lt_u32 + (v_cndmask, v_add) x 3 (vcc)"};
+    "v_mov_b64", "v_readlane_b32 / v_writelane_b32", "v_not_b32", "v_or3_b32", "v_bitop3_b32", "v_ffbl_b32", "v_mbcnt_lo + v_mbcnt_hi", "v_lshlrev_b32 alone", "v_lshrrev_b32 alone", "64-bit min as sub/subb + 2 cndmask (per 4)", "v_cmp_lt_u32_e64 s[20:21] + 3 v_cndmask_b32_e64", "v_cmp_lt_u32 + (v_cndmask, v_add) x 3 (vcc)", "v_min_f64 (64-bit minimum of sign-free, NaN-free bit patterns)"};
 // class key used by tools/valu_floor.py to map ISA mnemonics onto a measured rate
 static const char *keys[NMODES] = {"add32", "add3", "mul_lo", "mul_hi", "mad64", "mul24", "shift64", "lshl_add64", "cmp64_cnd", "shift32", "alignbit", "bfe", "and_or", "perm", "cndmask",
     "bfrev", "min32", "cmp32_cnd", "dpp_mov", "dpp_add", "mov", "lshl_or", "xad", "addc64",
-    "and_or32", "sub32", "lshl_add32", "cmp32", "cmp32_cnd2", "cmp32_cnd4", "cnd_sgpr", "cmp64_cnd2", "mov64", "lane", "not", "or3", "bitop3", "ffbl", "mbcnt", "shl32", "shr32", "min64emu", "cmp32_cnd3_sgpr", "cmp32_cnd3_spaced"};
+    "and_or32", "sub32", "lshl_add32", "cmp32", "cmp32_cnd2", "cmp32_cnd4", "cnd_sgpr", "cmp64_cnd2", "mov64", "lane", "not", "or3", "bitop3", "ffbl", "mbcnt", "shl32", "shr32", "min64emu", "cmp32_cnd3_sgpr", "cmp32_cnd3_spaced", "min_f64"};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t seed, int iters)
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t seed, int iters
         if (MODE == MIN64EMU) { REP8(asm volatile("v_sub_co_u32 %4, vcc, %0, %2\n v_subb_co_u32 %4, vcc, %1, %3, vcc\n v_cndmask_b32 %0, %2, %0, vcc\n v_cndmask_b32 %1, %3, %1, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc");) }
         if (MODE == CMP_CND3_SGPR) { REP8(asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 %2, %2, %3, s[20:21]\n v_cndmask_b32_e64 %3, %3, %0, s[20:21]\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "s20", "s21");) }
         if (MODE == CMP_CND3_SPACED) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_add_u32 %1, %1, %4\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc");) }
+        if (MODE == MIN_F64) { REP8(asm volatile("v_min_f64 %0, %0, %1\n v_min_f64 %1, %1, %0\n v_min_f64 %0, %0, %1\n v_min_f64 %1, %1, %0" : "+v"(x), "+v"(y));) }
         if (MODE == ADDC64) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %2, vcc, %2, %0\n v_addc_co_u32 %3, vcc, %3, %1, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + x + y;
